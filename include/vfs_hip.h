@@ -1,0 +1,121 @@
+/* libvfs_hip.so -- C ABI of the MI355X (gfx950) VFS hot path.
+ *
+ * The reference (xvjiarui/VFS) has no native code: every function below replaces a torch /
+ * mmcv call site of its Python hot path (file:line under /root/reference cited per entry).
+ * A maintainer of the reference binds these with ctypes underneath the
+ * same registry classes (ResNet / SimSiamHead / CosineSimLoss / SimSiamBaseTracker /
+ * VanillaTracker); vfs_amd/ is exactly that binding.
+ *
+ * Conventions
+ *   - the caller owns every buffer (device pointers from its allocator); the library keeps no
+ *     device state and never synchronises: all work is enqueued on `stream` (a hipStream_t)
+ *   - activations: bf16 NHWC; packed weights: bf16 [Cout][KH][KW][Cin] (forward) and
+ *     [Cin][KH][KW][Cout] (dgrad); master parameters / gradients: fp32 in the reference's
+ *     layouts (OIHW conv, [out][in] linear) so state_dicts stay interchangeable
+ *   - return 0 on success, negative on error; vfs_last_error() gives the message
+ *   - thread-safe per stream; one process per GPU
+ */
+#ifndef VFS_HIP_H
+#define VFS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vfs_stream_t; /* hipStream_t */
+typedef uint16_t vfs_bf16;
+
+const char* vfs_last_error(void);
+int vfs_abi_version(void);
+
+/* ---- input / parameter layout -------------------------------------------------------------
+ * imgs fp32 [B][2][3][T][H][W] (pipelines/formating.py:248-258) -> bf16 NHWC4 frames
+ * out[(v*B+b)*T+t][h][w][4], i.e. video2images(imgs[:, v]) per view
+ * (sim_siam_base_tracker.py:65-68, common/utils.py:45-53); width padded to even Wp with zeros */
+int vfs_imgs_to_nhwc4(const float* imgs, vfs_bf16* out, int B, int V, int T, int H, int W, int Wp,
+                      vfs_stream_t stream);
+
+/* table-driven repack of ALL fp32 master weights into the bf16 MFMA layouts in one launch.
+ * desc: device array of ntensors records {w, wf, wd, start, Cout, Cin, KH, KW, kind, 0}
+ * (8-byte pointers/int64 then 6 int32; kind 1 = 7x7 stem -> [64][8][8][4]) */
+int vfs_pack_weights(const void* desc, int ntensors, long long total_elems, vfs_stream_t stream);
+
+/* ---- convolution / linear: torch conv2d & linear call sites ---------------------------------
+ * forward  (resnet.py:51-73,163-191,267-277 via mmcv ConvModule; sim_siam_head.py:78-111):
+ *   y[N,Ho,Wo,Cout] = conv(x[N,H,W,Cin], wf) (+ bias)          Cin % 64 == 0, Cout % 64 == 0
+ *   stats (optional): float[ceil(N*Ho*Wo/128)][2][Cout] per-128-pixel-block (sum, sumsq) of the
+ *   stored bf16 outputs -- the BatchNorm batch statistics, free in the GEMM epilogue */
+int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats,
+                 int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                 int pad, vfs_stream_t stream);
+/* 7x7/2 stem conv (resnet.py:422-434) on NHWC4 input, wf = [64][8][8][4] */
+int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* stats, int N, int H,
+                 int Wp, int Ho, int Wo, vfs_stream_t stream);
+/* dgrad (autograd of the above): dx[N,H,W,Cin] = conv_transpose(dy[N,Ho,Wo,Cout], wd) (+ add) */
+int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, int N,
+                   int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                   int pad, vfs_stream_t stream);
+/* wgrad: grad[Cout][Cin][KH][KW] (fp32, reference OIHW layout) += sum_pixels dy * im2col(x).
+ * partial: workspace float[nsplit][Cout][KH*KW*Cin]; pix_per_split % 64 == 0 and
+ * nsplit*pix_per_split >= N*Ho*Wo.  Deterministic (fixed-order split-K reduction). */
+int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float* grad, int N, int H,
+                   int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                   int nsplit, int pix_per_split, vfs_stream_t stream);
+int vfs_stem_wgrad(const vfs_bf16* dy, const vfs_bf16* x4, float* partial, float* grad, int N, int H,
+                   int Wp, int Ho, int Wo, int nsplit, int pix_per_split, vfs_stream_t stream);
+/* db[Cout] += column sums of dy[M][Cout] (linear bias gradient) */
+int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stream);
+
+/* ---- BatchNorm / SyncBN + activation (torch batch_norm in ConvModule; configs/r*_*.py:9,15) ------
+ * G = number of independent BN batches inside the tensor (the two views), bpg partial blocks
+ * per group.  sums: double[G][2][C]; between reduce_partials and finalize the host all-reduces
+ * `sums` across ranks for SyncBN (count = global element count per channel per group).
+ * bnp: float[G][4][C] = {scale, shift, mean, invstd}. */
+int vfs_bn_reduce_partials(const float* partial, double* sums, int G, int bpg, int C,
+                           vfs_stream_t stream);
+int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp,
+                    float* running_mean, float* running_var, int G, int C, double count, float eps,
+                    float momentum, vfs_stream_t stream);
+int vfs_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float* bnp, int C, float eps, vfs_stream_t stream);
+/* y = [relu](x*scale+shift [+res] [+ rres*rscale+rshift])   (resnet.py:102-111,221-230) */
+int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres,
+               const float* rbnp, vfs_bf16* y, long long M, int C, int mpg, int relu,
+               vfs_stream_t stream);
+/* stem: y = maxpool3x3/2/1(relu(bn(x)))  (resnet.py:435), idx = argmax code per element */
+int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, int N, int H,
+                        int W, int C, int Hp, int Wp, int npg, vfs_stream_t stream);
+int vfs_maxpool_relu_bwd(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, vfs_bf16* ga,
+                         int N, int H, int W, int C, int Hp, int Wp, vfs_stream_t stream);
+/* BN backward: pass 1 -> partial[nblk][2][C] (S1 = sum gm, S2 = sum gm*xhat, gm = g*(y>0));
+ * then vfs_bn_reduce_partials -> sums (all-reduce for SyncBN) -> pass 2 */
+int vfs_bn_bwd_reduce(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp,
+                      float* partial, long long M, int C, int mpg, int ppb, vfs_stream_t stream);
+int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp,
+                     const double* sums, vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg,
+                     double count, vfs_stream_t stream);
+int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C,
+                      vfs_stream_t stream);
+
+/* ---- head: AdaptiveAvgPool2d((1,1)) + flatten (sim_siam_head.py:117,154-157) ---------------- */
+int vfs_avgpool_fwd(const vfs_bf16* x, vfs_bf16* y, int N, int HW, int C, vfs_stream_t stream);
+int vfs_avgpool_bwd(const vfs_bf16* g, vfs_bf16* gx, int N, int HW, int C, vfs_stream_t stream);
+
+/* ---- CosineSimLoss over all temporal rolls (sim_loss.py:42-63, sim_siam_head.py:165-174,
+ * sim_siam_base_tracker.py:31-56).  loss/gloss: float[K][N]; K = T (intra_video) or 1 */
+int vfs_cosine_loss_fwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2,
+                        const vfs_bf16* z2, float* loss, int N, int C, int T, int K, int negative,
+                        float weight, vfs_stream_t stream);
+int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2,
+                        const vfs_bf16* z2, const float* gloss, vfs_bf16* dp1, vfs_bf16* dp2, int N,
+                        int C, int T, int K, int negative, float weight, vfs_stream_t stream);
+
+/* ---- optimizer: torch.optim.SGD(lr, momentum, weight_decay) (configs/r*_*.py:134) on flat arenas --- */
+int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
+                 float momentum, float weight_decay, vfs_stream_t stream);
+int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,382 @@
+// CPU emulation of the HIP subset the vfs_amd kernels use -- TEST INFRASTRUCTURE.
+//
+// The kernels under vfs_amd/csrc are compiled UNMODIFIED by host clang with
+// `-I tests/emu` so that `#include <hip/hip_runtime.h>` resolves here.  One OS
+// thread runs one workgroup at a time; the workgroup's threads are ucontext
+// fibers scheduled round-robin, yielding at __syncthreads() and at wave-level
+// collectives (shuffles, ballots, MFMA).  MFMA builtins are emulated from the
+// documented gfx950 fragment layouts (cdna_hip_programming.md section 3):
+//   16x16x32 bf16: A[i][k] in lane i+16*(k/8) elem k%8, B[k][j] in lane
+//   j+16*(k/8) elem k%8, D[4*(lane>>4)+r][lane&15] in reg r;
+//   32x32x16 bf16: A[i][k] in lane i+32*(k/8), D[(r&3)+8*(r>>2)+4*(lane>>5)][lane&31].
+// This checks index math, LDS layouts, epilogues and reductions on the CPU; it
+// does not model timing, bank conflicts or the memory model.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define VFS_EMU 1
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+static const hipError_t hipSuccess = 0;
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  memset(p, v, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+static const int hipMemcpyDeviceToDevice = 3;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+namespace emu {
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  dim3 tid;
+  int lin = 0;
+  bool done = false;
+};
+
+struct WaveX {  // per-wave exchange area
+  uint32_t u32[64];
+  uint64_t u64[64];
+  short a[64][8];
+  short b[64][8];
+  int count = 0;
+  int gen = 0;
+};
+
+struct BlockCtx {
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  int cur = 0;
+  int nthreads = 0;
+  int bar_count = 0, bar_gen = 0;
+  std::vector<WaveX> waves;
+  dim3 bid, bdim, gdim;
+  std::function<void()> body;
+};
+
+inline thread_local BlockCtx* B = nullptr;
+
+inline void yield() { swapcontext(&B->fibers[B->cur].ctx, &B->sched); }
+
+inline void block_barrier() {
+  int gen = B->bar_gen;
+  if (++B->bar_count == B->nthreads) {
+    B->bar_count = 0;
+    B->bar_gen++;
+  } else {
+    while (B->bar_gen == gen) yield();
+  }
+}
+
+inline int lane_id() { return B->fibers[B->cur].lin & 63; }
+inline int wave_id() { return B->fibers[B->cur].lin >> 6; }
+inline int wave_size(int w) { return std::min(64, B->nthreads - w * 64); }
+
+inline void wave_barrier() {
+  WaveX& W = B->waves[wave_id()];
+  int gen = W.gen;
+  if (++W.count == wave_size(wave_id())) {
+    W.count = 0;
+    W.gen++;
+  } else {
+    while (W.gen == gen) yield();
+  }
+}
+
+static void fiber_entry() {
+  B->body();
+  B->fibers[B->cur].done = true;
+  swapcontext(&B->fibers[B->cur].ctx, &B->sched);
+}
+
+inline void run_block(BlockCtx& ctx) {
+  B = &ctx;
+  const size_t STK = 256 * 1024;
+  int n = ctx.nthreads;
+  for (int i = 0; i < n; ++i) {
+    Fiber& f = ctx.fibers[i];
+    f.done = false;
+    if (!f.stack) f.stack = (char*)malloc(STK);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STK;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+  }
+  ctx.bar_count = 0;
+  for (auto& w : ctx.waves) w.count = 0;
+  int remaining = n;
+  while (remaining > 0) {
+    int progressed = 0;
+    for (int i = 0; i < n; ++i) {
+      if (ctx.fibers[i].done) continue;
+      ctx.cur = i;
+      swapcontext(&ctx.sched, &ctx.fibers[i].ctx);
+      if (ctx.fibers[i].done) --remaining;
+      ++progressed;
+    }
+    if (!progressed) break;
+  }
+}
+
+template <typename K, typename... Args>
+inline void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+  size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  int nthreads = block.x * block.y * block.z;
+  unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  unsigned nworkers = (unsigned)std::min<size_t>(hw, nblocks);
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    BlockCtx ctx;
+    ctx.nthreads = nthreads;
+    ctx.fibers.resize(nthreads);
+    ctx.waves.resize((nthreads + 63) / 64);
+    ctx.bdim = block;
+    ctx.gdim = grid;
+    for (int i = 0; i < nthreads; ++i) {
+      ctx.fibers[i].lin = i;
+      ctx.fibers[i].tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+    }
+    ctx.body = [&]() { kernel(args...); };
+    for (;;) {
+      size_t b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      ctx.bid = dim3(b % grid.x, (b / grid.x) % grid.y, b / ((size_t)grid.x * grid.y));
+      run_block(ctx);
+    }
+    for (auto& f : ctx.fibers) free(f.stack);
+    B = nullptr;
+  };
+  if (nworkers <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nworkers; ++i) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+}
+
+// ---- wave collectives -----------------------------------------------------
+inline uint32_t shfl_u32(uint32_t v, int src) {
+  WaveX& W = B->waves[wave_id()];
+  W.u32[lane_id()] = v;
+  wave_barrier();
+  uint32_t r = W.u32[src & 63];
+  wave_barrier();
+  return r;
+}
+inline uint64_t ballot(int pred) {
+  WaveX& W = B->waves[wave_id()];
+  W.u32[lane_id()] = pred ? 1u : 0u;
+  wave_barrier();
+  uint64_t m = 0;
+  for (int i = 0; i < wave_size(wave_id()); ++i) m |= (uint64_t)(W.u32[i] & 1) << i;
+  wave_barrier();
+  return m;
+}
+template <typename T>
+inline T shfl_t(T v, int src) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "shfl size");
+  if (sizeof(T) == 4) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u = shfl_u32(u, src);
+    T r;
+    memcpy(&r, &u, 4);
+    return r;
+  } else {
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    uint32_t lo = shfl_u32((uint32_t)u, src), hi = shfl_u32((uint32_t)(u >> 32), src);
+    u = ((uint64_t)hi << 32) | lo;
+    T r;
+    memcpy(&r, &u, 8);
+    return r;
+  }
+}
+
+inline float bf16_to_f32(short s) {
+  uint32_t u = ((uint32_t)(uint16_t)s) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+typedef __attribute__((ext_vector_type(8))) short v8s;
+typedef __attribute__((ext_vector_type(4))) float v4f;
+typedef __attribute__((ext_vector_type(16))) float v16f;
+
+inline v4f mfma_16x16x32_bf16(v8s a, v8s b, v4f c) {
+  WaveX& W = B->waves[wave_id()];
+  int l = lane_id();
+  for (int i = 0; i < 8; ++i) {
+    W.a[l][i] = a[i];
+    W.b[l][i] = b[i];
+  }
+  wave_barrier();
+  v4f d = c;
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k)
+      acc = fmaf(bf16_to_f32(W.a[row + 16 * (k >> 3)][k & 7]), bf16_to_f32(W.b[col + 16 * (k >> 3)][k & 7]), acc);
+    d[r] = acc;
+  }
+  wave_barrier();
+  return d;
+}
+
+inline v16f mfma_32x32x16_bf16(v8s a, v8s b, v16f c) {
+  WaveX& W = B->waves[wave_id()];
+  int l = lane_id();
+  for (int i = 0; i < 8; ++i) {
+    W.a[l][i] = a[i];
+    W.b[l][i] = b[i];
+  }
+  wave_barrier();
+  v16f d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k)
+      acc = fmaf(bf16_to_f32(W.a[row + 32 * (k >> 3)][k & 7]), bf16_to_f32(W.b[col + 32 * (k >> 3)][k & 7]), acc);
+    d[r] = acc;
+  }
+  wave_barrier();
+  return d;
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::B->fibers[emu::B->cur].tid)
+#define blockIdx (emu::B->bid)
+#define blockDim (emu::B->bdim)
+#define gridDim (emu::B->gdim)
+#define warpSize 64
+
+inline void __syncthreads() { emu::block_barrier(); }
+#define __builtin_amdgcn_s_barrier() emu::block_barrier()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  int l = emu::lane_id();
+  return emu::shfl_t(v, (l & ~(width - 1)) | (src & (width - 1)));
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  return emu::shfl_t(v, emu::lane_id() ^ mask);
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int l = emu::lane_id();
+  int src = l + (int)d;
+  if ((src & ~(width - 1)) != (l & ~(width - 1))) src = l;
+  return emu::shfl_t(v, src);
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned d, int width = 64) {
+  int l = emu::lane_id();
+  int src = l - (int)d;
+  if (src < 0 || (src & ~(width - 1)) != (l & ~(width - 1))) src = l;
+  return emu::shfl_t(v, src);
+}
+inline unsigned long long __ballot(int p) { return emu::ballot(p); }
+inline int __any(int p) { return emu::ballot(p) != 0; }
+inline int __all(int p) {
+  int n = emu::wave_size(emu::wave_id());
+  unsigned long long full = n == 64 ? ~0ull : ((1ull << n) - 1);
+  return emu::ballot(p) == full;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll(x); }
+
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
+#define __builtin_amdgcn_readfirstlane(x) __shfl((x), 0)
+
+template <typename T>
+inline T atomicAdd(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (!__atomic_compare_exchange_n(p, &old, old + v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return old;
+}
+template <>
+inline float atomicAdd<float>(float* p, float v) {
+  uint32_t* ip = (uint32_t*)p;
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
+  for (;;) {
+    float f;
+    memcpy(&f, &old, 4);
+    f += v;
+    uint32_t nu;
+    memcpy(&nu, &f, 4);
+    if (__atomic_compare_exchange_n(ip, &old, nu, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+      float r;
+      memcpy(&r, &old, 4);
+      return r;
+    }
+  }
+}
+template <>
+inline double atomicAdd<double>(double* p, double v) {
+  uint64_t* ip = (uint64_t*)p;
+  uint64_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
+  for (;;) {
+    double f;
+    memcpy(&f, &old, 8);
+    f += v;
+    uint64_t nu;
+    memcpy(&nu, &f, 8);
+    if (__atomic_compare_exchange_n(ip, &old, nu, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+      double r;
+      memcpy(&r, &old, 8);
+      return r;
+    }
+  }
+}
+
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __expf(float x) { return expf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float __frcp_rn(float a) { return 1.0f / a; }
+using std::max;
+using std::min;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  emu::launch(kernel, dim3(grid), dim3(block), ##__VA_ARGS__)

@@ -1,0 +1,170 @@
+"""BatchNorm / pooling / loss / SGD kernels through the CPU fiber emulator vs torch.  CPU only."""
+import torch
+import torch.nn.functional as F
+
+from oracle import vfs_oracle as O
+from tests.emu_util import emu_lib, nchw, nhwc, rb, relerr
+
+
+def bn_forward_chain(lib, x_nhwc, gamma, beta, G, rm, rv):
+    """stats from a [M][C] bf16 tensor via the same kernels the engine chains after a conv."""
+    M, C = x_nhwc.reshape(-1, x_nhwc.shape[-1]).shape
+    mpg = M // G
+    ppb = 128 if mpg % 128 == 0 else mpg
+    # emulate the conv epilogue partials with torch (the conv test checks the real ones)
+    xf = x_nhwc.float().reshape(M, C)
+    nblk = M // ppb
+    partial = torch.stack([torch.stack([xf[b * ppb:(b + 1) * ppb].sum(0), (xf[b * ppb:(b + 1) * ppb] ** 2).sum(0)])
+                           for b in range(nblk)])
+    sums = torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_reduce_partials(partial, sums, G, nblk // G, C, None)
+    bnp = torch.zeros(G, 4, C)
+    lib.bn_finalize(sums, gamma, beta, bnp, rm, rv, G, C, float(mpg), 1e-5, 0.1, None)
+    return bnp, mpg
+
+
+def test_bn_train_forward_two_groups_and_residuals():
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(0)
+    N, C, H, W, G = 4, 64, 8, 8, 2
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.zeros(C), torch.ones(C)
+    bnp, mpg = bn_forward_chain(lib, nhwc(x), gamma, beta, G, rm, rv)
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.copy_(gamma); bn.bias.data.copy_(beta)
+    bn.train()
+    refs = [bn(x[:2]), bn(x[2:])]            # two separate BN calls, like the two views
+    ref = torch.cat(refs).detach()
+    assert relerr(rm, bn.running_mean) < 1e-5 and relerr(rv, bn.running_var) < 1e-5
+    M = N * H * W
+    y = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.bn_act(nhwc(x), bnp, None, None, None, y, M, C, mpg, 1, None)
+    assert relerr(nchw(y), F.relu(ref)) < 6e-3
+    res = rb(torch.randn(N, C, H, W, generator=g))
+    lib.bn_act(nhwc(x), bnp, nhwc(res), None, None, y, M, C, mpg, 1, None)
+    assert relerr(nchw(y), F.relu(ref + res)) < 6e-3
+    lib.bn_act(nhwc(x), bnp, None, nhwc(res), bnp, y, M, C, mpg, 0, None)   # raw residual with its own BN
+    ref_r = torch.cat([bn(res[:2]), bn(res[2:])]).detach()   # NOTE: uses res's own batch stats
+    bnp_r, _ = bn_forward_chain(lib, nhwc(res), gamma, beta, G, torch.zeros(C), torch.ones(C))
+    lib.bn_act(nhwc(x), bnp, None, nhwc(res), bnp_r, y, M, C, mpg, 0, None)
+    assert relerr(nchw(y), ref + ref_r) < 6e-3
+    # eval-mode parameters
+    bnp_e = torch.zeros(1, 4, C)
+    lib.bn_eval_params(gamma, beta, bn.running_mean, bn.running_var, bnp_e, C, 1e-5, None)
+    bn.eval()
+    lib.bn_act(nhwc(x), bnp_e, None, None, None, y, M, C, M, 0, None)
+    assert relerr(nchw(y), bn(x).detach()) < 6e-3
+
+
+def test_bn_backward_matches_autograd():
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(1)
+    N, C, H, W, G = 4, 128, 4, 8, 2
+    x = rb(torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    bnp, mpg = bn_forward_chain(lib, nhwc(x), gamma, beta, G, torch.zeros(C), torch.ones(C))
+    M = N * H * W
+    y = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.bn_act(nhwc(x), bnp, None, None, None, y, M, C, mpg, 1, None)
+    gout = rb(torch.randn(N, C, H, W, generator=g))
+    # autograd reference per group, on the same rounded tensors
+    xs = x.clone().requires_grad_(True)
+    gm_, bt_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    outs = [F.relu(F.batch_norm(xs[i:i + 2], None, None, gm_, bt_, True, 0.1, 1e-5)) for i in (0, 2)]
+    torch.cat(outs).backward(gout * (nchw(y) > 0))   # mask by the STORED activation like the kernel
+    ppb = 32
+    nblk = M // ppb
+    partial = torch.zeros(nblk, 2, C)
+    lib.bn_bwd_reduce(nhwc(gout), y, nhwc(x), bnp, partial, M, C, mpg, ppb, None)
+    sums = torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_reduce_partials(partial, sums, G, nblk // G, C, None)
+    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    gmask = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.bn_bwd_apply(nhwc(gout), y, nhwc(x), bnp, sums, dx, gmask, M, C, mpg, float(mpg), None)
+    assert relerr(nchw(dx), xs.grad) < 8e-3
+    assert torch.equal(nchw(gmask), gout * (nchw(y) > 0))
+    dgamma, dbeta = torch.zeros(C), torch.zeros(C)
+    lib.bn_param_grad(sums, dgamma, dbeta, G, C, None)
+    assert relerr(dgamma, gm_.grad) < 1e-4 and relerr(dbeta, bt_.grad) < 1e-4
+
+
+def test_stem_bn_relu_maxpool_fwd_bwd():
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(2)
+    N, C, H, W = 2, 64, 10, 12
+    x = rb(torch.randn(N, C, H, W, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    bnp, _ = bn_forward_chain(lib, nhwc(x), gamma, beta, 1, torch.zeros(C), torch.ones(C))
+    Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(N, Hp, Wp, C, dtype=torch.bfloat16)
+    idx = torch.empty(N, Hp, Wp, C, dtype=torch.uint8)
+    lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, N, H, W, C, Hp, Wp, N, None)
+    a = rb(F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5)))
+    a.requires_grad_(True)
+    ref = F.max_pool2d(a, 3, 2, 1)
+    # the kernel pools bf16(relu(bn(x))) computed with its own fp32 scale/shift: allow 1 bf16 ulp
+    assert relerr(nchw(y), ref) < 8e-3
+    gp = rb(torch.randn(N, C, Hp, Wp, generator=g))
+    ref.backward(gp)
+    ga = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.maxpool_relu_bwd(nhwc(gp), y, idx, ga, N, H, W, C, Hp, Wp, None)
+    want = a.grad * (a.detach() > 0)
+    got = nchw(ga)
+    # argmax ties between equal bf16 activations may route differently only if the kernel's
+    # activation differs by an ulp from torch's; require near-total agreement
+    frac = ((got - want).abs() > 1e-2 * want.abs().max()).float().mean()
+    assert frac < 2e-3, frac
+
+
+def test_avgpool_bias_loss_sgd():
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(3)
+    N, HW, C = 8, 6, 128
+    x = rb(torch.randn(N, HW, C, generator=g))
+    y = torch.empty(N, C, dtype=torch.bfloat16)
+    lib.avgpool_fwd(x.to(torch.bfloat16), y, N, HW, C, None)
+    assert relerr(y.float(), x.mean(1)) < 6e-3
+    gy = rb(torch.randn(N, C, generator=g))
+    gx = torch.empty(N, HW, C, dtype=torch.bfloat16)
+    lib.avgpool_bwd(gy.to(torch.bfloat16), gx, N, HW, C, None)
+    assert relerr(gx.float(), (gy / HW)[:, None, :].expand(N, HW, C)) < 6e-3
+    db = torch.ones(C)
+    lib.bias_grad(gy.to(torch.bfloat16), db, N, C, None)
+    assert relerr(db - 1, gy.sum(0)) < 1e-5
+
+    # cosine loss with temporal rolls (T=4, K=4) and without (T=1)
+    for T, K in ((4, 4), (1, 1), (4, 1)):
+        p1, z1, p2, z2 = (rb(torch.randn(N, C, generator=g)) for _ in range(4))
+        w = 1.0 / T if K > 1 else 1.0
+        loss = torch.empty(K, N)
+        args = [t.to(torch.bfloat16) for t in (p1, z1, p2, z2)]
+        lib.cosine_loss_fwd(*args, loss, N, C, T, K, 0, w, None)
+        p1r, p2r = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+        refs = [O.head_loss(p1r, z1, p2r, z2, w)]
+        if K > 1:
+            z2v, p2v = O.images2video(z2, T), O.images2video(p2r, T)
+            for i in range(1, T):
+                refs.append(O.head_loss(p1r, z1, O.video2images(p2v.roll(i, dims=2)),
+                                        O.video2images(z2v.roll(i, dims=2)), w))
+        ref = torch.stack(refs)
+        assert relerr(loss, ref.detach()) < 1e-5, (T, K)
+        gl = torch.randn(K, N, generator=g)
+        (ref * gl).sum().backward()
+        dp1 = torch.empty(N, C, dtype=torch.bfloat16)
+        dp2 = torch.empty(N, C, dtype=torch.bfloat16)
+        lib.cosine_loss_bwd(*args, gl, dp1, dp2, N, C, T, K, 0, w, None)
+        assert relerr(dp1.float(), p1r.grad) < 6e-3 and relerr(dp2.float(), p2r.grad) < 6e-3, (T, K)
+
+    # SGD, three steps against torch.optim.SGD
+    n = 1027
+    p = torch.randn(n, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.05, momentum=0.9, weight_decay=1e-4)
+    buf = torch.zeros(n)
+    for _ in range(3):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        lib.sgd_step(p, gr, buf, n, 0.05, 0.9, 1e-4, None)
+    assert relerr(p, pr.detach()) < 1e-6

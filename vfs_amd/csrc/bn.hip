@@ -1,0 +1,357 @@
+// BatchNorm (training mode, per-group batch statistics), activation, residual and the stem
+// max-pool for NHWC bf16 tensors on gfx950 -- all HBM-bound, 16 bytes (8 channels) per lane.
+//
+// Replaces torch batch_norm / SyncBatchNorm + relu + residual add + max_pool2d as the reference
+// composes them (mmcv ConvModule conv->norm->act; resnet.py:102-111,221-230,435; configs/*:9,15)
+// and their autograd backward.  "Groups" are independent BN batches inside one tensor: the two
+// augmented views of forward_train (sim_siam_base_tracker.py:69-70) are separate backbone calls
+// in the reference, so their statistics must not be merged.
+//
+// bnp layout (per layer): float[G][4][C] = {scale = gamma*invstd, shift = beta - mean*scale,
+//                                           mean, invstd}
+#include "vfs_ops.h"
+
+// ------------------------------------------------------------------------------------------
+// partial[nblk][2][C] (fp32, one per producer block) -> sums[G][2][C] (fp64), fixed order.
+// group gi owns blocks [gi*bpg, (gi+1)*bpg).
+__global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ partial,
+                                                                 double* __restrict__ sums, int bpg, int C) {
+  __shared__ double sh[8][2][32];
+  const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
+  const int c = blockIdx.x * 32 + cl, gi = blockIdx.y;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    const float* p = partial + (size_t)gi * bpg * 2 * C;
+    for (int b = sl; b < bpg; b += 8) {
+      a0 += (double)p[(size_t)b * 2 * C + c];
+      a1 += (double)p[(size_t)b * 2 * C + C + c];
+    }
+  }
+  sh[sl][0][cl] = a0;
+  sh[sl][1][cl] = a1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { r0 += sh[s][0][cl]; r1 += sh[s][1][cl]; }
+    sums[((size_t)gi * 2 + 0) * C + c] = r0;
+    sums[((size_t)gi * 2 + 1) * C + c] = r1;
+  }
+}
+
+// sums[G][2][C] (sum x, sum x^2; already all-reduced across ranks for SyncBN) + count ->
+// bnp, and the running statistics updated group after group (each group is one BN call of the
+// reference: running = (1-momentum)*running + momentum*stat, unbiased variance).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ bnp,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          int G, int C, double count, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  for (int gi = 0; gi < G; ++gi) {
+    const double mean = sums[((size_t)gi * 2) * C + c] / count;
+    double var = sums[((size_t)gi * 2 + 1) * C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * invstd;
+    float* o = bnp + (size_t)gi * 4 * C;
+    o[c] = scale;
+    o[C + c] = beta[c] - (float)mean * scale;
+    o[2 * C + c] = (float)mean;
+    o[3 * C + c] = invstd;
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rm = (1.f - momentum) * rm + momentum * (float)mean;
+    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+  }
+  if (running_mean) running_mean[c] = rm;
+  if (running_var) running_var[c] = rv;
+}
+
+// eval-mode BN: bnp from running statistics (G = 1)
+__global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ running_mean,
+                                                             const float* __restrict__ running_var, float* __restrict__ bnp,
+                                                             int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float scale = gamma[c] * invstd;
+  bnp[c] = scale;
+  bnp[C + c] = beta[c] - running_mean[c] * scale;
+  bnp[2 * C + c] = running_mean[c];
+  bnp[3 * C + c] = invstd;
+}
+
+__device__ __forceinline__ void ld8f(const float* p, float* f) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
+  f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
+
+__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
+  const int cv = a.C >> 3;
+  const long long total = a.M * cv;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    const long long m = v / cv;
+    const int c = (int)(v - m * cv) * 8;
+    const int gi = (int)(m / a.mpg);
+    const size_t o = (size_t)m * a.C + c;
+    float x[8], sc[8], sh[8];
+    unpack8(ld16(a.x + o), x);
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + c, sc);
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = x[i] * sc[i] + sh[i];
+    if (a.res) {
+      float r[8];
+      unpack8(ld16(a.res + o), r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] += r[i];
+    }
+    if (a.rres) {
+      float r[8];
+      unpack8(ld16(a.rres + o), r);
+      ld8f(a.rbnp + (size_t)gi * 4 * a.C + c, sc);
+      ld8f(a.rbnp + (size_t)gi * 4 * a.C + a.C + c, sh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] += r[i] * sc[i] + sh[i];
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = fmaxf(x[i], 0.f);
+    }
+    st16(a.y + o, pack8(x));
+  }
+}
+
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
+  const int cv = a.C >> 3;
+  const long long total = (long long)a.N * a.Hp * a.Wp * cv;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    long long p = v / cv;
+    const int c = (int)(v - p * cv) * 8;
+    const int wp = (int)(p % a.Wp); p /= a.Wp;
+    const int hp = (int)(p % a.Hp);
+    const int n = (int)(p / a.Hp);
+    const int gi = n / a.npg;
+    float sc[8], sh[8], best[8];
+    int bi[8];
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + c, sc);
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+    for (int dy = 0; dy < 3; ++dy) {
+      const int h = 2 * hp - 1 + dy;
+      if ((unsigned)h >= (unsigned)a.H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int w = 2 * wp - 1 + dx;
+        if ((unsigned)w >= (unsigned)a.W) continue;
+        float x[8];
+        unpack8(ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * a.C + c), x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float val = round_bf(fmaxf(x[i] * sc[i] + sh[i], 0.f));  // pool the STORED (bf16) activation
+          if (val > best[i]) { best[i] = val; bi[i] = dy * 3 + dx; }
+        }
+      }
+    }
+    const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
+    st16(a.y + o, pack8(best));
+    if (a.idx) {
+      u32x2 pk;
+      pk.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+      pk.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+      st8(a.idx + o, pk);
+    }
+  }
+}
+
+
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(PoolBwdArgs a) {
+  const int cv = a.C >> 3;
+  const long long total = (long long)a.N * a.H * a.W * cv;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    long long p = v / cv;
+    const int c = (int)(v - p * cv) * 8;
+    const int w = (int)(p % a.W); p /= a.W;
+    const int h = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+    // windows hp with 2hp-1 <= h <= 2hp+1
+    for (int hp = (h) >> 1; hp <= (h + 1) >> 1; ++hp) {
+      if (hp >= a.Hp) continue;
+      const int dy = h - (2 * hp - 1);
+      if (dy < 0 || dy > 2) continue;
+      for (int wp = (w) >> 1; wp <= (w + 1) >> 1; ++wp) {
+        if (wp >= a.Wp) continue;
+        const int dx = w - (2 * wp - 1);
+        if (dx < 0 || dx > 2) continue;
+        const unsigned code = (unsigned)(dy * 3 + dx);
+        const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
+        const u32x2 id = ld8(a.idx + o);
+        float gp[8], yp[8];
+        unpack8(ld16(a.gp + o), gp);
+        unpack8(ld16(a.yp + o), yp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned b = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;
+          if (b == code && yp[i] > 0.f) g[i] += gp[i];
+        }
+      }
+    }
+    st16(a.ga + (((size_t)n * a.H + h) * a.W + w) * a.C + c, pack8(g));
+  }
+}
+
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+  __shared__ float sh[256][17];
+  const int cv = a.C >> 3;          // chunk-threads per pixel (<=256)
+  const int rows = 256 / cv;        // pixels processed per step
+  const int t = threadIdx.x;
+  const int ct = t % cv, rt = t / cv;
+  const long long m0 = (long long)blockIdx.x * a.ppb;
+  const int gi = (int)(m0 / a.mpg);
+  const int c = ct * 8;
+  float s1[8], s2[8], mean[8], inv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (rt < rows) {
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + 2 * a.C + c, mean);
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
+    for (int r = rt; r < a.ppb; r += rows) {
+      const long long m = m0 + r;
+      if (m >= a.M) break;
+      const size_t o = (size_t)m * a.C + c;
+      float g[8], x[8];
+      unpack8(ld16(a.g + o), g);
+      unpack8(ld16(a.x + o), x);
+      if (a.y) {
+        float y[8];
+        unpack8(ld16(a.y + o), y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1[i] += g[i];
+        s2[i] += g[i] * ((x[i] - mean[i]) * inv[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sh[t][i] = s1[i]; sh[t][8 + i] = s2[i]; }
+  __syncthreads();
+  // thread (ct, i16) sums over the row-threads in fixed order
+  for (int e = t; e < cv * 16; e += 256) {
+    const int ec = e / 16, ei = e % 16;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += sh[r * cv + ec][ei];
+    const int ch = ec * 8 + (ei & 7);
+    a.partial[(size_t)blockIdx.x * 2 * a.C + (ei >> 3) * a.C + ch] = s;
+  }
+}
+
+// pass 2: dx = scale * (gm - S1/count - xhat * S2/count)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  const int cv = a.C >> 3;
+  const long long total = a.M * cv;
+  const float rc = (float)(1.0 / a.count);
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    const long long m = v / cv;
+    const int c = (int)(v - m * cv) * 8;
+    const int gi = (int)(m / a.mpg);
+    const size_t o = (size_t)m * a.C + c;
+    float g[8], x[8], sc[8], mean[8], inv[8];
+    unpack8(ld16(a.g + o), g);
+    unpack8(ld16(a.x + o), x);
+    if (a.y) {
+      float y[8];
+      unpack8(ld16(a.y + o), y);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+    }
+    const float* bp = a.bnp + (size_t)gi * 4 * a.C;
+    ld8f(bp + c, sc);
+    ld8f(bp + 2 * a.C + c, mean);
+    ld8f(bp + 3 * a.C + c, inv);
+    float d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float m1 = (float)a.sums[((size_t)gi * 2) * a.C + c + i] * rc;
+      const float m2 = (float)a.sums[((size_t)gi * 2 + 1) * a.C + c + i] * rc;
+      const float xh = (x[i] - mean[i]) * inv[i];
+      d[i] = sc[i] * (g[i] - m1 - xh * m2);
+    }
+    st16(a.dx + o, pack8(d));
+    if (a.gm) st16(a.gm + o, pack8(g));
+  }
+}
+
+// dgamma[c] += sum_g S2_local[g][c],  dbeta[c] += sum_g S1_local[g][c]  (local sums: DDP averages)
+__global__ __launch_bounds__(256) void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int G, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int gi = 0; gi < G; ++gi) {
+    s1 += sums[((size_t)gi * 2) * C + c];
+    s2 += sums[((size_t)gi * 2 + 1) * C + c];
+  }
+  dbeta[c] += (float)s1;
+  dgamma[c] += (float)s2;
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+static inline int grid_for(long long total_vec) {
+  long long b = (total_vec + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, int G, int bpg, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 31) / 32, G), dim3(256), 0, s, partial, sums, bpg, C);
+  return vfs_check_launch("bn_reduce_partials");
+}
+int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
+                           int G, int C, double count, float eps, float momentum, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, gamma, beta, bnp, rm, rv, G, C,
+                     count, eps, momentum);
+  return vfs_check_launch("bn_finalize");
+}
+int vfs_bn_eval_params_launch(const float* gamma, const float* beta, const float* rm, const float* rv, float* bnp, int C,
+                              float eps, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, bnp, C, eps);
+  return vfs_check_launch("bn_eval_params");
+}
+int vfs_bn_act_launch(const BnActArgs& a, hipStream_t s) {
+  if (a.C % 8) return vfs_set_error(VFS_ERR_SHAPE, "bn_act: C%8");
+  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(a.M * (a.C >> 3))), dim3(256), 0, s, a);
+  return vfs_check_launch("bn_act");
+}
+int vfs_bn_relu_maxpool_launch(const BnPoolArgs& a, hipStream_t s) {
+  if (a.C % 8) return vfs_set_error(VFS_ERR_SHAPE, "bn_relu_maxpool: C%8");
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for((long long)a.N * a.Hp * a.Wp * (a.C >> 3))), dim3(256), 0, s, a);
+  return vfs_check_launch("bn_relu_maxpool");
+}
+int vfs_maxpool_relu_bwd_launch(const PoolBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(grid_for((long long)a.N * a.H * a.W * (a.C >> 3))), dim3(256), 0, s, a);
+  return vfs_check_launch("maxpool_relu_bwd");
+}
+int vfs_bn_bwd_reduce_launch(const BnBwdArgs& a, int nblk, hipStream_t s) {
+  if (a.C % 8 || a.C > 2048 || 256 % (a.C >> 3)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_reduce: C must be 8*2^k <= 2048");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, a);
+  return vfs_check_launch("bn_bwd_reduce");
+}
+int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.M * (a.C >> 3))), dim3(256), 0, s, a);
+  return vfs_check_launch("bn_bwd_apply");
+}
+int vfs_bn_param_grad_launch(const double* sums, float* dgamma, float* dbeta, int G, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, dgamma, dbeta, G, C);
+  return vfs_check_launch("bn_param_grad");
+}

@@ -1,0 +1,180 @@
+// extern "C" entry points of libvfs_hip.so (declared in include/vfs_hip.h).
+#include <string.h>
+
+#include "../../include/vfs_hip.h"
+#include "vfs_conv.h"
+#include "vfs_ops.h"
+
+static thread_local char g_err[512] = "";
+
+int vfs_set_error(int code, const char* msg) {
+  strncpy(g_err, msg, sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+  return code;
+}
+int vfs_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char buf[400];
+    snprintf(buf, sizeof(buf), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return vfs_set_error(VFS_ERR_LAUNCH, buf);
+  }
+  return VFS_OK;
+}
+
+#define S(s) ((hipStream_t)(s))
+
+static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
+  ConvGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = Ktot;
+  g.M = N * Ho * Wo;
+  return g;
+}
+
+extern "C" {
+
+const char* vfs_last_error(void) { return g_err; }
+int vfs_abi_version(void) { return 1; }
+
+int vfs_imgs_to_nhwc4(const float* imgs, vfs_bf16* out, int B, int V, int T, int H, int W, int Wp, vfs_stream_t stream) {
+  if (Wp < W || (Wp & 1)) return vfs_set_error(VFS_ERR_SHAPE, "imgs_to_nhwc4: Wp must be even and >= W");
+  return vfs_imgs_to_nhwc4_launch(imgs, out, B, V, T, H, W, Wp, S(stream));
+}
+
+int vfs_pack_weights(const void* desc, int ntensors, long long total, vfs_stream_t stream) {
+  return vfs_pack_weights_launch((const PackDesc*)desc, ntensors, total, S(stream));
+}
+
+int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, int N, int H, int W,
+                 int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+  ConvArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout;
+  return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
+}
+
+int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* stats, int N, int H, int Wp, int Ho, int Wo,
+                 vfs_stream_t stream) {
+  if (Wp & 1) return vfs_set_error(VFS_ERR_SHAPE, "stem_fwd: padded width must be even");
+  ConvArgs a;
+  a.g = make_geom(N, H, Wp, 4, Ho, Wo, 7, 7, 2, 3, 256);
+  a.src = x4; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = nullptr; a.stats = stats; a.Cout = 64;
+  return vfs_conv_igemm_dispatch(a, GATHER_STEM, S(stream));
+}
+
+int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, int N, int H, int W, int Cin,
+                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+  // gather source = dy [N,Ho,Wo,Cout]; destination grid = dx [N,H,W,Cin]
+  ConvArgs a;
+  a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
+  a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin;
+  return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
+}
+
+int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float* grad, int N, int H, int W, int Cin, int Ho,
+                   int Wo, int Cout, int KH, int KW, int stride, int pad, int nsplit, int pix_per_split, vfs_stream_t stream) {
+  WgradArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.dy = dy; a.x = x; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
+  int rc = vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
+  if (rc) return rc;
+  return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
+}
+
+int vfs_stem_wgrad(const vfs_bf16* dy, const vfs_bf16* x4, float* partial, float* grad, int N, int H, int Wp, int Ho, int Wo,
+                   int nsplit, int pix_per_split, vfs_stream_t stream) {
+  WgradArgs a;
+  a.g = make_geom(N, H, Wp, 4, Ho, Wo, 7, 7, 2, 3, 256);
+  a.dy = dy; a.x = x4; a.partial = partial; a.Cout = 64; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
+  int rc = vfs_conv_wgrad_dispatch(a, GATHER_STEM, S(stream));
+  if (rc) return rc;
+  return vfs_wgrad_reduce_launch(partial, grad, nsplit, 64, 256, 3, 7, 7, 1, S(stream));
+}
+
+int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stream) {
+  return vfs_bias_grad_launch(dy, db, M, C, S(stream));
+}
+
+int vfs_bn_reduce_partials(const float* partial, double* sums, int G, int bpg, int C, vfs_stream_t stream) {
+  return vfs_bn_reduce_partials_launch(partial, sums, G, bpg, C, S(stream));
+}
+int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp, float* running_mean,
+                    float* running_var, int G, int C, double count, float eps, float momentum, vfs_stream_t stream) {
+  return vfs_bn_finalize_launch(sums, gamma, beta, bnp, running_mean, running_var, G, C, count, eps, momentum, S(stream));
+}
+int vfs_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* bnp,
+                       int C, float eps, vfs_stream_t stream) {
+  return vfs_bn_eval_params_launch(gamma, beta, running_mean, running_var, bnp, C, eps, S(stream));
+}
+int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+               long long M, int C, int mpg, int relu, vfs_stream_t stream) {
+  BnActArgs a;
+  a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
+  return vfs_bn_act_launch(a, S(stream));
+}
+int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, int N, int H, int W, int C, int Hp,
+                        int Wp, int npg, vfs_stream_t stream) {
+  BnPoolArgs a;
+  a.x = x; a.bnp = bnp; a.y = y; a.idx = idx; a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg;
+  return vfs_bn_relu_maxpool_launch(a, S(stream));
+}
+int vfs_maxpool_relu_bwd(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, vfs_bf16* ga, int N, int H, int W, int C,
+                         int Hp, int Wp, vfs_stream_t stream) {
+  PoolBwdArgs a;
+  a.gp = gp; a.yp = yp; a.idx = idx; a.ga = ga; a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp;
+  return vfs_maxpool_relu_bwd_launch(a, S(stream));
+}
+int vfs_bn_bwd_reduce(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, float* partial, long long M,
+                      int C, int mpg, int ppb, vfs_stream_t stream) {
+  if (ppb <= 0 || mpg % ppb) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_reduce: pixels-per-group % pixels-per-block");
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.partial = partial; a.M = M; a.C = C; a.mpg = mpg; a.ppb = ppb;
+  return vfs_bn_bwd_reduce_launch(a, (int)((M + ppb - 1) / ppb), S(stream));
+}
+int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, const double* sums,
+                     vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg, double count, vfs_stream_t stream) {
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.sums = sums; a.dx = dx; a.gm = gm; a.M = M; a.C = C; a.mpg = mpg; a.count = count;
+  return vfs_bn_bwd_apply_launch(a, S(stream));
+}
+int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C, vfs_stream_t stream) {
+  return vfs_bn_param_grad_launch(sums, dgamma, dbeta, G, C, S(stream));
+}
+
+int vfs_avgpool_fwd(const vfs_bf16* x, vfs_bf16* y, int N, int HW, int C, vfs_stream_t stream) {
+  return vfs_avgpool_fwd_launch(x, y, N, HW, C, S(stream));
+}
+int vfs_avgpool_bwd(const vfs_bf16* g, vfs_bf16* gx, int N, int HW, int C, vfs_stream_t stream) {
+  return vfs_avgpool_bwd_launch(g, gx, N, HW, C, S(stream));
+}
+
+int vfs_cosine_loss_fwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2, const vfs_bf16* z2, float* loss, int N,
+                        int C, int T, int K, int negative, float weight, vfs_stream_t stream) {
+  if (N % T) return vfs_set_error(VFS_ERR_SHAPE, "cosine_loss: N % T");
+  LossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.p1 = p1; a.z1 = z1; a.p2 = p2; a.z2 = z2; a.loss = loss; a.N = N; a.C = C; a.T = T; a.K = K; a.negative = negative;
+  a.weight = weight;
+  return vfs_cosine_loss_fwd_launch(a, S(stream));
+}
+int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2, const vfs_bf16* z2, const float* gloss,
+                        vfs_bf16* dp1, vfs_bf16* dp2, int N, int C, int T, int K, int negative, float weight,
+                        vfs_stream_t stream) {
+  if (N % T) return vfs_set_error(VFS_ERR_SHAPE, "cosine_loss: N % T");
+  LossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.p1 = p1; a.z1 = z1; a.p2 = p2; a.z2 = z2; a.gloss = gloss; a.dp1 = dp1; a.dp2 = dp2;
+  a.N = N; a.C = C; a.T = T; a.K = K; a.negative = negative; a.weight = weight;
+  return vfs_cosine_loss_bwd_launch(a, S(stream));
+}
+
+int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
+                 float weight_decay, vfs_stream_t stream) {
+  return vfs_sgd_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, S(stream));
+}
+int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream) { return vfs_scale_launch(x, n, scale, S(stream)); }
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// Weight-gradient convolution for gfx950 (autograd wgrad of the reference's conv2d / linear).
+//
+//   dW[cout][k] = sum_pixels dY[pixel][cout] * G[pixel][k]        (G = implicit im2col of the
+//                                                                   forward input, vfs_conv.h)
+// GEMM view: rows(i) = k-columns (A operand), cols(j) = cout (B operand), reduction = pixels.
+// Both operands live in memory pixel-major (NHWC), i.e. with the REDUCTION index slowest, so the
+// stage transposes while filling LDS: each thread loads 4 pixels x 8 channels (4 x 16 B, rows
+// of 128 B coalesced), regroups them with 16 bit-permutes into 8 channels x 4 pixels and writes
+// 8-byte runs into a [channel][64 pixels] swizzled tile; fragments are then plain ds_read_b128
+// exactly as in the forward kernel.  Split-K over pixel ranges; fp32 partials are summed in a
+// fixed order by wgrad_reduce (deterministic), which also scatters into the reference's OIHW
+// parameter layout.
+#include "vfs_conv.h"
+
+template <int BCW, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int BKC = 128;        // k-columns per workgroup (two forward K-steps)
+  constexpr int TM = 4;           // 64 k-columns per wave
+  constexpr int TN = BCW / 32;    // (BCW/2) couts per wave
+  __shared__ __attribute__((aligned(16))) bf16_t sA[2][BKC * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t sD[2][BCW * 64];
+
+  const ConvGeom g = a.g;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nkb = (g.Ktot + BKC - 1) / BKC;
+  const int ncb = a.Cout / BCW;
+  int b = blockIdx.x;
+  const int kb = b % nkb; b /= nkb;
+  const int cb = b % ncb; b /= ncb;
+  const int split = b;
+  const int nk = g.Ktot >> 6;
+
+  // loader roles
+  const int a_cj = t & 15, a_pg = t >> 4;                       // A tile: 16 chunks x 16 pixel groups
+  const int a_kt = kb * 2 + (a_cj >> 3), a_j = a_cj & 7;
+  const bool a_ok = a_kt < nk;
+  const KStep a_ks = kstep_decode<MODE>(g, a_ok ? a_kt : 0);
+  constexpr int DCH = BCW / 8;                                   // dY chunks per pixel
+  const int d_cj = t % DCH, d_pg = (t / DCH) & 15;
+  const bool d_active = t < DCH * 16;
+
+  const int pix_begin = split * a.pix_per_split;
+  const int iters = a.pix_per_split >> 6;
+
+  u32x4 av[4], dv[4];
+  auto load_tiles = [&](int it) {
+    const int p0 = pix_begin + it * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = p0 + a_pg * 4 + i;
+      if (a_ok) {
+        PixCoord pc = pix_decode<MODE>(g, m);
+        av[i] = gather16<MODE>(g, a.x, pc, a_ks, a_j);
+      } else {
+        av[i] = zero16();
+      }
+    }
+    if (d_active) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = p0 + d_pg * 4 + i;
+        dv[i] = (m < g.M) ? ld16(a.dy + (size_t)m * a.Cout + cb * BCW + d_cj * 8) : zero16();
+      }
+    }
+  };
+  auto store_transposed = [&](bf16_t* tile, const u32x4 (&v)[4], int cj, int pg) {
+    const int ch = pg >> 1, half = (pg & 1) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned d0 = v[0][q], d1 = v[1][q], d2 = v[2][q], d3 = v[3][q];
+      u32x2 e, o;
+      e.x = (d0 & 0xffffu) | (d1 << 16);
+      e.y = (d2 & 0xffffu) | (d3 << 16);
+      o.x = (d0 >> 16) | (d1 & 0xffff0000u);
+      o.y = (d2 >> 16) | (d3 & 0xffff0000u);
+      const int r0 = cj * 8 + 2 * q;
+      st8(tile + lds_off_t(r0, ch) + half, e);
+      st8(tile + lds_off_t(r0 + 1, ch) + half, o);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    store_transposed(sA[buf], av, a_cj, a_pg);
+    if (d_active) store_transposed(sD[buf], dv, d_cj, d_pg);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    const bool more = it + 1 < iters;
+    if (more) load_tiles(it + 1);
+    mma_kstep<TM, TN, true>(sA[cur], sD[cur], wm * 64, wn * (BCW / 2), lane, acc);
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int cout = cb * BCW + wn * (BCW / 2) + tn * 16 + lr;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int kc = kb * BKC + wm * 64 + tm * 16 + lq * 4;
+      if (kc < g.Ktot)
+        *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) = acc[tm][tn];
+    }
+  }
+}
+
+template <int BCW, int MODE>
+static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+  int nkb = (a.g.Ktot + 127) / 128;
+  int ncb = a.Cout / BCW;
+  hipLaunchKernelGGL((conv_wgrad_kernel<BCW, MODE>), dim3(nkb * ncb * a.nsplit), dim3(256), 0, stream, a);
+  return vfs_check_launch("conv_wgrad");
+}
+
+int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
+  if (a.g.Ktot % 64 || a.Cout % 64 || a.pix_per_split % 64 || a.nsplit < 1)
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: K%64, Cout%64, pix_per_split%64");
+  if ((long long)a.pix_per_split * a.nsplit < a.g.M) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: splits do not cover M");
+  const bool wide = (a.Cout % 128 == 0);
+  if (mode == GATHER_FWD) return wide ? launch_wgrad<128, GATHER_FWD>(a, stream) : launch_wgrad<64, GATHER_FWD>(a, stream);
+  if (mode == GATHER_STEM) return launch_wgrad<64, GATHER_STEM>(a, stream);
+  return vfs_set_error(VFS_ERR_ARG, "conv_wgrad: bad mode");
+}
+
+// ---------------------------------------------------------------------------------------------
+// partial[nsplit][Cout][Ktot] -> grad (+=) in the reference's parameter layout (OIHW fp32):
+//   FWD  : k = (r*KW + s)*Cin + cin          -> grad[cout][cin][r][s]
+//   STEM : k = (r*8 + (s+1))*4 + c           -> grad[cout][c][r][s]   (r<7, 0<=s<7, c<3)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad,
+                                                           int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
+                                                           int stem) {
+  const size_t total = (size_t)Cout * Ktot;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cout = (int)(i / Ktot), k = (int)(i - (size_t)cout * Ktot);
+    int cin, r, s;
+    bool ok = true;
+    if (stem) {
+      cin = k & 3;
+      const int si = (k >> 2) & 7;
+      r = k >> 5; s = si - 1;
+      ok = (cin < 3) && (r < 7) && (si >= 1);
+    } else {
+      const int tap = k / Cin;
+      cin = k - tap * Cin;
+      r = tap / KW; s = tap - r * KW;
+    }
+    if (!ok) continue;
+    float sum = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) sum += partial[(size_t)sp * total + i];
+    const int cin_n = stem ? 3 : Cin;
+    grad[(((size_t)cout * cin_n + cin) * KH + r) * KW + s] += sum;
+  }
+}
+
+int vfs_wgrad_reduce_launch(const float* partial, float* grad, int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
+                            int stem, hipStream_t stream) {
+  size_t total = (size_t)Cout * Ktot;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, grad, nsplit, Cout, Ktot, Cin, KH,
+                     KW, stem);
+  return vfs_check_launch("wgrad_reduce");
+}

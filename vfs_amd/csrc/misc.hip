@@ -1,0 +1,254 @@
+// Layout conversion, weight packing, pooling, cosine loss and SGD kernels (HBM / latency bound).
+#include "vfs_ops.h"
+
+// ------------------------------------------------------------------ input frames
+// reference layout: imgs[b][v][c][t][h][w] fp32 (pipelines/formating.py:248-258), view v is
+// video2images(imgs[:, v]) = frames ordered (b, t)  (common/utils.py:45-53)
+__global__ __launch_bounds__(256) void imgs_to_nhwc4_kernel(const float* __restrict__ imgs, bf16_t* __restrict__ out,
+                                                            int B, int V, int T, int H, int W, int Wp) {
+  const long long total = (long long)V * B * T * H * Wp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long p = i;
+    const int w = (int)(p % Wp); p /= Wp;
+    const int h = (int)(p % H); p /= H;
+    const int t = (int)(p % T); p /= T;
+    const int b = (int)(p % B);
+    const int v = (int)(p / B);
+    u32x2 pk = {0u, 0u};
+    if (w < W) {
+      const size_t plane = (size_t)T * H * W;
+      const size_t base = (((size_t)b * V + v) * 3) * plane + ((size_t)t * H + h) * W + w;
+      pk.x = pack2bf(imgs[base], imgs[base + plane]);
+      pk.y = pack2bf(imgs[base + 2 * plane], 0.f);
+    }
+    st8(out + (size_t)i * 4, pk);
+  }
+}
+int vfs_imgs_to_nhwc4_launch(const float* imgs, bf16_t* out, int B, int V, int T, int H, int W, int Wp, hipStream_t s) {
+  long long total = (long long)V * B * T * H * Wp;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(imgs_to_nhwc4_kernel, dim3((int)blocks), dim3(256), 0, s, imgs, out, B, V, T, H, W, Wp);
+  return vfs_check_launch("imgs_to_nhwc4");
+}
+
+// ------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ table, int n, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = table[lo];
+    long long e = i - d.start;
+    const int s = (int)(e % d.KW); e /= d.KW;
+    const int r = (int)(e % d.KH); e /= d.KH;
+    const int cin = (int)(e % d.Cin);
+    const int cout = (int)(e / d.Cin);
+    const bf16_t v = f2bf(d.w[i - d.start]);
+    if (d.kind == 1) {
+      d.wf[(((size_t)cout * 8 + r) * 8 + (s + 1)) * 4 + cin] = v;
+    } else {
+      d.wf[(((size_t)cout * d.KH + r) * d.KW + s) * d.Cin + cin] = v;
+      if (d.wd) d.wd[(((size_t)cin * d.KH + r) * d.KW + s) * d.Cout + cout] = v;
+    }
+  }
+}
+int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total, hipStream_t s) {
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((int)blocks), dim3(256), 0, s, table, ntensors, total);
+  return vfs_check_launch("pack_weights");
+}
+
+// ------------------------------------------------------------------ global average pool
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int HW,
+                                                          int C) {
+  const int cv = C >> 3;
+  const int total = N * cv;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < total; v += gridDim.x * 256) {
+    const int n = v / cv, c = (v - n * cv) * 8;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float f[8];
+      unpack8(ld16(x + ((size_t)n * HW + p) * C + c), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += f[i];
+    }
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] *= inv;
+    st16(y + (size_t)n * C + c, pack8(acc));
+  }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ gx, int N, int HW,
+                                                          int C) {
+  const int cv = C >> 3;
+  const long long total = (long long)N * HW * cv;
+  const float inv = 1.0f / (float)HW;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    const long long p = v / cv;
+    const int c = (int)(v - p * cv) * 8;
+    const int n = (int)(p / HW);
+    float f[8];
+    unpack8(ld16(g + (size_t)n * C + c), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] *= inv;
+    st16(gx + (size_t)p * C + c, pack8(f));
+  }
+}
+int vfs_avgpool_fwd_launch(const bf16_t* x, bf16_t* y, int N, int HW, int C, hipStream_t s) {
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((N * (C >> 3) + 255) / 256), dim3(256), 0, s, x, y, N, HW, C);
+  return vfs_check_launch("avgpool_fwd");
+}
+int vfs_avgpool_bwd_launch(const bf16_t* g, bf16_t* gx, int N, int HW, int C, hipStream_t s) {
+  long long b = ((long long)N * HW * (C >> 3) + 255) / 256;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((int)(b > 4096 ? 4096 : b)), dim3(256), 0, s, g, gx, N, HW, C);
+  return vfs_check_launch("avgpool_bwd");
+}
+
+// db[c] += sum_m dy[m][c]
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int M, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += bf2f(dy[(size_t)m * C + c]);
+  db[c] += s;
+}
+int vfs_bias_grad_launch(const bf16_t* dy, float* db, int M, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dy, db, M, C);
+  return vfs_check_launch("bias_grad");
+}
+
+// ------------------------------------------------------------------ cosine loss
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ int roll_src(int i, int T, int k) {  // index of roll(k)[i] within i's video
+  const int b = i / T, t = i - b * T;
+  int u = t - k;
+  if (u < 0) u += T;
+  return b * T + u;
+}
+// one wave per (k, i):  loss[k][i] = w * (0.5*L(p1[i], z2[j]) + 0.5*L(p2[j], z1[i])),  j = roll_k(i)
+__global__ __launch_bounds__(64) void cosine_loss_fwd_kernel(LossArgs a) {
+  const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+  const int j = roll_src(i, a.T, k);
+  float d1 = 0.f, d2 = 0.f, np1 = 0.f, nz2 = 0.f, np2 = 0.f, nz1 = 0.f;
+  for (int c = lane; c < a.C; c += 64) {
+    const float p1 = bf2f(a.p1[(size_t)i * a.C + c]), z1 = bf2f(a.z1[(size_t)i * a.C + c]);
+    const float p2 = bf2f(a.p2[(size_t)j * a.C + c]), z2 = bf2f(a.z2[(size_t)j * a.C + c]);
+    d1 += p1 * z2; d2 += p2 * z1;
+    np1 += p1 * p1; nz2 += z2 * z2; np2 += p2 * p2; nz1 += z1 * z1;
+  }
+  d1 = wave_sum(d1); d2 = wave_sum(d2);
+  np1 = wave_sum(np1); nz2 = wave_sum(nz2); np2 = wave_sum(np2); nz1 = wave_sum(nz1);
+  if (lane == 0) {
+    const float eps = 1e-12f;
+    const float c1 = d1 / (fmaxf(sqrtf(np1), eps) * fmaxf(sqrtf(nz2), eps));
+    const float c2 = d2 / (fmaxf(sqrtf(np2), eps) * fmaxf(sqrtf(nz1), eps));
+    const float l1 = a.negative ? -c1 : 2.f - 2.f * c1;
+    const float l2 = a.negative ? -c2 : 2.f - 2.f * c2;
+    a.loss[(size_t)k * a.N + i] = (0.5f * l1 + 0.5f * l2) * a.weight;
+  }
+}
+// one wave per (view, i): gradient wrt p (z is detached in the reference)
+//   view 0: dp1[i] = sum_k gloss[k][i]      * w/2 * dL/da (a = p1[i], b = z2[roll_k(i)])
+//   view 1: dp2[j] = sum_k gloss[k][inv_k(j)] * w/2 * dL/da (a = p2[j], b = z1[inv_k(j)])
+//   dL/da = coef * (bhat - cos * ahat) / max(|a|, eps),  coef = -2 (or -1 when negative)
+__global__ __launch_bounds__(64) void cosine_loss_bwd_kernel(LossArgs a) {
+  const int i = blockIdx.x, view = blockIdx.y, lane = threadIdx.x;
+  const bf16_t* A = view == 0 ? a.p1 : a.p2;
+  const bf16_t* Bz = view == 0 ? a.z2 : a.z1;
+  bf16_t* out = view == 0 ? a.dp1 : a.dp2;
+  const float eps = 1e-12f, coef = a.negative ? -1.f : -2.f;
+  float na = 0.f;
+  for (int c = lane; c < a.C; c += 64) { const float v = bf2f(A[(size_t)i * a.C + c]); na += v * v; }
+  na = fmaxf(sqrtf(wave_sum(na)), eps);
+  const int bvid = i / a.T, t = i - bvid * a.T;
+  constexpr int MAXC = 32;  // supports C <= 2048
+  float acc[MAXC];
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) acc[q] = 0.f;
+  for (int k = 0; k < a.K; ++k) {
+    int u, gi;
+    if (view == 0) { u = t - k; if (u < 0) u += a.T; gi = i; }        // partner = roll_k(i), loss index i
+    else { u = t + k; if (u >= a.T) u -= a.T; gi = bvid * a.T + u; }  // p2[i] is paired with loss index inv_k(i)
+    const int j = bvid * a.T + u;
+    float nb = 0.f, dot = 0.f;
+    for (int c = lane; c < a.C; c += 64) {
+      const float av = bf2f(A[(size_t)i * a.C + c]), bv = bf2f(Bz[(size_t)j * a.C + c]);
+      nb += bv * bv; dot += av * bv;
+    }
+    nb = fmaxf(sqrtf(wave_sum(nb)), eps);
+    const float cs = wave_sum(dot) / (na * nb);
+    const float gs = a.gloss[(size_t)k * a.N + gi] * a.weight * 0.5f * coef / na;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+      const int c = lane + q * 64;
+      if (c < a.C) {
+        const float av = bf2f(A[(size_t)i * a.C + c]), bv = bf2f(Bz[(size_t)j * a.C + c]);
+        acc[q] += gs * (bv / nb - cs * av / na);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int c = lane + q * 64;
+    if (c < a.C) out[(size_t)i * a.C + c] = f2bf(acc[q]);
+  }
+}
+int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cosine_loss_fwd_kernel, dim3(a.N, a.K), dim3(64), 0, s, a);
+  return vfs_check_launch("cosine_loss_fwd");
+}
+int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s) {
+  if (a.C > 2048) return vfs_set_error(VFS_ERR_SHAPE, "cosine_loss_bwd: C > 2048");
+  hipLaunchKernelGGL(cosine_loss_bwd_kernel, dim3(a.N, 2), dim3(64), 0, s, a);
+  return vfs_check_launch("cosine_loss_bwd");
+}
+
+// ------------------------------------------------------------------ SGD
+// torch.optim.SGD (configs/*:134): g += wd*p ; buf = momentum*buf + g ; p -= lr*buf
+// (a zero-initialised buf reproduces torch's "buf = g" on the first step)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long long n, float lr, float momentum, float wd) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 bv = reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float gg = gv[q] + wd * pv[q];
+      bv[q] = momentum * bv[q] + gg;
+      pv[q] -= lr * bv[q];
+    }
+    reinterpret_cast<f32x4*>(buf)[i] = bv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] + wd * p[i];
+    buf[i] = momentum * buf[i] + gg;
+    p[i] -= lr * buf[i];
+  }
+}
+int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, hipStream_t s) {
+  long long b = ((n >> 2) + 255) / 256;
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd);
+  return vfs_check_launch("sgd");
+}
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ p, long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] *= scale;
+}
+int vfs_scale_launch(float* p, long long n, float scale, hipStream_t s) {
+  long long b = (n + 255) / 256;
+  hipLaunchKernelGGL(scale_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, p, n, scale);
+  return vfs_check_launch("scale");
+}

@@ -1,0 +1,170 @@
+// Geometry + gather shared by the implicit-GEMM convolution kernels.
+//
+// GEMM view (all three directions):   D[chan][pixel] = sum_k  Wt[chan][k] * G[pixel][k]
+//   * pixel   : m = (n*Ho + ho)*Wo + wo  over the DESTINATION grid (Ho x Wo)
+//   * k       : 64-element K-steps; K-step kt, 16-byte chunk j (8 bf16) of a pixel's
+//               gathered row come from ONE contiguous 16-byte run of the NHWC source
+//   * G       : never materialised (im2col on the fly), zero where the tap is padding
+// Gather modes
+//   FWD   : source = input activations [N,H,W,C], k = (r, s, c)           (conv forward)
+//   DGRAD : source = dY [N,H,W,C=Cout], k = (r, s, cout), tap valid iff
+//           (ho+pad-r) and (wo+pad-s) are multiples of stride             (conv dgrad)
+//   STEM  : 7x7 stride-2 pad-3 conv on NHWC4 input (channel 3 is zero padding);
+//           K-step kt covers kernel rows 2kt,2kt+1; chunk j = row (j>>2), column pair (j&3)
+//           starting at column 2wo-4 (tap s=-1 and row 7 carry zero weights): K = 8*8*4 = 256
+#pragma once
+#include "vfs_common.h"
+
+enum { GATHER_FWD = 0, GATHER_DGRAD = 1, GATHER_STEM = 2 };
+
+struct ConvGeom {
+  int N, H, W, C;   // gather-source tensor (NHWC), C = physical channels per pixel
+  int Ho, Wo;       // destination pixel grid
+  int KH, KW, stride, pad;
+  int Ktot;         // GEMM K (multiple of 64)
+  int M;            // N*Ho*Wo
+};
+
+struct ConvArgs {
+  ConvGeom g;
+  const bf16_t* src;   // gather source
+  const bf16_t* wgt;   // [Cout][Ktot] bf16, K contiguous, K ordered as the gather mode defines
+  bf16_t* out;         // [M][Cout]
+  const bf16_t* add;   // optional [M][Cout] (may alias out)
+  const float* bias;   // optional [Cout]
+  float* stats;        // optional [num_pixel_blocks][2][Cout]
+  int Cout;
+};
+
+struct WgradArgs {
+  ConvGeom g;          // geometry of the FORWARD conv (gather source = forward input)
+  const bf16_t* dy;    // [M][Cout] gradient of the raw conv output
+  const bf16_t* x;     // forward input activations (gather source)
+  float* partial;      // [nsplit][Cout][Ktot] fp32 partial sums
+  int Cout;
+  int pix_per_split;   // multiple of 64
+  int nsplit;
+};
+
+int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
+int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream);
+
+struct PixCoord {
+  int nH;  // n*H of the source tensor
+  int hb;  // base source row   (FWD/STEM: ho*stride-pad ; DGRAD: ho+pad) ; <<0 when pixel invalid
+  int wb;  // base source column
+};
+
+template <int MODE>
+__device__ __forceinline__ PixCoord pix_decode(const ConvGeom& g, int m) {
+  PixCoord pc;
+  if (m >= g.M) {
+    pc.nH = 0; pc.hb = -(1 << 24); pc.wb = -(1 << 24);
+    return pc;
+  }
+  int hw = g.Ho * g.Wo;
+  int n = m / hw;
+  int rem = m - n * hw;
+  int ho = rem / g.Wo;
+  int wo = rem - ho * g.Wo;
+  pc.nH = n * g.H;
+  if (MODE == GATHER_DGRAD) {
+    pc.hb = ho + g.pad; pc.wb = wo + g.pad;
+  } else if (MODE == GATHER_STEM) {
+    pc.hb = 2 * ho - 3; pc.wb = 2 * wo - 4;
+  } else {
+    pc.hb = ho * g.stride - g.pad; pc.wb = wo * g.stride - g.pad;
+  }
+  return pc;
+}
+
+struct KStep {  // decoded K-step (uniform per workgroup)
+  int r, s, c0;
+};
+
+template <int MODE>
+__device__ __forceinline__ KStep kstep_decode(const ConvGeom& g, int kt) {
+  KStep ks;
+  if (MODE == GATHER_STEM) {
+    ks.r = 2 * kt; ks.s = 0; ks.c0 = 0;
+  } else {
+    int cpt = g.C >> 6;
+    int tap = kt / cpt;
+    ks.c0 = (kt - tap * cpt) << 6;
+    ks.r = tap / g.KW;
+    ks.s = tap - ks.r * g.KW;
+  }
+  return ks;
+}
+
+// 16-byte chunk j of pixel pc at K-step ks; zero when the tap falls on padding
+template <int MODE>
+__device__ __forceinline__ u32x4 gather16(const ConvGeom& g, const bf16_t* __restrict__ src,
+                                          const PixCoord& pc, const KStep& ks, int j) {
+  int hi, wi;
+  bool ok;
+  size_t off;
+  if (MODE == GATHER_STEM) {
+    int r = ks.r + (j >> 2);
+    hi = pc.hb + r;
+    wi = pc.wb + 2 * (j & 3);
+    ok = (r < 7) && ((unsigned)hi < (unsigned)g.H) && ((unsigned)wi < (unsigned)g.W);
+    off = ((size_t)(pc.nH + hi) * g.W + wi) * 4;
+  } else if (MODE == GATHER_DGRAD) {
+    int th = pc.hb - ks.r, tw = pc.wb - ks.s;
+    ok = (th >= 0) && (tw >= 0);
+    if (g.stride == 1) {
+      hi = th; wi = tw;
+    } else {
+      hi = th / g.stride; wi = tw / g.stride;
+      ok = ok && (hi * g.stride == th) && (wi * g.stride == tw);
+    }
+    ok = ok && (hi < g.H) && (wi < g.W);
+    off = ((size_t)(pc.nH + hi) * g.W + wi) * g.C + ks.c0 + j * 8;
+  } else {
+    hi = pc.hb + ks.r;
+    wi = pc.wb + ks.s;
+    ok = ((unsigned)hi < (unsigned)g.H) && ((unsigned)wi < (unsigned)g.W);
+    off = ((size_t)(pc.nH + hi) * g.W + wi) * g.C + ks.c0 + j * 8;
+  }
+  return ok ? ld16(src + off) : zero16();
+}
+
+// LDS tile: rows of 64 bf16 (128 B); the eight 16-byte chunks of a row are XOR-swizzled so
+// that both the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 fragment groups
+// (16 consecutive rows, same chunk) hit 16 distinct 16-byte slots of the 64-bank row.
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+// variant for tiles filled by the transposing wgrad stage (rows written with stride 8)
+__device__ __forceinline__ int lds_off_t(int row, int chunk) {
+  return row * 64 + ((chunk ^ (((row >> 1) ^ (row >> 4)) & 7)) << 3);
+}
+
+// one 64-deep K-step of MFMAs for a wave: acc[tm][tn] += A(rowsA + tm*16) x B(rowsB + tn*16)
+template <int TM, int TN, bool TSWZ>
+__device__ __forceinline__ void mma_kstep(const bf16_t* __restrict__ sA, const bf16_t* __restrict__ sB,
+                                          int rowA0, int rowB0, int lane, f32x4 (&acc)[TM][TN]) {
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bf16x8 af[TM], bfr[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      int row = rowA0 + tm * 16 + lr;
+      int o = TSWZ ? lds_off_t(row, kk * 4 + lq) : lds_off(row, kk * 4 + lq);
+      af[tm] = *reinterpret_cast<const bf16x8*>(sA + o);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      int row = rowB0 + tn * 16 + lr;
+      int o = TSWZ ? lds_off_t(row, kk * 4 + lq) : lds_off(row, kk * 4 + lq);
+      bfr[tn] = *reinterpret_cast<const bf16x8*>(sB + o);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+  }
+}

@@ -1,0 +1,103 @@
+// Argument structs + host launchers of the element-wise / reduction kernels (bn.hip, misc.hip).
+#pragma once
+#include "vfs_common.h"
+
+// y = [relu]( x*scale + shift  [+ res]  [+ rres*rscale + rshift] )
+struct BnActArgs {
+  const bf16_t* x;      // [M][C] raw conv output
+  const float* bnp;     // [G][4][C]
+  const bf16_t* res;    // optional materialised residual [M][C]
+  const bf16_t* rres;   // optional RAW residual (downsample conv output) ...
+  const float* rbnp;    // ... with its own BN parameters [G][4][C]
+  bf16_t* y;            // [M][C]
+  long long M;
+  int C, mpg, relu;     // mpg = pixels per group
+};
+
+// stem: y = maxpool3x3/s2/p1( relu( x*scale + shift ) ), argmax position (0..8, first maximum in
+// scan order as torch's CPU max_pool2d) saved per element for the backward pass
+struct BnPoolArgs {
+  const bf16_t* x;   // [N][H][W][C]
+  const float* bnp;  // [G][4][C]
+  bf16_t* y;         // [N][Hp][Wp][C]
+  uint8_t* idx;      // [N][Hp][Wp][C] or null
+  int N, H, W, C, Hp, Wp, npg;  // npg = images per group
+};
+
+// backward of the stem max-pool (+ReLU): ga[n][h][w][c] = sum over the <=4 windows containing
+// (h,w) whose argmax is (h,w) of gp[window] * (yp[window] > 0); gather form, no atomics
+struct PoolBwdArgs {
+  const bf16_t* gp;    // [N][Hp][Wp][C] gradient wrt pooled output
+  const bf16_t* yp;    // pooled output (ReLU mask: pooled max > 0)
+  const uint8_t* idx;  // argmax positions
+  bf16_t* ga;          // [N][H][W][C]
+  int N, H, W, C, Hp, Wp;
+};
+
+// ------------------------------------------------------------------------------------------
+// BN backward, pass 1: per-channel  S1 = sum gm,  S2 = sum gm * xhat   with gm = g * (y > 0)
+// one partial[2][C] per workgroup (PIX_PER_BLOCK pixels of one group)
+struct BnBwdArgs {
+  const bf16_t* g;     // [M][C] gradient wrt the unit's output
+  const bf16_t* y;     // [M][C] unit output for the ReLU mask, or null (no activation)
+  const bf16_t* x;     // [M][C] raw conv output
+  const float* bnp;    // [G][4][C]
+  const double* sums;  // pass 2: [G][2][C] (S1,S2), all-reduced for SyncBN
+  float* partial;      // pass 1 output [nblk][2][C]
+  bf16_t* dx;          // pass 2 output [M][C]
+  bf16_t* gm;          // pass 2 optional output: masked gradient (identity branch)
+  long long M;
+  int C, mpg, ppb;     // pixels per group, pixels per block (pass 1; mpg % ppb == 0)
+  double count;        // pass 2: elements per channel per group (global for SyncBN)
+};
+
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, int G, int bpg, int C, hipStream_t s);
+int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
+                           int G, int C, double count, float eps, float momentum, hipStream_t s);
+int vfs_bn_eval_params_launch(const float* gamma, const float* beta, const float* rm, const float* rv, float* bnp, int C,
+                              float eps, hipStream_t s);
+int vfs_bn_act_launch(const BnActArgs& a, hipStream_t s);
+int vfs_bn_relu_maxpool_launch(const BnPoolArgs& a, hipStream_t s);
+int vfs_maxpool_relu_bwd_launch(const PoolBwdArgs& a, hipStream_t s);
+int vfs_bn_bwd_reduce_launch(const BnBwdArgs& a, int nblk, hipStream_t s);
+int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s);
+int vfs_bn_param_grad_launch(const double* sums, float* dgamma, float* dbeta, int G, int C, hipStream_t s);
+int vfs_wgrad_reduce_launch(const float* partial, float* grad, int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
+                            int stem, hipStream_t stream);
+
+// ---- misc.hip ------------------------------------------------------------------------------
+// imgs fp32 [B][V][3][T][H][W] (reference layout, FormatShape 'NCTHW') -> bf16 NHWC4
+// out[(v*B + b)*T + t][h][w][0..3], channel 3 = 0, width padded to Wp (even) with zeros
+int vfs_imgs_to_nhwc4_launch(const float* imgs, bf16_t* out, int B, int V, int T, int H, int W, int Wp, hipStream_t s);
+
+// table-driven fp32 OIHW master weights -> bf16 packed copies (forward KRSC + dgrad CRSK)
+struct PackDesc {
+  const float* w;   // [Cout][Cin][KH][KW]
+  bf16_t* wf;       // kind 0: [Cout][KH][KW][Cin]   kind 1 (stem): [Cout][8][8][4] (pre-zeroed)
+  bf16_t* wd;       // kind 0: [Cin][KH][KW][Cout] or null
+  long long start;  // first global element index of this tensor
+  int Cout, Cin, KH, KW;
+  int kind, pad0;
+};
+int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total, hipStream_t s);
+
+int vfs_avgpool_fwd_launch(const bf16_t* x, bf16_t* y, int N, int HW, int C, hipStream_t s);
+int vfs_avgpool_bwd_launch(const bf16_t* g, bf16_t* gx, int N, int HW, int C, hipStream_t s);
+int vfs_bias_grad_launch(const bf16_t* dy, float* db, int M, int C, hipStream_t s);
+
+// SimSiam cosine loss, all T temporal rolls at once (sim_siam_base_tracker.py:31-56,
+// sim_siam_head.py:165-174, sim_loss.py:42-63)
+struct LossArgs {
+  const bf16_t *p1, *z1, *p2, *z2;  // [N][C], N = B*T
+  float* loss;                      // fwd out [K][N]   (K = T if intra_video else 1)
+  const float* gloss;               // bwd in  [K][N] upstream gradient of each loss element
+  bf16_t *dp1, *dp2;                // bwd out [N][C]
+  int N, C, T, K, negative;
+  float weight;
+};
+int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
+int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);
+
+// fused SGD over the flat parameter arena (torch.optim.SGD, dampening 0, no nesterov)
+int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, hipStream_t s);
+int vfs_scale_launch(float* p, long long n, float scale, hipStream_t s);
