@@ -162,7 +162,7 @@ class ResNet(nn.Module):
                      152: (Bottleneck, (3, 8, 36, 3))}
 
     def __init__(self, depth, strides=(1, 2, 2, 2), out_indices=(3,), zero_init_residual=True,
-                 stop_after_out=False):
+                 stop_after_out=False, num_stages=4):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError(f'invalid depth {depth} for resnet')
@@ -173,7 +173,7 @@ class ResNet(nn.Module):
         self.maxpool = nn.MaxPool2d(3, 2, 1)                      # resnet.py:435
         inplanes = 64
         self.res_layers = []
-        for i, nb in enumerate(stage_blocks):
+        for i, nb in enumerate(stage_blocks[:num_stages]):
             planes, stride = 64 * 2 ** i, strides[i]
             down = None
             if stride != 1 or inplanes != planes * block.expansion:   # resnet.py:266-277
@@ -300,9 +300,9 @@ def images2video(imgs, clip_len):                                # common/utils.
 class SimSiamTracker(nn.Module):
     """trackers/sim_siam_base_tracker.py:12-76 + trackers/base.py:76-156."""
 
-    def __init__(self, depth, head_kwargs, intra_video=False):
+    def __init__(self, depth, head_kwargs, intra_video=False, **backbone_kwargs):
         super().__init__()
-        self.backbone = ResNet(depth)
+        self.backbone = ResNet(depth, **backbone_kwargs)
         self.img_head = SimSiamHead(**head_kwargs)
         self.intra_video = intra_video
         self.register_buffer('iteration', torch.tensor(0, dtype=torch.float))  # base.py:39
@@ -523,8 +523,9 @@ HEAD_KW = {18: dict(in_channels=512, projection_mid_channels=512, projection_out
                     predictor_mid_channels=512, predictor_out_channels=2048)}
 
 
-def build_tracker(depth, intra_video=None):
-    """The two shipped model configs (configs/r18_*:2-26, configs/r50_*:2-26)."""
+def build_tracker(depth, intra_video=None, head_kw=None, **backbone_kwargs):
+    """The two shipped model configs (configs/r18_*:2-26, configs/r50_*:2-26); head_kw /
+    backbone_kwargs allow truncated variants for cheap tests."""
     if intra_video is None:
         intra_video = depth == 18
-    return SimSiamTracker(depth, HEAD_KW[depth], intra_video)
+    return SimSiamTracker(depth, head_kw or HEAD_KW[depth], intra_video, **backbone_kwargs)

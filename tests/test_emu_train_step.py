@@ -1,0 +1,216 @@
+"""The whole SimSiam train step (host engine + every kernel) on the CPU through the fiber
+emulator, against the oracle with bf16 storage emulation.  CPU only, tiny shapes."""
+import os
+
+import pytest
+import torch
+
+from oracle import vfs_oracle as O
+from tests.emu_util import emu_lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def emu_engine():
+    from vfs_amd import engine
+    eng = engine.Engine(lib=emu_lib())
+    engine.set_shared_engine(eng)
+    yield eng
+    engine._ENGINES.clear()
+
+
+def _l2rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+SHALLOW = dict(num_stages=2, strides=(1, 2), out_indices=(1,))
+SHALLOW_MINE = dict(SHALLOW, dilations=(1, 1))
+SHALLOW_HEAD = dict(in_channels=128, projection_mid_channels=128, projection_out_channels=128,
+                    predictor_mid_channels=64, predictor_out_channels=128)
+
+
+def _filled(depth, shallow=False):
+    """deterministic non-degenerate weights; the last BN gamma of every residual block is damped
+    (x0.25) so the net is reasonably conditioned (the reference zero-initialises them)."""
+    ref = O.build_tracker(depth, head_kw=SHALLOW_HEAD, **SHALLOW) if shallow else O.build_tracker(depth)
+    O.fill_state_dict_(ref, seed=3)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, O.BasicBlock):
+                m.conv2.bn.weight.mul_(0.25)
+            elif isinstance(m, O.Bottleneck):
+                m.conv3.bn.weight.mul_(0.25)
+    return ref
+
+
+def _run_oracle(depth, imgs, emulate, shallow=False):
+    ref = _filled(depth, shallow)
+    ref.set_emulate_bf16(emulate).train()
+    rl = ref.forward_train(imgs)
+    rloss, rlog = O.parse_losses(rl)
+    rloss.backward()
+    return ref, rlog
+
+
+@pytest.mark.parametrize('depth,shape', [(18, [8, 2, 3, 2, 32, 32]), (50, [16, 2, 3, 1, 32, 32])])
+def test_train_step_matches_oracle(emu_engine, depth, shape):
+    """bf16 storage makes a deep net chaotic at the ulp level (one rounding flip fans out through
+    every following 3x3 conv), so end-to-end equality with ANY other bf16 implementation is not a
+    meaningful bar; per-kernel parity on identical inputs is (tests/test_emu_conv.py,
+    test_emu_bn.py).  Here the bar is: the HIP pipeline is as close to the fp32 oracle (the
+    reference's arithmetic) as the oracle's own bf16-storage emulation is."""
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    imgs = O.fill_tensor(shape, seed=11, scale=2.0)
+    ref32, log32 = _run_oracle(depth, imgs, False)
+    refbf, logbf = _run_oracle(depth, imgs, True)
+    assert list(model.state_dict().keys()) == list(ref32.state_dict().keys())
+    model.load_state_dict(_filled(depth).state_dict())
+    model.train()
+
+    out = model.train_step(dict(imgs=imgs, label=torch.zeros(shape[0], 1)), None)
+    out['loss'].backward()
+
+    def bar(mine, emu):      # "as accurate as a bf16-storage pipeline can be"
+        return mine <= 1.6 * emu + 2e-3
+
+    assert list(out['log_vars'].keys()) == list(log32.keys())
+    for k in log32:
+        assert bar(abs(out['log_vars'][k] - log32[k]), abs(logbf[k] - log32[k])), (k, out['log_vars'][k], log32[k], logbf[k])
+    assert out['num_samples'] == shape[0]
+    msd, s32, sbf = model.state_dict(), ref32.state_dict(), refbf.state_dict()
+    for k in s32:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert bar(_l2rel(msd[k], s32[k]), _l2rel(sbf[k], s32[k])), k
+        if k.endswith('num_batches_tracked'):
+            assert int(msd[k]) == int(s32[k]) == 2, k
+    g32, gbf = dict(ref32.named_parameters()), dict(refbf.named_parameters())
+    ratios = []
+    for n, p in model.named_parameters():
+        r = g32[n].grad
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        if r.norm() < 1e-6:
+            assert p.grad.norm() < 5e-3, n        # Linear biases in front of a BatchNorm: exact 0 in fp32,
+                                                  # rounding residue of the bf16 dx column sums here
+            continue
+        mine, emu = _l2rel(p.grad, r), _l2rel(gbf[n].grad, r)
+        assert mine <= 2.0 * emu + 5e-3, (n, mine, emu)
+        ratios.append(mine / max(emu, 1e-4))
+    ratios.sort()
+    assert ratios[len(ratios) // 2] < 1.3, ratios[len(ratios) // 2]
+    # one fused SGD step
+    opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    opt.step()
+    for n, p in model.named_parameters():
+        want = before[n] - 0.05 * (grads[n] + 1e-4 * before[n])
+        assert torch.allclose(p.detach(), want, rtol=1e-5, atol=1e-7), n
+
+
+def _nchw(t):
+    return t.float().permute(0, 3, 1, 2).contiguous()
+
+
+def _maxrel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('depth,shape', [(18, [4, 2, 3, 2, 32, 32]), (50, [8, 2, 3, 1, 32, 32])])
+def test_every_stage_matches_oracle_on_engine_inputs(emu_engine, depth, shape):
+    """Tight orchestration check without the chaos: run the fused step, then for the stem, every
+    residual block, the head and the loss feed the ENGINE'S OWN input / incoming-gradient buffers
+    to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
+    and require outputs, input gradients and parameter gradients to agree to bf16 rounding."""
+    import vfs_amd
+    eng = emu_engine
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    ref = _filled(depth)
+    model.load_state_dict(ref.state_dict())
+    ref.set_emulate_bf16(True).train()
+    model.train()
+    imgs = O.fill_tensor(shape, seed=11, scale=2.0)
+    losses = model.forward_train(imgs)
+    ctx = model._ctx
+    loss, _ = model._parse_losses(losses)
+    loss.backward()
+    B = eng.bufs
+    Nv = ctx['Nv']
+    T = shape[3]
+    mg = dict(model.named_parameters())
+
+    def check_param_grads(prefix, module, tol=3e-2):
+        for n, p in module.named_parameters():
+            g = mg[f'{prefix}.{n}'].grad
+            if p.grad is None:
+                continue
+            if p.grad.norm() < 1e-3:     # biases in front of a BatchNorm: zero up to rounding residue
+                assert g.norm() < 5e-3, (prefix, n)
+            else:
+                assert _l2rel(g, p.grad) < tol, (prefix, n, _l2rel(g, p.grad))
+
+    def two_views(fn, x, g):
+        """apply fn to each view separately (separate BN batches), backprop g, return out, x.grad"""
+        x = x.clone().requires_grad_(True)
+        out = torch.cat([fn(x[:Nv]), fn(x[Nv:])])
+        out.backward(g)
+        return out.detach(), x.grad
+
+    # ---- loss: gradient wrt p from the engine's own p, z
+    p, z = ctx['p'].float(), ctx['z'].float()
+    p1, p2 = p[:Nv].clone().requires_grad_(True), p[Nv:].clone().requires_grad_(True)
+    ref.zero_grad()
+    rl = ref.forward_img_head.__func__  # noqa: F841  (documented entry; losses recomputed below)
+    w = 1.0 / T if ref.intra_video else 1.0
+    terms = [O.head_loss(p1, z[:Nv], p2, z[Nv:], w)]
+    if ref.intra_video:
+        z2v, p2v = O.images2video(z[Nv:], T), O.images2video(p2, T)
+        for i in range(1, T):
+            terms.append(O.head_loss(p1, z[:Nv], O.video2images(p2v.roll(i, dims=2)),
+                                     O.video2images(z2v.roll(i, dims=2)), w))
+    for i, t in enumerate(terms):
+        assert _maxrel(losses[f'img_head.{i}.loss_feat'].detach(), t.detach()) < 1e-4
+    sum(t.mean() for t in terms).backward()
+    dp = B['img_head.dp'].float()
+    assert _l2rel(dp[:Nv], p1.grad) < 1e-2 and _l2rel(dp[Nv:], p2.grad) < 1e-2
+
+    # ---- head: from the engine's backbone feature, gradient dp
+    feat = _nchw(ctx['bctx']['blocks'][-1]['out'])
+    ref.zero_grad()
+
+    def head_p(xv):
+        return ref.img_head(xv)[1]
+    pout, gfeat = two_views(head_p, feat, dp)
+    assert _maxrel(p, pout) < 2e-2
+    # five Linear+BN layers with a BN batch of Nv samples: rounding noise compounds to a few percent
+    assert _l2rel(_nchw(B['img_head.gfeat']), gfeat) < 0.1
+    check_param_grads('img_head', ref.img_head, tol=0.1)
+
+    # ---- residual blocks, last to first
+    names = []
+    for lname in model.backbone.res_layers:
+        for bi in range(len(getattr(model.backbone, lname))):
+            names.append((lname, bi))
+    g_in = _nchw(B['img_head.gfeat'])
+    for (lname, bi), bctx in reversed(list(zip(names, ctx['bctx']['blocks']))):
+        rblk = getattr(ref.backbone, lname)[bi]
+        ref.zero_grad()
+        out, gx = two_views(rblk, _nchw(bctx['x']), g_in)
+        assert _maxrel(_nchw(bctx['out']), out) < 1.2e-2, (lname, bi)
+        mine_gx = _nchw(B[f'backbone.{lname}.{bi}.conv1.gin'])
+        assert _l2rel(mine_gx, gx) < 3e-2, (lname, bi, _l2rel(mine_gx, gx))
+        check_param_grads(f'backbone.{lname}.{bi}', rblk)
+        g_in = mine_gx
+
+    # ---- stem + max-pool from the (bf16-rounded) frames
+    frames = torch.cat([O.video2images(imgs[:, v].contiguous()) for v in range(2)])
+    ref.zero_grad()
+
+    def stem(xv):
+        return ref.backbone.maxpool(ref.backbone.conv1(xv))
+    pooled, _ = two_views(stem, O.round_bf16(frames), g_in)
+    assert _maxrel(_nchw(ctx['bctx']['pooled']), pooled) < 1.2e-2
+    check_param_grads('backbone.conv1', ref.backbone.conv1)

@@ -1,0 +1,216 @@
+"""Host-side executor: sequences the libvfs_hip.so kernels for ResNet / SimSiam-head forward
+and backward over NHWC bf16 buffers.  PyTorch supplies device memory (torch.empty), streams and
+torch.distributed; every number on the path is produced by the HIP kernels.
+
+Layout of one "unit" (mmcv ConvModule = conv -> BN -> act in the reference):
+    raw = conv(a_prev)                 bf16, BatchNorm partial statistics from the GEMM epilogue
+    bnp = finalize(statistics)         float[G][4][C]   (G independent BN batches = views)
+    act = relu(raw*scale+shift [+res]) bf16
+Backward of a unit: bn_bwd_reduce -> (all-reduce) -> bn_bwd_apply -> wgrad (+dgrad).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from ._lib import get_lib
+from .packing import build_pack_table, wgrad_splits
+
+BF16 = torch.bfloat16
+
+
+class ConvUnit:
+    """Host state of one conv / linear layer (+ its BatchNorm)."""
+
+    def __init__(self, name, weight, bias, bn, k, stride, pad, kind='conv'):
+        self.name, self.weight, self.bias, self.bn = name, weight, bias, bn
+        self.k, self.stride, self.pad, self.kind = k, stride, pad, kind
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.wf = self.wd = None
+        self.bnp = self.sums = self.bsums = None
+        self.need_wd = True
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+
+
+class Engine:
+    def __init__(self, lib=None):
+        self.lib = lib if lib is not None else get_lib()
+        self.bufs = {}
+        self.units = []
+        self._pack = None
+        self._pack_key = None
+        self.process_group = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group)
+        return 1
+
+    @staticmethod
+    def stream(dev):
+        if dev.type == 'cuda':
+            return torch.cuda.current_stream(dev).cuda_stream
+        return None
+
+    def buf(self, key, shape, dtype, dev):
+        t = self.bufs.get(key)
+        shape = tuple(int(s) for s in shape)
+        if t is None or t.shape != shape or t.dtype != dtype or t.device != dev:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            self.bufs[key] = t
+        return t
+
+    def ws(self, key, numel, dtype, dev):
+        """grow-only flat workspace"""
+        t = self.bufs.get(key)
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != dev:
+            t = torch.empty(int(numel), dtype=dtype, device=dev)
+            self.bufs[key] = t
+        return t
+
+    def allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, group=self.process_group)
+
+    # ------------------------------------------------------------------ weights
+    def register(self, unit):
+        self.units.append(unit)
+        self._pack = None
+        return unit
+
+    def pack_weights(self):
+        """fp32 OIHW master weights -> bf16 MFMA layouts, all layers in ONE launch."""
+        if not self.units:
+            return
+        dev = self.units[0].weight.device
+        key = tuple((u.weight.data_ptr(), u.weight.device) for u in self.units)
+        if self._pack is None or self._pack_key != key:
+            entries = []
+            for u in self.units:
+                if u.kind == 'stem':
+                    u.wf = torch.zeros(u.cout, 8, 8, 4, dtype=BF16, device=dev)
+                    u.wd = None
+                else:
+                    u.wf = torch.empty(u.cout, u.k, u.k, u.cin, dtype=BF16, device=dev)
+                    u.wd = torch.empty(u.cin, u.k, u.k, u.cout, dtype=BF16, device=dev) if u.need_wd else None
+                entries.append((u.weight.data, u.wf, u.wd, 1 if u.kind == 'stem' else 0))
+            self._pack = build_pack_table(entries, dev)
+            self._pack_key = key
+        tab, n, total = self._pack
+        self.lib.pack_weights(tab, n, total, self.stream(dev))
+
+    # ------------------------------------------------------------------ forward primitives
+    def conv_fwd(self, u, x, N, H, W, G, train, tag=''):
+        """raw = conv(x); BN statistics/params when the unit has a BN.  Returns (raw, Ho, Wo)."""
+        dev = x.device
+        s = self.stream(dev)
+        lib = self.lib
+        if u.kind == 'stem':
+            Ho, Wo = (H + 6 - 7) // 2 + 1, (u.true_w + 6 - 7) // 2 + 1
+        else:
+            Ho, Wo = u.out_hw(H, W)
+        M = N * Ho * Wo
+        y = self.buf(f'{u.name}{tag}.raw', (N, Ho, Wo, u.cout), BF16, dev)
+        want_stats = u.bn is not None and train
+        Ng = N // G
+        mpg = Ng * Ho * Wo
+        fused = G == 1 or mpg % 128 == 0
+        nblk_g = (mpg + 127) // 128
+        partial = self.ws('ws.stats', G * nblk_g * 2 * u.cout, torch.float32, dev) if want_stats else None
+        bias = u.bias.data if u.bias is not None else None
+        groups = [(0, N, partial)] if fused else [
+            (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_stats else None) for g in range(G)]
+        for n0, nn_, part in groups:
+            if u.kind == 'stem':
+                lib.stem_fwd(x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
+            else:
+                lib.conv_fwd(x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
+                             u.k, u.k, u.stride, u.pad, s)
+        if u.bn is not None:
+            bn = u.bn
+            if train:
+                u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
+                u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
+                lib.bn_reduce_partials(partial, u.sums, G, nblk_g, u.cout, s)
+                self.allreduce(u.sums)
+                lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
+                                u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
+                bn.num_batches_tracked += G
+            else:
+                u.bnp = self.buf(f'{u.name}.bnp_eval', (1, 4, u.cout), torch.float32, dev)
+                lib.bn_eval_params(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, u.bnp, u.cout,
+                                   float(bn.eps), s)
+        return y, Ho, Wo
+
+    def bn_act(self, u, raw, M, G, train, relu, res=None, rres=None, rbnp=None, tag=''):
+        dev = raw.device
+        y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
+        mpg = M // G if train else M
+        self.lib.bn_act(raw, u.bnp, res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0, self.stream(dev))
+        return y
+
+    # ------------------------------------------------------------------ backward primitives
+    def bn_bwd(self, u, g, ymask, raw, M, G, want_gm=False):
+        """gradient wrt the raw conv output (and optionally the ReLU-masked incoming gradient)."""
+        dev = raw.device
+        s = self.stream(dev)
+        lib = self.lib
+        C = u.cout
+        mpg = M // G
+        ppb = math.gcd(mpg, 512)
+        if ppb < 16:
+            ppb = mpg
+        nblk = M // ppb
+        partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
+        u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
+        lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, s)
+        lib.bn_reduce_partials(partial, u.bsums, G, nblk // G, C, s)
+        lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
+        self.allreduce(u.bsums)
+        dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
+        gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
+        lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), s)
+        return dx, gm
+
+    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None):
+        """weight (and bias) gradients accumulate into .grad; returns the input gradient or None."""
+        dev = dx.device
+        s = self.stream(dev)
+        lib = self.lib
+        M = N * Ho * Wo
+        if u.kind == 'stem':
+            nsplit, pps = wgrad_splits(M, 64, 256)
+            partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)
+            lib.stem_wgrad(dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, s)
+            return None
+        ktot = u.k * u.k * u.cin
+        nsplit, pps = wgrad_splits(M, u.cout, ktot)
+        partial = self.ws('ws.wgrad', nsplit * u.cout * ktot, torch.float32, dev)
+        lib.conv_wgrad(dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad,
+                       nsplit, pps, s)
+        if u.bias is not None:
+            lib.bias_grad(dx, u.bias.grad, M, u.cout, s)
+        if not need_dgrad:
+            return None
+        gin = g_out if g_out is not None else self.buf(f'{u.name}.gin', (N, H, W, u.cin), BF16, dev)
+        lib.conv_dgrad(dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
+        return gin
+
+
+_ENGINES = {}
+
+
+def shared_engine(device=None):
+    """One Engine (buffer pool + packed weights) per process; one process drives one GPU."""
+    eng = _ENGINES.get('default')
+    if eng is None:
+        eng = _ENGINES['default'] = Engine()
+    return eng
+
+
+def set_shared_engine(eng):
+    _ENGINES['default'] = eng

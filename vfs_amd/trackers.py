@@ -1,0 +1,294 @@
+"""Trackers under the reference's registry names, constructors and call signatures
+(mmaction/models/trackers/base.py, sim_siam_base_tracker.py, vanilla_tracker.py).
+
+`forward_train` runs the whole two-view SimSiam step (frames -> NHWC4, ResNet, head, cosine
+loss) as one chain of HIP kernels and returns the reference's loss dict of UNREDUCED [N]
+tensors; `loss.backward()` (what mmcv's OptimizerHook calls) triggers the hand-written backward
+chain through a single autograd node, which accumulates into `param.grad` and -- when
+torch.distributed is initialised -- all-reduces the flat gradient arena over RCCL in buckets
+that overlap the remaining backward kernels (the DDP reducer's job in the reference,
+apis/train.py:62-66)."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import builder
+from .engine import BF16, shared_engine
+from .registry import TRACKERS
+from .resnet import ResNet
+
+
+def add_prefix(inputs, prefix):
+    """mmaction/utils/misc.py:30-46."""
+    return {f'{prefix}.{k}': v for k, v in inputs.items()}
+
+
+class _TrainStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, tracker, imgs):
+        ctx.tracker = tracker
+        return tracker._hip_forward_train(imgs)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.tracker._hip_backward(g)
+        return None, None, None
+
+
+class BaseTracker(nn.Module):
+    """trackers/base.py:12-156."""
+
+    def __init__(self, backbone, cls_head=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.backbone = builder.build_backbone(backbone)
+        if cls_head is not None:
+            self.cls_head = builder.build_head(cls_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights()
+        self.fp16_enabled = False
+        self.register_buffer('iteration', torch.tensor(0, dtype=torch.float))
+        self._flat = None
+
+    @property
+    def with_cls_head(self):
+        return hasattr(self, 'cls_head') and self.cls_head is not None
+
+    def init_weights(self):
+        self.backbone.init_weights()
+        if self.with_cls_head:
+            self.cls_head.init_weights()
+
+    def extract_feat(self, imgs):
+        return self.backbone(imgs)
+
+    def forward_train(self, imgs, labels=None):
+        raise NotImplementedError
+
+    def forward_test(self, imgs, **kwargs):
+        raise NotImplementedError
+
+    @staticmethod
+    def _parse_losses(losses):
+        """base.py:76-110: mean every entry, sum the keys containing 'loss', average each
+        log var over ranks.  The per-key all-reduces / .item() syncs of the reference are
+        batched into one small all-reduce and one host read; values are identical."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        packed = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        if dist.is_available() and dist.is_initialized():
+            packed = packed / dist.get_world_size()
+            dist.all_reduce(packed)
+        for k, v in zip(list(log_vars.keys()), packed.tolist()):
+            log_vars[k] = v
+        return loss, log_vars
+
+    def forward(self, imgs, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(imgs, **kwargs)
+        return self.forward_test(imgs, **kwargs)
+
+    def train_step(self, data_batch, optimizer, **kwargs):
+        """base.py:119-156; backward + optimizer step stay with the caller (OptimizerHook)."""
+        self.iteration += 1
+        losses = self(**data_batch)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(next(iter(data_batch.values()))))
+
+    def val_step(self, data_batch, optimizer, **kwargs):
+        losses = self(data_batch['imgs'], data_batch['ref_seg_map'], data_batch['img_meta'])
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(next(iter(data_batch.values()))))
+
+    # ------------------------------------------------------------------ flat parameter arena
+    def flatten_parameters(self):
+        """Move every parameter (and its gradient) into one fp32 arena each, keeping the
+        nn.Parameter objects and state_dict names: enables the one-launch SGD and bucketed
+        gradient all-reduce.  Call after .to(device)."""
+        params = [p for p in self.parameters()]
+        if not params:
+            return None
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            p.grad = gflat[o:o + p.numel()].view(p.shape)
+        self._flat = dict(params=flat, grads=gflat, offsets=offs, plist=params, device=dev)
+        return self._flat
+
+    def _ensure_arena(self):
+        p0 = next(self.parameters())
+        if self._flat is None or self._flat['device'] != p0.device or \
+                self._flat['plist'][0].data_ptr() != self._flat['params'].data_ptr():
+            self.flatten_parameters()
+        f = self._flat
+        if any(p.grad is None for p in f['plist']):     # zero_grad(set_to_none=True) happened
+            f['grads'].zero_()
+            for p, o in zip(f['plist'], f['offsets']):
+                p.grad = f['grads'][o:o + p.numel()].view(p.shape)
+        return f
+
+
+@TRACKERS.register_module()
+class SimSiamBaseTracker(BaseTracker):
+    """trackers/sim_siam_base_tracker.py:8-79."""
+
+    def __init__(self, *args, backbone, img_head=None, **kwargs):
+        super().__init__(*args, backbone=backbone, **kwargs)
+        if img_head is not None:
+            self.img_head = builder.build_head(img_head)
+        self.init_extra_weights()
+        self.intra_video = False
+        self.transpose_temporal = False
+        if self.train_cfg is not None:
+            self.intra_video = self.train_cfg.get('intra_video', False)
+            self.transpose_temporal = self.train_cfg.get('transpose_temporal', False)
+        self._anchor = None
+        self._ctx = None
+        self.grad_bucket_bytes = 25 * 1024 * 1024
+
+    @property
+    def with_img_head(self):
+        return hasattr(self, 'img_head') and self.img_head is not None
+
+    def init_extra_weights(self):
+        if self.with_img_head:
+            self.img_head.init_weights()
+
+    # ------------------------------------------------------------------ the HIP step
+    def _hip_forward_train(self, imgs):
+        eng = shared_engine()
+        dev = imgs.device
+        self.backbone.attach(eng)
+        self.img_head.attach(eng)
+        self._ensure_arena()
+        eng.pack_weights()
+        B, V, _, T, H, W = imgs.shape
+        Nv = B * T
+        N = V * Nv
+        Wp = W + (W & 1)
+        x4 = eng.buf('backbone.x4', (N, H, Wp, 4), BF16, dev)
+        s = eng.stream(dev)
+        eng.lib.imgs_to_nhwc4(imgs.contiguous().float(), x4, B, V, T, H, W, Wp, s)
+        outs, bctx = self.backbone.forward_nhwc(eng, x4, N, H, W, V, True)
+        last = max(outs)
+        feat, h, w, C = outs[last]
+        z, p, hctx = self.img_head.forward_nhwc(eng, feat, N, h, w, C, V, True)
+        K = T if self.intra_video else 1
+        weight = (1.0 / T if self.intra_video else 1.0) * float(self.img_head.loss_feat.loss_weight)
+        neg = int(self.img_head.loss_feat.negative)
+        loss = torch.empty(K, Nv, dtype=torch.float32, device=dev)
+        eng.lib.cosine_loss_fwd(p[:Nv], z[:Nv], p[Nv:], z[Nv:], loss, Nv, p.shape[1], T, K, neg, weight, s)
+        self._ctx = dict(bctx=bctx, hctx=hctx, z=z, p=p, Nv=Nv, T=T, K=K, weight=weight, neg=neg, last=last)
+        return loss
+
+    def _hip_backward(self, gl):
+        eng = shared_engine()
+        c = self._ctx
+        if c is None:
+            raise RuntimeError('backward called without a matching forward_train')
+        z, p, Nv = c['z'], c['p'], c['Nv']
+        dev = p.device
+        s = eng.stream(dev)
+        dp = eng.buf('img_head.dp', p.shape, BF16, dev)
+        gl = gl.contiguous().float()
+        eng.lib.cosine_loss_bwd(p[:Nv], z[:Nv], p[Nv:], z[Nv:], gl, dp[:Nv], dp[Nv:], Nv, p.shape[1], c['T'],
+                                c['K'], c['neg'], c['weight'], s)
+        gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
+        works = self._allreduce_range(self._head_range(), async_op=True)
+        self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat})
+        works += self._allreduce_range(self._backbone_range(), async_op=True)
+        for wk in works:
+            wk.wait()
+        self._ctx = None
+
+    # ------------------------------------------------------------------ data-parallel gradients
+    def _param_range(self, module):
+        f = self._flat
+        ids = {id(p) for p in module.parameters()}
+        offs = [(o, p.numel()) for p, o in zip(f['plist'], f['offsets']) if id(p) in ids]
+        if not offs:
+            return (0, 0)
+        return (min(o for o, _ in offs), max(o + (n + 3) // 4 * 4 for o, n in offs))
+
+    def _head_range(self):
+        return self._param_range(self.img_head)
+
+    def _backbone_range(self):
+        return self._param_range(self.backbone)
+
+    def _allreduce_range(self, rng, async_op=True):
+        """mean-all-reduce flat_grads[lo:hi] in ~25 MB buckets (torch DDP's default bucket size)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return []
+        lo, hi = rng
+        eng = shared_engine()
+        g = self._flat['grads']
+        world = dist.get_world_size()
+        step = max(1, self.grad_bucket_bytes // 4)
+        works = []
+        for a in range(lo, hi, step):
+            b = min(hi, a + step)
+            chunk = g[a:b]
+            if chunk.device.type == 'cuda':
+                eng.lib.scale(chunk, b - a, 1.0 / world, eng.stream(chunk.device))
+            else:
+                chunk.mul_(1.0 / world)
+            works.append(dist.all_reduce(chunk, async_op=async_op))
+        return [w for w in works if w is not None]
+
+    # ------------------------------------------------------------------ reference API
+    def forward_train(self, imgs, grids=None, label=None):
+        """imgs [B,2,3,T,H,W] -> {'img_head.{i}.loss_feat': [B*T]} (sim_siam_base_tracker.py:58-76)."""
+        if self.transpose_temporal:
+            imgs = imgs.transpose(1, 3).contiguous()
+        assert imgs.size(1) == 2
+        assert imgs.ndim == 6
+        if not self.with_img_head:
+            return dict()
+        if self._anchor is None or self._anchor.device != imgs.device:
+            self._anchor = torch.zeros(1, device=imgs.device, requires_grad=True)
+        loss = _TrainStepFn.apply(self._anchor, self, imgs)
+        losses = {f'{i}.loss_feat': loss[i] for i in range(loss.shape[0])}
+        return add_prefix(losses, prefix='img_head')
+
+    def forward_test(self, imgs, **kwargs):
+        raise NotImplementedError
+
+
+@TRACKERS.register_module()
+class VanillaTracker(BaseTracker):
+    """trackers/vanilla_tracker.py:16-206: DAVIS label propagation."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.save_np = self.test_cfg.get('save_np', False)
+
+    @property
+    def stride(self):
+        assert isinstance(self.backbone, ResNet)
+        end = self.backbone.original_out_indices[0]
+        return int(np.prod(self.backbone.strides[:end + 1]) * 4)
+
+    def forward_train(self, imgs, labels=None):
+        raise NotImplementedError
+
+    def forward_test(self, imgs, ref_seg_map, img_meta):
+        from .labelprop import forward_test_hip
+        return forward_test_hip(self, imgs, ref_seg_map, img_meta)
