@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Benchmark of the VFS training hot path on MI355X: frame-pairs/s of the SimSiam train step
+(forward_train + backward + SGD) on synthetic 256x256 clips.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one per-GPU batch: imgs [32, 2, 3, T, 256, 256]
+(BASELINE.json configs[1]: ResNet-18 r2_1xNx8, T=4 -> 128 frame-pairs per GPU per step;
+--model r50: configs[2] shape, T=1 -> 32 frame-pairs).  Inputs are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline(depth, size, threads):
+    """The oracle (CPU restatement of the reference's PyTorch path, fp32) timed on the host cores
+    on a bounded sample of the same workload."""
+    from oracle import vfs_oracle as O
+    torch.set_num_threads(threads)
+    T = 4 if depth == 18 else 1
+    B = 2 if depth == 18 else 4
+    model = O.build_tracker(depth).train()
+    params = [p for p in model.parameters()]
+    bufs = [None] * len(params)
+    imgs = torch.randn(B, 2, 3, T, size, size, generator=torch.Generator().manual_seed(0))
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss, _ = O.parse_losses(model.forward_train(imgs))
+        loss.backward()
+        with torch.no_grad():
+            O.sgd_step(params, [p.grad for p in params], bufs, lr=0.05)
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 10 and n < 20):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=B * T / dt, unit='frame-pairs/s', cores=threads, kind='port',
+                sample=f'oracle (fp32 torch-CPU restatement) R{depth} train step, imgs [{B},2,3,{T},{size},{size}], '
+                       f'1 warm-up + {n} timed steps, {dt * 1e3:.0f} ms/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--model', default='r18', choices=['r18', 'r50'])
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=32, help='videos per GPU (configs: videos_per_gpu=32)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import vfs_amd
+    from vfs_amd.engine import shared_engine
+    depth = 18 if args.model == 'r18' else 50
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    torch.manual_seed(0)
+    model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev).train()
+    flat = model.flatten_parameters()
+    if world > 1:
+        dist.broadcast(flat['params'], 0)
+    opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+    T = int(cfg.clip_len)
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = torch.randn(B, 2, 3, T, args.size, args.size, device=dev, generator=g)
+    batch = dict(imgs=imgs, label=torch.zeros(B, 1, device=dev))
+    eng = shared_engine()
+
+    def step():
+        out = model.train_step(batch, opt)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_roofline:
+        eng.prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, eng.prof = eng.prof, None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    pairs_per_step = B * T * world
+    res = {
+        'metric': 'frame-pairs/sec (train)', 'value': pairs_per_step * args.steps / dt, 'unit': 'frame-pairs/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'ResNet-{depth} SimSiam (VFS) forward_train+backward+SGD, imgs [{B},2,3,{T},{args.size},'
+                               f'{args.size}] per GPU (configs[{1 if depth == 18 else 2}] shape), SyncBN, fp32 master weights',
+                   'frame_pairs_per_step': pairs_per_step, 'parallelism': f'dp{world}'},
+        'loss': out['log_vars']['loss'],
+    }
+    if rank == 0 and prof:
+        agg = {}
+        for kind, flops, e0, e1 in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        kind = max(agg, key=lambda k: agg[k][1])
+        fl, tm, cnt = agg[kind]
+        ach = fl / tm / 1e12
+        res['roofline'] = {'kernel': kind, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None, 'launches': cnt,
+                           'avg_launch_ms': tm / cnt * 1e3,
+                           'time_share_of_step': tm / dt,
+                           'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'time_share_of_step': v[1] / dt}
+                                      for k, v in agg.items() if k != kind}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(depth, args.size, os.cpu_count() or 1)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,9 +1,10 @@
-"""BatchNorm / pooling / loss / SGD kernels through the CPU fiber emulator vs torch.  CPU only."""
+"""BatchNorm / pooling / loss / SGD kernels vs torch (CPU fp32) on the same bf16-rounded operands.
+backend=emu: fiber emulator on the CPU; backend=gpu: libvfs_hip.so on the MI355X."""
 import torch
 import torch.nn.functional as F
 
 from oracle import vfs_oracle as O
-from tests.emu_util import emu_lib, nchw, nhwc, rb, relerr
+from tests.emu_util import nchw, nhwc, rb, relerr
 
 
 def bn_forward_chain(lib, x_nhwc, gamma, beta, G, rm, rv):
@@ -23,8 +24,8 @@ def bn_forward_chain(lib, x_nhwc, gamma, beta, G, rm, rv):
     return bnp, mpg
 
 
-def test_bn_train_forward_two_groups_and_residuals():
-    lib = emu_lib()
+def test_bn_train_forward_two_groups_and_residuals(backend):
+    lib = backend.hostlib
     g = torch.Generator().manual_seed(0)
     N, C, H, W, G = 4, 64, 8, 8, 2
     x = rb(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
@@ -57,8 +58,8 @@ def test_bn_train_forward_two_groups_and_residuals():
     assert relerr(nchw(y), bn(x).detach()) < 6e-3
 
 
-def test_bn_backward_matches_autograd():
-    lib = emu_lib()
+def test_bn_backward_matches_autograd(backend):
+    lib = backend.hostlib
     g = torch.Generator().manual_seed(1)
     N, C, H, W, G = 4, 128, 4, 8, 2
     x = rb(torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
@@ -89,8 +90,8 @@ def test_bn_backward_matches_autograd():
     assert relerr(dgamma, gm_.grad) < 1e-4 and relerr(dbeta, bt_.grad) < 1e-4
 
 
-def test_stem_bn_relu_maxpool_fwd_bwd():
-    lib = emu_lib()
+def test_stem_bn_relu_maxpool_fwd_bwd(backend):
+    lib = backend.hostlib
     g = torch.Generator().manual_seed(2)
     N, C, H, W = 2, 64, 10, 12
     x = rb(torch.randn(N, C, H, W, generator=g))
@@ -117,8 +118,8 @@ def test_stem_bn_relu_maxpool_fwd_bwd():
     assert frac < 2e-3, frac
 
 
-def test_avgpool_bias_loss_sgd():
-    lib = emu_lib()
+def test_avgpool_bias_loss_sgd(backend):
+    lib = backend.hostlib
     g = torch.Generator().manual_seed(3)
     N, HW, C = 8, 6, 128
     x = rb(torch.randn(N, HW, C, generator=g))

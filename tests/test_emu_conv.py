@@ -1,24 +1,68 @@
-"""Conv kernels (forward / dgrad / wgrad / stem) run through the CPU fiber emulator and compared
-with torch conv2d on the same bf16-rounded operands.  CPU only."""
+"""Conv kernels (forward / dgrad / wgrad / stem) against torch conv2d (CPU, fp32) on the same
+bf16-rounded operands.  backend=emu: host build through the fiber emulator (CPU);
+backend=gpu: libvfs_hip.so on the MI355X."""
 import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.emu_util import emu_lib, nchw, nhwc, rb, relerr
+from tests.emu_util import nchw, nhwc, rb, relerr
 from vfs_amd.packing import build_pack_table, wgrad_splits
 
 
-def pack(lib, w, stem=False):
+def pack(be, w, stem=False):
     cout, cin, kh, kw = w.shape
+    dev = be.dev
+    w = w.to(dev)
     if stem:
-        wf = torch.zeros(cout, 8, 8, 4, dtype=torch.bfloat16)
+        wf = torch.zeros(cout, 8, 8, 4, dtype=torch.bfloat16, device=dev)
         wd = None
     else:
-        wf = torch.empty(cout, kh, kw, cin, dtype=torch.bfloat16)
-        wd = torch.empty(cin, kh, kw, cout, dtype=torch.bfloat16)
-    tab, n, total = build_pack_table([(w, wf, wd, 1 if stem else 0)], 'cpu')
-    lib.pack_weights(tab, n, total, None)
+        wf = torch.empty(cout, kh, kw, cin, dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(cin, kh, kw, cout, dtype=torch.bfloat16, device=dev)
+    tab, n, total = build_pack_table([(w, wf, wd, 1 if stem else 0)], dev)
+    be.lib.pack_weights(tab, n, total, None)
     return wf, wd
+
+
+def run_conv_case(be, N, H, W, Cin, Cout, k, stride, pad, wgrad_blocks=12):
+    lib, d = be.lib, be.d
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    wf, wd = pack(be, w)
+    assert torch.equal(wf.float().cpu(), w.permute(0, 2, 3, 1))
+    assert torch.equal(wd.float().cpu(), w.permute(1, 2, 3, 0))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xh = d(nhwc(x))
+    M = N * Ho * Wo
+    y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16, device=be.dev)
+    nblk = (M + 127) // 128
+    stats = torch.full((nblk, 2, Cout), float('nan'), device=be.dev)
+    bias = torch.randn(Cout, generator=g)
+    lib.conv_fwd(xh, wf, y, d(bias), stats, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
+    ref = F.conv2d(x, w, bias, stride, pad)
+    assert relerr(nchw(y.cpu()), ref) < 6e-3          # one bf16 rounding of the output
+    yf = y.float().cpu().reshape(M, Cout)
+    assert torch.isfinite(yf).all()
+    pad_rows = nblk * 128 - M
+    blk = torch.cat([yf, torch.zeros(pad_rows, Cout)]).reshape(nblk, 128, Cout)
+    assert torch.allclose(stats[:, 0].cpu(), blk.sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(stats[:, 1].cpu(), (blk * blk).sum(1), rtol=1e-4, atol=2e-3)
+
+    # ---- dgrad (+ fused residual-gradient add) and wgrad vs autograd
+    dy = rb(torch.randn(N, Cout, Ho, Wo, generator=g))
+    add = rb(torch.randn(N, Cin, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride, pad).backward(dy)
+    dx = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=be.dev)
+    lib.conv_dgrad(d(nhwc(dy)), wd, dx, d(nhwc(add)), N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
+    assert relerr(nchw(dx.cpu()), xr.grad + add) < 6e-3
+    nsplit, pps = wgrad_splits(M, Cout, k * k * Cin, target_blocks=wgrad_blocks)
+    partial = torch.full((nsplit, Cout, k * k * Cin), float('nan'), device=be.dev)
+    grad = torch.ones(Cout, Cin, k, k, device=be.dev)
+    lib.conv_wgrad(d(nhwc(dy)), xh, partial, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, nsplit, pps, None)
+    assert relerr(grad.cpu() - 1.0, wr.grad) < 3e-4    # fp32 accumulate / fp32 output, accumulates into grad
 
 
 CASES = [  # N, H, W, Cin, Cout, k, stride, pad
@@ -30,69 +74,50 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', CASES)
-def test_conv_fwd_dgrad_wgrad(N, H, W, Cin, Cout, k, stride, pad):
-    lib = emu_lib()
-    g = torch.Generator().manual_seed(N * 100 + H)
-    x = rb(torch.randn(N, Cin, H, W, generator=g))
-    w = rb(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
-    wf, wd = pack(lib, w)
-    assert torch.equal(wf.float(), w.permute(0, 2, 3, 1))
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    xh = nhwc(x)
-    M = N * Ho * Wo
-    y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16)
-    nblk = (M + 127) // 128
-    stats = torch.full((nblk, 2, Cout), float('nan'))
-    bias = torch.randn(Cout, generator=g)
-    lib.conv_fwd(xh, wf, y, bias, stats, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
-    ref = F.conv2d(x, w, bias, stride, pad)
-    assert relerr(nchw(y), ref) < 6e-3          # one bf16 rounding of the output
-    yf = y.float().reshape(M, Cout)
-    assert torch.isfinite(yf).all()
-    for b in range(nblk):
-        blk = yf[b * 128:(b + 1) * 128]
-        assert torch.allclose(stats[b, 0], blk.sum(0), rtol=1e-4, atol=1e-3)
-        assert torch.allclose(stats[b, 1], (blk * blk).sum(0), rtol=1e-4, atol=1e-3)
-
-    # ---- dgrad (+ fused residual-gradient add) and wgrad vs autograd
-    dy = rb(torch.randn(N, Cout, Ho, Wo, generator=g))
-    add = rb(torch.randn(N, Cin, H, W, generator=g))
-    xr = x.clone().requires_grad_(True)
-    wr = w.clone().requires_grad_(True)
-    F.conv2d(xr, wr, None, stride, pad).backward(dy)
-    dx = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16)
-    lib.conv_dgrad(nhwc(dy), wd, dx, nhwc(add), N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
-    assert relerr(nchw(dx), xr.grad + add) < 6e-3
-    nsplit, pps = wgrad_splits(M, Cout, k * k * Cin, target_blocks=12)
-    partial = torch.full((nsplit, Cout, k * k * Cin), float('nan'))
-    grad = torch.ones(Cout, Cin, k, k)
-    lib.conv_wgrad(nhwc(dy), xh, partial, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, nsplit, pps, None)
-    assert relerr(grad - 1.0, wr.grad) < 2e-4    # fp32 accumulate / fp32 output, accumulates into grad
+def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
+    run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
 
 
-def test_stem_fwd_wgrad():
-    lib = emu_lib()
+BIG_CASES = [  # the layer shapes of the bench configs (per-GPU batch reduced), ragged M included
+    (8, 64, 64, 64, 64, 3, 1, 1),      # R18 layer1 @256
+    (8, 64, 64, 64, 128, 3, 2, 1),     # R18 layer2.0.conv1
+    (8, 16, 16, 256, 512, 3, 2, 1),    # layer4.0.conv1
+    (16, 8, 8, 512, 512, 3, 1, 1),     # layer4
+    (4, 64, 64, 64, 256, 1, 1, 0),     # R50 layer1 conv3
+    (4, 32, 32, 512, 1024, 1, 2, 0),   # R50 layer3 downsample
+    (3, 60, 107, 64, 64, 3, 1, 1),     # DAVIS-sized feature map, ragged pixel tiles
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', BIG_CASES)
+def test_conv_bench_shapes(gpu_backend, N, H, W, Cin, Cout, k, stride, pad):
+    run_conv_case(gpu_backend, N, H, W, Cin, Cout, k, stride, pad, wgrad_blocks=1024)
+
+
+def test_stem_fwd_wgrad(backend):
+    lib, d, dev = backend.lib, backend.d, backend.dev
     g = torch.Generator().manual_seed(5)
-    N, H, W = 2, 20, 18
+    N, H, W = (2, 20, 18) if backend.name == 'emu' else (6, 96, 128)
     x = rb(torch.randn(N, 3, H, W, generator=g))
     w = rb(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
-    wf, _ = pack(lib, w, stem=True)
+    wf, _ = pack(backend, w, stem=True)
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     # reference input layout [B][V][3][T][H][W] with B=N, V=1, T=1
-    x4 = torch.full((N, H, W, 4), float('nan'), dtype=torch.bfloat16)
-    lib.imgs_to_nhwc4(x.reshape(N, 1, 3, 1, H, W).contiguous(), x4, N, 1, 1, H, W, W, None)
-    assert torch.equal(x4[..., :3].float(), x.permute(0, 2, 3, 1)) and (x4[..., 3] == 0).all()
+    x4 = torch.full((N, H, W, 4), float('nan'), dtype=torch.bfloat16, device=dev)
+    lib.imgs_to_nhwc4(d(x.reshape(N, 1, 3, 1, H, W).contiguous()), x4, N, 1, 1, H, W, W, None)
+    assert torch.equal(x4[..., :3].float().cpu(), x.permute(0, 2, 3, 1)) and (x4[..., 3] == 0).all()
     M = N * Ho * Wo
-    y = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16)
-    stats = torch.zeros((M + 127) // 128, 2, 64)
+    y = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros((M + 127) // 128, 2, 64, device=dev)
     lib.stem_fwd(x4, wf, y, stats, N, H, W, Ho, Wo, None)
     ref = F.conv2d(x, w, None, 2, 3)
-    assert relerr(nchw(y), ref) < 6e-3
+    assert relerr(nchw(y.cpu()), ref) < 6e-3
     dy = rb(torch.randn(N, 64, Ho, Wo, generator=g))
     wr = w.clone().requires_grad_(True)
     F.conv2d(x, wr, None, 2, 3).backward(dy)
-    nsplit, pps = wgrad_splits(M, 64, 256, target_blocks=6)
-    partial = torch.zeros(nsplit, 64, 256)
-    grad = torch.zeros(64, 3, 7, 7)
-    lib.stem_wgrad(nhwc(dy), x4, partial, grad, N, H, W, Ho, Wo, nsplit, pps, None)
-    assert relerr(grad, wr.grad) < 2e-4
+    nsplit, pps = wgrad_splits(M, 64, 256, target_blocks=6 if backend.name == 'emu' else 256)
+    partial = torch.zeros(nsplit, 64, 256, device=dev)
+    grad = torch.zeros(64, 3, 7, 7, device=dev)
+    lib.stem_wgrad(d(nhwc(dy)), x4, partial, grad, N, H, W, Ho, Wo, nsplit, pps, None)
+    assert relerr(grad.cpu(), wr.grad) < 3e-4

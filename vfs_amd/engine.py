@@ -42,6 +42,7 @@ class Engine:
         self._pack = None
         self._pack_key = None
         self.process_group = None
+        self.prof = None     # list collecting (kind, flops, start_event, end_event) when profiling
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -71,6 +72,17 @@ class Engine:
             t = torch.empty(int(numel), dtype=dtype, device=dev)
             self.bufs[key] = t
         return t
+
+    def timed(self, kind, flops, dev, fn, *args):
+        """launch through `fn`; with profiling on, bracket it with events on the launch stream"""
+        if self.prof is None or dev.type != 'cuda':
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.prof.append((kind, flops, e0, e1))
+        return rc
 
     def allreduce(self, t):
         if self.world > 1:
@@ -126,10 +138,12 @@ class Engine:
             (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_stats else None) for g in range(G)]
         for n0, nn_, part in groups:
             if u.kind == 'stem':
-                lib.stem_fwd(x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
+                self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * 64 * 147, dev, lib.stem_fwd,
+                           x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
             else:
-                lib.conv_fwd(x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
-                             u.k, u.k, u.stride, u.pad, s)
+                self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin, dev, lib.conv_fwd,
+                           x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
+                           u.k, u.k, u.stride, u.pad, s)
         if u.bn is not None:
             bn = u.bn
             if train:
@@ -185,19 +199,22 @@ class Engine:
         if u.kind == 'stem':
             nsplit, pps = wgrad_splits(M, 64, 256)
             partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)
-            lib.stem_wgrad(dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, s)
+            self.timed('conv_wgrad', 2.0 * M * 64 * 147, dev, lib.stem_wgrad,
+                       dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, s)
             return None
         ktot = u.k * u.k * u.cin
         nsplit, pps = wgrad_splits(M, u.cout, ktot)
         partial = self.ws('ws.wgrad', nsplit * u.cout * ktot, torch.float32, dev)
-        lib.conv_wgrad(dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad,
-                       nsplit, pps, s)
+        flops = 2.0 * M * u.cout * ktot
+        self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho, Wo,
+                   u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, s)
         if u.bias is not None:
             lib.bias_grad(dx, u.bias.grad, M, u.cout, s)
         if not need_dgrad:
             return None
         gin = g_out if g_out is not None else self.buf(f'{u.name}.gin', (N, H, W, u.cin), BF16, dev)
-        lib.conv_dgrad(dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
+        self.timed('conv_igemm', flops, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
+                   u.k, u.k, u.stride, u.pad, s)
         return gin
 
 
