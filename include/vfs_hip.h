@@ -115,6 +115,24 @@ int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long lo
                  float momentum, float weight_decay, vfs_stream_t stream);
 int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream);
 
+/* ---- DAVIS label propagation (VanillaTracker.forward_test, vanilla_tracker.py:80-206) -------
+ * F.normalize(dim=channel) of NHWC rows, once per frame when it enters the bank
+ * (local_attention.py:277-279 does it on every propagation step) */
+int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stream_t stream);
+/* masked_attention_efficient (local_attention.py:237-348) + spatial_neighbor 'circle'
+ * (affinity_utils.py:144-156): fbank [frames][H*W][C] normalised bf16, sbank [frames][H*W][CO]
+ * fp32; key frames kslot[0..nkeys) in the reference's order (first frame first, duplicates
+ * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), topk <= 10. */
+int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, int qframe, const int* kslot,
+                  int nkeys, int H, int W, int C, int CO, int radius, int topk, float temperature,
+                  vfs_stream_t stream);
+/* bilinear upsample (align_corners=False) + per-channel min-max normalisation where max > 0 +
+ * argmax -> uint8 [Ho][Wo] (vanilla_tracker.py:162-181); partial: workspace float[64*CO*2] */
+int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho,
+                        int Wo, vfs_stream_t stream);
+/* F.one_hot of the resized first-frame label map into the seg bank (vanilla_tracker.py:96-100) */
+int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

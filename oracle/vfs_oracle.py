@@ -424,7 +424,7 @@ def seg_postprocess(seg_logit, out_hw):
 
 
 def label_propagate(feats, ref_seg_map, out_hw, *, precede_frames=20, topk=10, temperature=0.07,
-                    neighbor_range=None, with_first=True, dtype=None, return_logits=False):
+                    neighbor_range=None, with_first=True, dtype=None, return_logits=False, normalize=True):
     """vanilla_tracker.py:80-206 given the feature bank ``feats`` [1,C,T,h,w]
     (what get_feats returns) and the first-frame uint8 labels [H,W].
     Returns uint8 [T,H_out,W_out] (frame 0 = nearest-resized ground truth)."""
@@ -443,7 +443,7 @@ def label_propagate(feats, ref_seg_map, out_hw, *, precede_frames=20, topk=10, t
         if with_first:   # frame 0 is prepended even when it is already in the window
             k = torch.cat([feats[:, :, 0:1], k], dim=2)
             v = torch.cat([seg_bank[0].unsqueeze(2), v], dim=2)
-        seg = masked_attention_efficient(q, k, v, mask, temperature, topk, True, dtype=dtype).float()
+        seg = masked_attention_efficient(q, k, v, mask, temperature, topk, normalize, dtype=dtype).float()
         seg_bank.append(seg)
         logits.append(seg)
         preds.append(seg_postprocess(seg, out_hw)[0])

@@ -101,3 +101,25 @@ int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);
 // fused SGD over the flat parameter arena (torch.optim.SGD, dampening 0, no nesterov)
 int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, hipStream_t s);
 int vfs_scale_launch(float* p, long long n, float scale, hipStream_t s);
+
+// ---- labelprop.hip -------------------------------------------------------------------------
+#define LP_MAX_KEYS 24
+#define LP_MAX_CLASSES 256
+#define LP_POST_BLOCKS 64
+struct LabelPropArgs {
+  const bf16_t* fbank;  // [frames][H*W][C] L2-normalised bf16 features (the clip's feature bank)
+  const float* sbank;   // [frames][H*W][CO] fp32 value logits (frame 0 = one-hot labels)
+  float* out;           // [H*W][CO] propagated logits of the query frame
+  int qframe;           // bank index of the query frame
+  int nkeys;            // number of key frames, in the reference's order (first frame first)
+  int kslot[LP_MAX_KEYS];
+  int H, W, C, CO;
+  int radius;           // neighbor_range // 2 (mask: distance < radius); <= 0: no spatial mask
+  int topk;             // <= 10
+  float inv_temp;
+};
+int vfs_l2norm_rows_launch(const bf16_t* x, bf16_t* y, long long P, int C, hipStream_t s);
+int vfs_labelprop_launch(const LabelPropArgs& a, hipStream_t s);
+int vfs_seg_postprocess_launch(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
+                               hipStream_t s);
+int vfs_onehot_launch(const uint8_t* lab, float* out, int P, int CO, hipStream_t s);
