@@ -23,6 +23,26 @@ sys.path.insert(0, REPO)
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, MI355X_MICROARCH.md
 
 
+def log(*a):
+    print(f'[bench {time.strftime("%H:%M:%S")}]', *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline_subprocess(depth, size, threads, timeout=240):
+    """run cpu_baseline() in a child so a pathological host (thread oversubscription) cannot
+    hang the benchmark; returns the dict or a null entry with the reason"""
+    import subprocess
+    code = (f'import sys, json; sys.path.insert(0, {REPO!r}); import bench; '
+            f'print("CPUBASE " + json.dumps(bench.cpu_baseline({depth}, {size}, {threads})))')
+    try:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout)
+        for line in out.stdout.splitlines():
+            if line.startswith('CPUBASE '):
+                return json.loads(line[8:])
+        return dict(value=None, unit='frame-pairs/s', cores=threads, kind='port', sample='failed: ' + out.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='frame-pairs/s', cores=threads, kind='port', sample=f'timed out after {timeout}s')
+
+
 def cpu_baseline(depth, size, threads):
     """The oracle (CPU restatement of the reference's PyTorch path, fp32) timed on the host cores
     on a bounded sample of the same workload."""
@@ -44,7 +64,7 @@ def cpu_baseline(depth, size, threads):
             O.sgd_step(params, [p.grad for p in params], bufs, lr=0.05)
     step()
     n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < 10 and n < 20):
+    while n < 2 or (time.perf_counter() - t0 < 10 and n < 20):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
@@ -99,14 +119,25 @@ def main():
         opt.step()
         return out
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         out = step()
+        torch.cuda.synchronize()
+        log(f'warmup step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms, loss {out["log_vars"]["loss"]:.4f}')
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_roofline:
+        # count the instrumented launches of one step, then pre-create every event the timed
+        # region will need so that only hipEventRecord is left inside it
         eng.prof = []
+        step()
+        torch.cuda.synchronize()
+        per_step = len(eng.prof)
+        eng.prof_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step * args.steps + 16)]
+        eng.prof = []
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -115,6 +146,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    log(f'{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step')
     prof, eng.prof = eng.prof, None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -148,7 +180,8 @@ def main():
                            'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'time_share_of_step': v[1] / dt}
                                       for k, v in agg.items() if k != kind}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(depth, args.size, os.cpu_count() or 1)
+        log('timing the CPU oracle (bounded sample) ...')
+        res['cpu_baseline'] = cpu_baseline_subprocess(depth, args.size, min(os.cpu_count() or 1, 64))
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

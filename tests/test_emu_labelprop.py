@@ -31,24 +31,29 @@ def run_labelprop_case(be, T, H, W, C, CO, radius, slots, qframe, topk=10, seed=
     out = torch.full((H * W, CO), float('nan'))
     ks = (ctypes.c_int * len(slots))(*slots)
     lib.labelprop(fb, seg, out, qframe, ks, len(slots), H, W, C, CO, radius, topk, 0.07, None)
-    # oracle on the SAME normalised bf16 features (normalize=False), reference tensor layout
-    fn = fb.float()
+    # oracle on the SAME normalised bf16 features (normalize=False), reference tensor layout, fp64
+    fn = fb.double()
     q = fn[qframe].t().reshape(1, C, H, W)
     k = torch.stack([fn[s].t().reshape(C, H, W) for s in slots], dim=1)[None]
-    v = torch.stack([seg[s].t().reshape(CO, H, W) for s in slots], dim=1)[None]
+    v = torch.stack([seg[s].t().reshape(CO, H, W) for s in slots], dim=1)[None].double()
     mask = O.spatial_neighbor_circle(H, W, 2 * radius) if radius > 0 else None
     ref = O.masked_attention_efficient(q, k, v, mask, 0.07, topk, normalize=False)
-    ref = ref[0].reshape(CO, H * W).t()
-    ref64 = O.masked_attention_efficient(q, k, v, mask, 0.07, topk, normalize=False, dtype=torch.float64)
-    ref64 = ref64[0].reshape(CO, H * W).t().float()
+    ref = ref[0].reshape(CO, H * W).t().float()
     assert torch.isfinite(out).all()
     err = (out - ref).abs().max(dim=1)[0]
-    # near-ties between the 10th and 11th candidate may legitimately resolve differently under a
-    # different fp32 summation order; the fp32 and fp64 oracles disagree on exactly those queries
-    ambiguous = (ref - ref64).abs().max(dim=1)[0] > 1e-4
-    bad = (err > 2e-4) & ~ambiguous
-    assert not bad.any(), (int(bad.sum()), float(err.max()))
-    assert ambiguous.float().mean() < 0.02
+    bad = torch.nonzero(err > 2e-4).flatten()
+    # A different fp32 summation order may legitimately swap the 10th and 11th candidate when they
+    # are (nearly) tied -- torch.topk itself leaves ties unspecified.  Every query that differs
+    # must be explained by such a near-tie in the exact (fp64) scores.
+    assert len(bad) < 0.05 * H * W + 1, len(bad)
+    if len(bad):
+        kv = k[0].reshape(C, -1)                                   # [C, T*HW]
+        sc = (kv.t() @ q[0].reshape(C, -1)[:, bad]) / 0.07         # [T*HW, nbad]
+        if mask is not None:
+            sc.masked_fill_(~mask[:, bad].repeat(len(slots), 1), float('-inf'))
+        top = sc.topk(topk + 1, dim=0)[0]
+        gap = top[topk - 1] - top[topk]
+        assert (gap < 2e-4).all(), (float(gap.max()), int((gap >= 2e-4).sum()))
     return out
 
 
@@ -56,6 +61,7 @@ def run_labelprop_case(be, T, H, W, C, CO, radius, slots, qframe, topk=10, seed=
     dict(T=6, H=12, W=16, C=64, CO=3, radius=4, slots=[0, 1, 2, 3, 4], qframe=5),
     dict(T=4, H=9, W=13, C=128, CO=5, radius=3, slots=[0, 0, 1, 2], qframe=3),       # duplicated first frame, ragged tiles
     dict(T=3, H=8, W=8, C=64, CO=2, radius=0, slots=[0, 1], qframe=2, topk=5),       # no spatial mask
+    dict(T=3, H=20, W=28, C=64, CO=3, radius=6, slots=[0, 1], qframe=2),             # several 128-key blocks per window
 ])
 def test_labelprop_matches_oracle(backend, case):
     run_labelprop_case(backend, **case)

@@ -77,7 +77,11 @@ class Engine:
         """launch through `fn`; with profiling on, bracket it with events on the launch stream"""
         if self.prof is None or dev.type != 'cuda':
             return fn(*args)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pool = getattr(self, 'prof_pool', None)
+        if pool:                       # pre-created events: creation is the expensive part
+            e0, e1 = pool.pop(), pool.pop()
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
