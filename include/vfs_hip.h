@@ -71,8 +71,8 @@ int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stre
  * per group.  sums: double[G][2][C]; between reduce_partials and finalize the host all-reduces
  * `sums` across ranks for SyncBN (count = global element count per channel per group).
  * bnp: float[G][4][C] = {scale, shift, mean, invstd}. */
-int vfs_bn_reduce_partials(const float* partial, double* sums, int G, int bpg, int C,
-                           vfs_stream_t stream);
+int vfs_bn_reduce_partials(const float* partial, double* sums, double* scratch, int G, int bpg, int C,
+                           vfs_stream_t stream); /* scratch: double[G][128][2][C] or NULL */
 int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp,
                     float* running_mean, float* running_var, int G, int C, double count, float eps,
                     float momentum, vfs_stream_t stream);
@@ -87,13 +87,15 @@ int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_
                         int W, int C, int Hp, int Wp, int npg, vfs_stream_t stream);
 int vfs_maxpool_relu_bwd(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, vfs_bf16* ga,
                          int N, int H, int W, int C, int Hp, int Wp, vfs_stream_t stream);
-/* BN backward: pass 1 -> partial[nblk][2][C] (S1 = sum gm, S2 = sum gm*xhat, gm = g*(y>0));
- * then vfs_bn_reduce_partials -> sums (all-reduce for SyncBN) -> pass 2 */
+/* BN backward: pass 1 -> partial[nblk][2][C] (S1 = sum gm, S2 = sum gm*xhat, gm = g*mask);
+ * then vfs_bn_reduce_partials -> sums (all-reduce for SyncBN) -> pass 2.
+ * mask: y != NULL -> (y > 0) (residual units); y == NULL && relu -> (x*scale+shift > 0); else 1 */
 int vfs_bn_bwd_reduce(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp,
-                      float* partial, long long M, int C, int mpg, int ppb, vfs_stream_t stream);
+                      float* partial, long long M, int C, int mpg, int ppb, int relu,
+                      vfs_stream_t stream);
 int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp,
                      const double* sums, vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg,
-                     double count, vfs_stream_t stream);
+                     double count, int relu, vfs_stream_t stream);
 int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C,
                       vfs_stream_t stream);
 

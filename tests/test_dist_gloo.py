@@ -1,0 +1,56 @@
+"""Data-parallel path on the CPU: 2 gloo ranks, each running the fused step (kernels through the
+fiber emulator) on half of the batch, must reproduce the single-process full-batch step:
+SyncBN statistics all-reduced per view, gradients mean-all-reduced in buckets, log vars averaged
+(reference: MMDistributedDataParallel + SyncBN + _parse_losses, apis/train.py:58-66,
+trackers/base.py:103-108)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, 'tests', 'dist_worker.py')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_equal_one_process(tmp_path):
+    from tests.emu_util import emu_lib
+    emu_lib()                                  # build once, before the ranks race for it
+    single = str(tmp_path / 'single.npz')
+    env0 = dict(os.environ, WORLD_SIZE='1', RANK='0')
+    subprocess.run([sys.executable, WORKER, single], check=True, env=env0, timeout=600)
+    port = str(_free_port())
+    procs, outs = [], []
+    for r in range(2):
+        o = str(tmp_path / f'rank{r}.npz')
+        outs.append(o)
+        env = dict(os.environ, WORLD_SIZE='2', RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, WORKER, o], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    s = np.load(single)
+    r0, r1 = np.load(outs[0]), np.load(outs[1])
+
+    def l2(a, b):
+        return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+    for k in s.files:
+        if k.startswith('log/'):
+            assert abs(float(r0[k]) - float(s[k])) < 2e-3 and abs(float(r0[k]) - float(r1[k])) < 1e-6, k
+        elif k.startswith('buf/'):
+            assert l2(r0[k], s[k]) < 1e-4 and np.array_equal(r0[k], r1[k]), k
+        elif k.startswith('grad/'):
+            assert np.array_equal(r0[k], r1[k]), k             # both ranks hold the reduced gradient
+            if np.linalg.norm(s[k]) > 1e-3:
+                assert l2(r0[k], s[k]) < 3e-2, (k, l2(r0[k], s[k]))
+        elif k.startswith('param/'):
+            assert np.array_equal(r0[k], r1[k]), k             # replicas stay in lock-step after SGD

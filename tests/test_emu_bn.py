@@ -18,7 +18,7 @@ def bn_forward_chain(lib, x_nhwc, gamma, beta, G, rm, rv):
     partial = torch.stack([torch.stack([xf[b * ppb:(b + 1) * ppb].sum(0), (xf[b * ppb:(b + 1) * ppb] ** 2).sum(0)])
                            for b in range(nblk)])
     sums = torch.zeros(G, 2, C, dtype=torch.float64)
-    lib.bn_reduce_partials(partial, sums, G, nblk // G, C, None)
+    lib.bn_reduce_partials(partial, sums, torch.zeros(G * 128 * 2 * C, dtype=torch.float64), G, nblk // G, C, None)
     bnp = torch.zeros(G, 4, C)
     lib.bn_finalize(sums, gamma, beta, bnp, rm, rv, G, C, float(mpg), 1e-5, 0.1, None)
     return bnp, mpg
@@ -77,14 +77,16 @@ def test_bn_backward_matches_autograd(backend):
     ppb = 32
     nblk = M // ppb
     partial = torch.zeros(nblk, 2, C)
-    lib.bn_bwd_reduce(nhwc(gout), y, nhwc(x), bnp, partial, M, C, mpg, ppb, None)
-    sums = torch.zeros(G, 2, C, dtype=torch.float64)
-    lib.bn_reduce_partials(partial, sums, G, nblk // G, C, None)
-    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16)
-    gmask = torch.empty(N, H, W, C, dtype=torch.bfloat16)
-    lib.bn_bwd_apply(nhwc(gout), y, nhwc(x), bnp, sums, dx, gmask, M, C, mpg, float(mpg), None)
-    assert relerr(nchw(dx), xs.grad) < 8e-3
-    assert torch.equal(nchw(gmask), gout * (nchw(y) > 0))
+    scratch = torch.zeros(G * 128 * 2 * C, dtype=torch.float64)
+    for ymask, relu in ((y, 0), (None, 1)):       # mask from the stored output / recomputed from x
+        lib.bn_bwd_reduce(nhwc(gout), ymask, nhwc(x), bnp, partial, M, C, mpg, ppb, relu, None)
+        sums = torch.zeros(G, 2, C, dtype=torch.float64)
+        lib.bn_reduce_partials(partial, sums, scratch, G, nblk // G, C, None)
+        dx = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+        gmask = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+        lib.bn_bwd_apply(nhwc(gout), ymask, nhwc(x), bnp, sums, dx, gmask, M, C, mpg, float(mpg), relu, None)
+        assert relerr(nchw(dx), xs.grad) < 8e-3
+        assert torch.equal(nchw(gmask), gout * (nchw(y) > 0))
     dgamma, dbeta = torch.zeros(C), torch.zeros(C)
     lib.bn_param_grad(sums, dgamma, dbeta, G, C, None)
     assert relerr(dgamma, gm_.grad) < 1e-4 and relerr(dbeta, bt_.grad) < 1e-4
@@ -169,3 +171,15 @@ def test_avgpool_bias_loss_sgd(backend):
         opt.step()
         lib.sgd_step(p, gr, buf, n, 0.05, 0.9, 1e-4, None)
     assert relerr(p, pr.detach()) < 1e-6
+
+
+def test_bn_reduce_partials_two_stage(backend):
+    """row counts above 64 take the chunked two-stage path; result must equal the fp64 column sums"""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(4)
+    G, bpg, C = 2, 1000, 96
+    partial = torch.randn(G * bpg, 2, C, generator=g)
+    sums = torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_reduce_partials(partial, sums, torch.zeros(G * 128 * 2 * C, dtype=torch.float64), G, bpg, C, None)
+    want = partial.double().reshape(G, bpg, 2, C).sum(1)
+    assert torch.allclose(sums, want, rtol=1e-12, atol=1e-9)

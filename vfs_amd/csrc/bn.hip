@@ -13,16 +13,20 @@
 
 // ------------------------------------------------------------------------------------------
 // partial[nblk][2][C] (fp32, one per producer block) -> sums[G][2][C] (fp64), fixed order.
-// group gi owns blocks [gi*bpg, (gi+1)*bpg).
-__global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ partial,
-                                                                 double* __restrict__ sums, int bpg, int C) {
+// group gi owns rows [gi*bpg, (gi+1)*bpg).  Large row counts are reduced in two deterministic
+// stages (row chunks in parallel -> fp64 chunk sums -> final) so that e.g. the 16384 partials
+// per view of the stem do not serialise on four workgroups.
+template <typename TIN>
+__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const TIN* __restrict__ in, double* __restrict__ out, int bpg,
+                                                             int C, int rpc, int nchunks) {
   __shared__ double sh[8][2][32];
   const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
-  const int c = blockIdx.x * 32 + cl, gi = blockIdx.y;
+  const int c = blockIdx.x * 32 + cl, gi = blockIdx.y, ch = blockIdx.z;
+  const int r0 = ch * rpc, r1 = min(bpg, r0 + rpc);
   double a0 = 0.0, a1 = 0.0;
   if (c < C) {
-    const float* p = partial + (size_t)gi * bpg * 2 * C;
-    for (int b = sl; b < bpg; b += 8) {
+    const TIN* p = in + (size_t)gi * bpg * 2 * C;
+    for (int b = r0 + sl; b < r1; b += 8) {
       a0 += (double)p[(size_t)b * 2 * C + c];
       a1 += (double)p[(size_t)b * 2 * C + C + c];
     }
@@ -31,11 +35,12 @@ __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __
   sh[sl][1][cl] = a1;
   __syncthreads();
   if (sl == 0 && c < C) {
-    double r0 = 0.0, r1 = 0.0;
+    double r0s = 0.0, r1s = 0.0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { r0 += sh[s][0][cl]; r1 += sh[s][1][cl]; }
-    sums[((size_t)gi * 2 + 0) * C + c] = r0;
-    sums[((size_t)gi * 2 + 1) * C + c] = r1;
+    for (int s = 0; s < 8; ++s) { r0s += sh[s][0][cl]; r1s += sh[s][1][cl]; }
+    double* o = out + ((size_t)gi * nchunks + ch) * 2 * C;
+    o[c] = r0s;
+    o[C + c] = r1s;
   }
 }
 
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(PoolBwdArgs a) {
 
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
-  __shared__ float sh[256][17];
+  __shared__ float red[256][17];
   const int cv = a.C >> 3;          // chunk-threads per pixel (<=256)
   const int rows = 256 / cv;        // pixels processed per step
   const int t = threadIdx.x;
@@ -218,10 +223,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   const long long m0 = (long long)blockIdx.x * a.ppb;
   const int gi = (int)(m0 / a.mpg);
   const int c = ct * 8;
-  float s1[8], s2[8], mean[8], inv[8];
+  float s1[8], s2[8], mean[8], inv[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
   if (rt < rows) {
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + c, sc);
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 2 * a.C + c, mean);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
     for (int r = rt; r < a.ppb; r += rows) {
@@ -236,6 +243,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         unpack8(ld16(a.y + o), y);
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+      } else if (a.relu) {   // plain conv->BN->ReLU unit: the mask is recomputed from x (saves a read)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = (x[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -245,13 +255,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { sh[t][i] = s1[i]; sh[t][8 + i] = s2[i]; }
+  for (int i = 0; i < 8; ++i) { red[t][i] = s1[i]; red[t][8 + i] = s2[i]; }
   __syncthreads();
   // thread (ct, i16) sums over the row-threads in fixed order
   for (int e = t; e < cv * 16; e += 256) {
     const int ec = e / 16, ei = e % 16;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += sh[r * cv + ec][ei];
+    for (int r = 0; r < rows; ++r) s += red[r * cv + ec][ei];
     const int ch = ec * 8 + (ei & 7);
     a.partial[(size_t)blockIdx.x * 2 * a.C + (ei >> 3) * a.C + ch] = s;
   }
@@ -270,16 +280,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     float g[8], x[8], sc[8], mean[8], inv[8];
     unpack8(ld16(a.g + o), g);
     unpack8(ld16(a.x + o), x);
+    const float* bp = a.bnp + (size_t)gi * 4 * a.C;
+    ld8f(bp + c, sc);
+    ld8f(bp + 2 * a.C + c, mean);
+    ld8f(bp + 3 * a.C + c, inv);
     if (a.y) {
       float y[8];
       unpack8(ld16(a.y + o), y);
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+    } else if (a.relu) {
+      float sh[8];
+      ld8f(bp + a.C + c, sh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = (x[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
     }
-    const float* bp = a.bnp + (size_t)gi * 4 * a.C;
-    ld8f(bp + c, sc);
-    ld8f(bp + 2 * a.C + c, mean);
-    ld8f(bp + 3 * a.C + c, inv);
     float d[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -313,8 +328,19 @@ static inline int grid_for(long long total_vec) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-int vfs_bn_reduce_partials_launch(const float* partial, double* sums, int G, int bpg, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 31) / 32, G), dim3(256), 0, s, partial, sums, bpg, C);
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s) {
+  const int cb = (C + 31) / 32;
+  if (bpg <= 64 || scratch == nullptr) {
+    hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, 1), dim3(256), 0, s, partial, sums, bpg, C, bpg, 1);
+    return vfs_check_launch("bn_reduce_partials");
+  }
+  int nchunks = (bpg + 31) / 32;
+  if (nchunks > VFS_BN_MAX_CHUNKS) nchunks = VFS_BN_MAX_CHUNKS;
+  const int rpc = (bpg + nchunks - 1) / nchunks;
+  nchunks = (bpg + rpc - 1) / rpc;
+  hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, nchunks), dim3(256), 0, s, partial, scratch, bpg, C, rpc, nchunks);
+  hipLaunchKernelGGL((bn_reduce_rows_kernel<double>), dim3(cb, G, 1), dim3(256), 0, s, (const double*)scratch, sums, nchunks, C,
+                     nchunks, 1);
   return vfs_check_launch("bn_reduce_partials");
 }
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,

@@ -96,8 +96,8 @@ int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stre
   return vfs_bias_grad_launch(dy, db, M, C, S(stream));
 }
 
-int vfs_bn_reduce_partials(const float* partial, double* sums, int G, int bpg, int C, vfs_stream_t stream) {
-  return vfs_bn_reduce_partials_launch(partial, sums, G, bpg, C, S(stream));
+int vfs_bn_reduce_partials(const float* partial, double* sums, double* scratch, int G, int bpg, int C, vfs_stream_t stream) {
+  return vfs_bn_reduce_partials_launch(partial, sums, scratch, G, bpg, C, S(stream));
 }
 int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp, float* running_mean,
                     float* running_var, int G, int C, double count, float eps, float momentum, vfs_stream_t stream) {
@@ -126,18 +126,19 @@ int vfs_maxpool_relu_bwd(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* 
   return vfs_maxpool_relu_bwd_launch(a, S(stream));
 }
 int vfs_bn_bwd_reduce(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, float* partial, long long M,
-                      int C, int mpg, int ppb, vfs_stream_t stream) {
+                      int C, int mpg, int ppb, int relu, vfs_stream_t stream) {
   if (ppb <= 0 || mpg % ppb) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_reduce: pixels-per-group % pixels-per-block");
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.partial = partial; a.M = M; a.C = C; a.mpg = mpg; a.ppb = ppb;
+  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.partial = partial; a.M = M; a.C = C; a.mpg = mpg; a.ppb = ppb; a.relu = relu;
   return vfs_bn_bwd_reduce_launch(a, (int)((M + ppb - 1) / ppb), S(stream));
 }
 int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, const double* sums,
-                     vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg, double count, vfs_stream_t stream) {
+                     vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg, double count, int relu, vfs_stream_t stream) {
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.sums = sums; a.dx = dx; a.gm = gm; a.M = M; a.C = C; a.mpg = mpg; a.count = count;
+  a.relu = relu;
   return vfs_bn_bwd_apply_launch(a, S(stream));
 }
 int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C, vfs_stream_t stream) {

@@ -110,16 +110,20 @@ int vfs_avgpool_bwd_launch(const bf16_t* g, bf16_t* gx, int N, int HW, int C, hi
   return vfs_check_launch("avgpool_bwd");
 }
 
-// db[c] += sum_m dy[m][c]
+// db[c] += sum_m dy[m][c]   (64 channels x 4 row-slices per workgroup, fixed-order combine)
 __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int M, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int m = 0; m < M; ++m) s += bf2f(dy[(size_t)m * C + c]);
-  db[c] += s;
+  if (c < C)
+    for (int m = sl; m < M; m += 4) s += bf2f(dy[(size_t)m * C + c]);
+  sh[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) db[c] += (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 int vfs_bias_grad_launch(const bf16_t* dy, float* db, int M, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dy, db, M, C);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dy, db, M, C);
   return vfs_check_launch("bias_grad");
 }
 

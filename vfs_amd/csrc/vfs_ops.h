@@ -39,7 +39,7 @@ struct PoolBwdArgs {
 // one partial[2][C] per workgroup (PIX_PER_BLOCK pixels of one group)
 struct BnBwdArgs {
   const bf16_t* g;     // [M][C] gradient wrt the unit's output
-  const bf16_t* y;     // [M][C] unit output for the ReLU mask, or null (no activation)
+  const bf16_t* y;     // [M][C] unit output for the ReLU mask, or null (mask from x when relu, else none)
   const bf16_t* x;     // [M][C] raw conv output
   const float* bnp;    // [G][4][C]
   const double* sums;  // pass 2: [G][2][C] (S1,S2), all-reduced for SyncBN
@@ -48,10 +48,12 @@ struct BnBwdArgs {
   bf16_t* gm;          // pass 2 optional output: masked gradient (identity branch)
   long long M;
   int C, mpg, ppb;     // pixels per group, pixels per block (pass 1; mpg % ppb == 0)
+  int relu;            // with y == null: recompute the ReLU mask as x*scale+shift > 0
   double count;        // pass 2: elements per channel per group (global for SyncBN)
 };
 
-int vfs_bn_reduce_partials_launch(const float* partial, double* sums, int G, int bpg, int C, hipStream_t s);
+#define VFS_BN_MAX_CHUNKS 128
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s);
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s);
 int vfs_bn_eval_params_launch(const float* gamma, const float* beta, const float* rm, const float* rv, float* bnp, int C,

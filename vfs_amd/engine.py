@@ -153,7 +153,7 @@ class Engine:
             if train:
                 u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
                 u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
-                lib.bn_reduce_partials(partial, u.sums, G, nblk_g, u.cout, s)
+                lib.bn_reduce_partials(partial, u.sums, self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
                 self.allreduce(u.sums)
                 lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
                                 u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
@@ -164,6 +164,9 @@ class Engine:
                                    float(bn.eps), s)
         return y, Ho, Wo
 
+    def bn_scratch(self, G, C, dev):
+        return self.ws('ws.bnred', G * 128 * 2 * C, torch.float64, dev)
+
     def bn_act(self, u, raw, M, G, train, relu, res=None, rres=None, rbnp=None, tag=''):
         dev = raw.device
         y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
@@ -172,8 +175,10 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ backward primitives
-    def bn_bwd(self, u, g, ymask, raw, M, G, want_gm=False):
-        """gradient wrt the raw conv output (and optionally the ReLU-masked incoming gradient)."""
+    def bn_bwd(self, u, g, ymask, raw, M, G, want_gm=False, relu=False):
+        """gradient wrt the raw conv output (and optionally the ReLU-masked incoming gradient).
+        ymask: the unit's output (residual units); relu=True without ymask: conv->BN->ReLU unit,
+        the mask is recomputed from raw inside the kernels."""
         dev = raw.device
         s = self.stream(dev)
         lib = self.lib
@@ -185,13 +190,14 @@ class Engine:
         nblk = M // ppb
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
-        lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, s)
-        lib.bn_reduce_partials(partial, u.bsums, G, nblk // G, C, s)
+        rl = 1 if relu else 0
+        lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, rl, s)
+        lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, nblk // G, C, s)
         lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
         self.allreduce(u.bsums)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
-        lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), s)
+        lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), rl, s)
         return dx, gm
 
     def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None):

@@ -335,7 +335,7 @@ class ResNet(nn.Module):
             if ci > 0:
                 p = convs[ci - 1]
                 _, _, ph, pw = bctx['dims'][ci - 1]
-                dx, _ = eng.bn_bwd(p.unit, gin, bctx['acts'][ci - 1], bctx['raws'][ci - 1], N * ph * pw, G)
+                dx, _ = eng.bn_bwd(p.unit, gin, None, bctx['raws'][ci - 1], N * ph * pw, G, relu=True)
         if blk.downsample is not None:
             d = blk.downsample
             boh, bow = bctx['dims'][last][2:]

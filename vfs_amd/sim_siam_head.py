@@ -112,7 +112,7 @@ class SimSiamHead(nn.Module):
             if ui == self._n_proj - 1 and dz is not None:
                 raise NotImplementedError('explicit z gradient')
             if u.bn is not None:
-                dx, _ = eng.bn_bwd(u, g, ctx['acts'][ui] if u.relu else None, ctx['raws'][ui], N, G)
+                dx, _ = eng.bn_bwd(u, g, None, ctx['raws'][ui], N, G, relu=u.relu)
             else:
                 dx = g
             g = eng.conv_bwd(u, dx, ctx['ins'][ui], N, 1, 1, 1, 1, need_dgrad=True)
