@@ -329,6 +329,29 @@ inline int __ffsll(unsigned long long x) { return __builtin_ffsll(x); }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_readfirstlane(x) __shfl((x), 0)
 
+// raw buffer descriptor + bounds-checked 16-byte load (out of range -> zeros, as the hardware)
+namespace emu {
+struct rsrc_t {
+  const char* base;
+  unsigned num_records;
+};
+inline rsrc_t make_buffer_rsrc(void* p, int stride, unsigned num, unsigned flags) {
+  (void)stride; (void)flags;
+  return rsrc_t{(const char*)p, num};
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int v4u;
+inline v4u raw_buffer_load_b128(rsrc_t r, unsigned voff, unsigned soff, int aux) {
+  (void)aux;
+  v4u v = {0u, 0u, 0u, 0u};
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 16 <= r.num_records) memcpy(&v, r.base + o, 16);
+  return v;
+}
+}  // namespace emu
+#define __amdgpu_buffer_rsrc_t emu::rsrc_t
+#define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128
+
 template <typename T>
 inline T atomicAdd(T* p, T v) {
   T old = __atomic_load_n(p, __ATOMIC_RELAXED);

@@ -70,6 +70,7 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (1, 12, 10, 64, 128, 3, 2, 1),
     (3, 7, 7, 128, 64, 1, 1, 0),
     (2, 8, 8, 64, 128, 1, 2, 0),
+    (2, 9, 11, 64, 64, 3, 2, 1),      # odd sizes: unequal parity classes in the stride-2 dgrad
 ]
 
 

@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution for gfx950: forward, dgrad and the 7x7 stem share one kernel.
+// Implicit-GEMM convolution for gfx950: forward, dgrad (stride 1 and 2) and the 7x7 stem share
+// one kernel.
 //
 //   out[pixel][chan] = sum_k Wt[chan][k] * G[pixel][k]   (+bias[chan]) (+add[pixel][chan])
 //
@@ -10,14 +11,22 @@
 //   * 128 pixels x BC channels (BC = 64|128) per workgroup, K-steps of 64
 //   * MFMA v_mfma_f32_16x16x32_bf16, rows(i)=channels (A operand = packed weights),
 //     cols(j)=pixels (B operand = gathered NHWC activations); each wave owns (BC/2) x 64
-//   * global -> VGPR (16 B/lane, 128-byte rows fully coalesced) -> XOR-swizzled LDS,
-//     double-buffered: tile kt+1 is in flight while tile kt feeds the MFMAs; one barrier/K-step
+//   * operand rows are fetched with buffer_load_dwordx4 through a raw buffer descriptor: a
+//     pixel row's byte offset is  base(row) + delta(tap, channel chunk)  with delta uniform per
+//     workgroup, and padding taps are sent out of range (hardware returns zeros), so a K-step
+//     costs ~4 VALU per load instead of a re-derivation of (n, h, w) and a divergent branch
+//   * global -> VGPR -> XOR-swizzled LDS, double-buffered: tile kt+1 is in flight while tile kt
+//     feeds the MFMAs; one barrier per K-step
+//   * stride-2 dgrad runs per OUTPUT PARITY CLASS (blockIdx.y = (h&1, w&1)): a class only sees the
+//     taps r = (h+pad) mod 2, s = (w+pad) mod 2 (1, 2, 2 or 4 of the 9 taps of a 3x3), so no MFMA
+//     multiplies the zeros a gather over the dilated gradient would insert
 //   * epilogue: lane holds 4 consecutive channels of one pixel -> one 8-byte NHWC store;
 //     optional per-channel (sum, sum of squares) of the bf16-ROUNDED outputs, reduced
 //     wave-wide with shuffles and written as one deterministic partial per pixel-block
-//     (consumed by bn_reduce_partials: BatchNorm batch statistics without an extra pass)
+//     (consumed by bn_reduce_rows: BatchNorm batch statistics without an extra pass)
 #include "vfs_conv.h"
 
+#define OOB_OFFSET 0xFFFFFFF0u   // >= any num_records: the load returns zeros
 
 template <int BC, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -38,21 +47,109 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int pb = blockIdx.x / ncb, cb = blockIdx.x - pb * ncb;
   const int m0 = pb * BP, c0 = cb * BC;
   const int j = t & 7, row0 = t >> 3;
-  const int nk = g.Ktot >> 6;
 
-  PixCoord pc[4];
+  // ---- destination pixel grid of this workgroup (a parity class for stride-2 dgrad)
+  const int ph = (MODE == GATHER_DGRAD2) ? (int)(blockIdx.y >> 1) : 0;
+  const int pw = (MODE == GATHER_DGRAD2) ? (int)(blockIdx.y & 1) : 0;
+  const int Hc = (MODE == GATHER_DGRAD2) ? (g.Ho - ph + 1) / 2 : g.Ho;
+  const int Wc = (MODE == GATHER_DGRAD2) ? (g.Wo - pw + 1) / 2 : g.Wo;
+  const int Mc = g.N * Hc * Wc;
+  if (m0 >= Mc) return;   // uniform: whole workgroup leaves before any barrier
+
+  // ---- tap list (uniform)
+  const int cpt = (MODE == GATHER_STEM) ? 1 : (g.C >> 6);
+  int r0 = 0, s0 = 0, tstep = 1, nr = g.KH, ns = g.KW;
+  if (MODE == GATHER_DGRAD2) {
+    r0 = (ph + g.pad) & 1; s0 = (pw + g.pad) & 1; tstep = 2;
+    nr = r0 < g.KH ? (g.KH - r0 + 1) / 2 : 0;
+    ns = s0 < g.KW ? (g.KW - s0 + 1) / 2 : 0;
+  }
+  const int nk = (MODE == GATHER_STEM) ? 4 : nr * ns * cpt;
+
+  // ---- per-row descriptors: byte offset base (mod 2^32) and a validity bit per tap
+  unsigned xbase[4], xmask[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pc[i] = pix_decode<MODE>(g, m0 + row0 + 32 * i);
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    unsigned mask = 0;
+    long long base = 0;
+    if (m < Mc) {
+      const int hw = Hc * Wc;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int hc = rem / Wc, wcx = rem - hc * Wc;
+      if (MODE == GATHER_STEM) {
+        const int hb = 2 * hc - 3 + (j >> 2), wi = 2 * wcx - 4 + 2 * (j & 3);
+        base = ((long long)(n * g.H + hb) * g.W + wi) * 4;
+        const bool wok = (unsigned)wi < (unsigned)g.W;
+        for (int kt = 0; kt < 4; ++kt) {
+          const int r = 2 * kt + (j >> 2), hi = hb + 2 * kt;
+          if (wok && r < 7 && (unsigned)hi < (unsigned)g.H) mask |= 1u << kt;
+        }
+      } else {
+        int hb, wb;
+        if (MODE == GATHER_FWD) { hb = hc * g.stride - g.pad; wb = wcx * g.stride - g.pad; }
+        else if (MODE == GATHER_DGRAD) { hb = hc + g.pad; wb = wcx + g.pad; }
+        else { hb = hc; wb = wcx; }
+        base = ((long long)(n * g.H + hb) * g.W + wb) * g.C + j * 8;
+        for (int ri = 0; ri < nr; ++ri)
+          for (int si = 0; si < ns; ++si) {
+            const int r = r0 + tstep * ri, s = s0 + tstep * si;
+            int hi, wi;
+            if (MODE == GATHER_FWD) { hi = hb + r; wi = wb + s; }
+            else if (MODE == GATHER_DGRAD) { hi = hb - r; wi = wb - s; }
+            else { hi = hb + (ph + g.pad - r) / 2; wi = wb + (pw + g.pad - s) / 2; }
+            if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) mask |= 1u << (ri * ns + si);
+          }
+      }
+    }
+    xbase[i] = (unsigned)(base * 2);
+    xmask[i] = mask;
+  }
+  unsigned wbase[WLD];
+  bool wok[WLD];
+#pragma unroll
+  for (int i = 0; i < WLD; ++i) {
+    const int c = c0 + row0 + 32 * i;
+    wok[i] = c < a.Cout;
+    wbase[i] = (unsigned)(((size_t)c * g.Ktot + j * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.wgt, 0, (unsigned)((size_t)a.Cout * g.Ktot * 2), 0x00020000);
 
   u32x4 xr[4], wr[WLD];
-  auto load_tiles = [&](int kt) {
-    KStep ks = kstep_decode<MODE>(g, kt);
+  int l_cc = 0, l_ri = 0, l_si = 0, l_ti = 0;   // K-step counters of the NEXT load (uniform, no divisions)
+  auto load_tiles = [&](int kt) {                // called with kt = 0, 1, 2, ... in order
+    // uniform decode of the K-step: tap index, source delta (bytes), weight column (bytes)
+    int ti, delta, wcol;
+    if (MODE == GATHER_STEM) {
+      ti = kt; delta = 2 * kt * g.W * 4 * 2; wcol = kt * 64 * 2;
+    } else {
+      ti = l_ti;
+      const int cc = l_cc << 6;
+      const int r = r0 + tstep * l_ri, s = s0 + tstep * l_si;
+      if (++l_cc == cpt) {
+        l_cc = 0; ++l_ti;
+        if (++l_si == ns) { l_si = 0; ++l_ri; }
+      }
+      int dh, dw;
+      if (MODE == GATHER_FWD) { dh = r; dw = s; }
+      else if (MODE == GATHER_DGRAD) { dh = -r; dw = -s; }
+      else { dh = (ph + g.pad - r) / 2; dw = (pw + g.pad - s) / 2; }
+      delta = ((dh * g.W + dw) * g.C + cc) * 2;
+      wcol = ((r * g.KW + s) * g.C + cc) * 2;
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xr[i] = gather16<MODE>(g, a.src, pc[i], ks, j);
+    for (int i = 0; i < 4; ++i) {
+      const unsigned off = ((xmask[i] >> ti) & 1u) ? xbase[i] + (unsigned)delta : OOB_OFFSET;
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
-      int c = c0 + row0 + 32 * i;
-      wr[i] = (c < a.Cout) ? ld16(a.wgt + (size_t)c * g.Ktot + kt * 64 + j * 8) : zero16();
+      const unsigned off = wok[i] ? wbase[i] + (unsigned)wcol : OOB_OFFSET;
+      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -68,16 +165,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) load_tiles(kt + 1);
-    mma_kstep<TM, TN, false>(sW[cur], sX[cur], wc * WC, wp * 64, lane, acc);
-    if (more) store_tiles(cur ^ 1);
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < nk;
+      if (more) load_tiles(kt + 1);
+      mma_kstep<TM, TN, false>(sW[cur], sX[cur], wc * WC, wp * 64, lane, acc);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue ----------------
@@ -92,7 +191,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int m = m0 + wp * 64 + tn * 16 + lr;
-    const bool mok = m < g.M;
+    const bool mok = m < Mc;
+    size_t mdst = (size_t)m;
+    if (MODE == GATHER_DGRAD2 && mok) {   // class-local pixel -> position in the full gradient
+      const int hw = Hc * Wc;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int hc = rem / Wc, wcx = rem - hc * Wc;
+      mdst = ((size_t)n * g.Ho + (2 * hc + ph)) * g.Wo + (2 * wcx + pw);
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int c = c0 + wc * WC + tm * 16 + lq * 4;
@@ -102,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
         }
-        const size_t o = (size_t)m * a.Cout + c;
+        const size_t o = mdst * a.Cout + c;
         if (a.add) {
           u32x2 ad = ld8(a.add + o);
           v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
@@ -150,21 +257,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // ------------------------------------------------------------------ host launcher
 template <int BC, int MODE>
 static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
-  int npb = (a.g.M + 127) / 128;
+  int M = a.g.M, classes = 1;
+  if (MODE == GATHER_DGRAD2) {   // largest parity class: ceil(Ho/2) x ceil(Wo/2)
+    M = a.g.N * ((a.g.Ho + 1) / 2) * ((a.g.Wo + 1) / 2);
+    classes = 4;
+  }
+  int npb = (M + 127) / 128;
   int ncb = (a.Cout + BC - 1) / BC;
-  hipLaunchKernelGGL((conv_igemm_kernel<BC, MODE>), dim3(npb * ncb), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BC, MODE>), dim3(npb * ncb, classes), dim3(256), 0, stream, a);
   return vfs_check_launch("conv_igemm");
 }
 
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
   if (a.g.Ktot % 64 != 0 || a.Cout % 4 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: K%64 or Cout%4");
   if (mode != GATHER_STEM && a.g.C % 64 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: C%64");
+  if (mode != GATHER_STEM && a.g.KH * a.g.KW > 32) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: more than 32 taps");
+  if ((size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 >= 0xFFFFFFF0ull || (size_t)a.Cout * a.g.Ktot * 2 >= 0xFFFFFFF0ull)
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: tensor >= 4 GiB (split the batch)");
   const bool wide = (a.Cout % 128 == 0);
   switch (mode) {
     case GATHER_FWD:
       return wide ? launch_igemm<128, GATHER_FWD>(a, stream) : launch_igemm<64, GATHER_FWD>(a, stream);
     case GATHER_DGRAD:
-      return wide ? launch_igemm<128, GATHER_DGRAD>(a, stream) : launch_igemm<64, GATHER_DGRAD>(a, stream);
+      if (a.g.stride == 1)
+        return wide ? launch_igemm<128, GATHER_DGRAD>(a, stream) : launch_igemm<64, GATHER_DGRAD>(a, stream);
+      if (a.g.stride == 2)
+        return wide ? launch_igemm<128, GATHER_DGRAD2>(a, stream) : launch_igemm<64, GATHER_DGRAD2>(a, stream);
+      return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad: stride must be 1 or 2");
     case GATHER_STEM:
       return launch_igemm<64, GATHER_STEM>(a, stream);
   }

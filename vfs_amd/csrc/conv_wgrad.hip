@@ -43,19 +43,54 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int pix_begin = split * a.pix_per_split;
   const int iters = a.pix_per_split >> 6;
 
+  // The 4 pixels a thread gathers advance by exactly 64 per iteration; their (n, ho, wo) are kept
+  // incrementally (no integer division in the loop): 64 = dn*Ho*Wo + dh*Wo + dw.
+  const int hw = g.Ho * g.Wo;
+  const int dn = 64 / hw, dr = 64 - dn * hw, dh = dr / g.Wo, dw = dr - dh * g.Wo;
+  int pn[4], ph[4], pw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = pix_begin + a_pg * 4 + i;
+    pn[i] = m / hw;
+    const int rem = m - pn[i] * hw;
+    ph[i] = rem / g.Wo;
+    pw[i] = rem - ph[i] * g.Wo;
+  }
+  auto pix_coord = [&](int i) {
+    PixCoord pc;
+    if (pn[i] >= g.N) {
+      pc.nH = 0; pc.hb = -(1 << 24); pc.wb = -(1 << 24);
+    } else {
+      pc.nH = pn[i] * g.H;
+      if (MODE == GATHER_STEM) { pc.hb = 2 * ph[i] - 3; pc.wb = 2 * pw[i] - 4; }
+      else { pc.hb = ph[i] * g.stride - g.pad; pc.wb = pw[i] * g.stride - g.pad; }
+    }
+    return pc;
+  };
+  auto pix_advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pw[i] += dw;
+      if (pw[i] >= g.Wo) { pw[i] -= g.Wo; ph[i] += 1; }
+      ph[i] += dh;
+      if (ph[i] >= g.Ho) { ph[i] -= g.Ho; pn[i] += 1; }
+      pn[i] += dn;
+    }
+  };
+
   u32x4 av[4], dv[4];
-  auto load_tiles = [&](int it) {
+  auto load_tiles = [&](int it) {   // must be called with it = 0, 1, 2, ... in order
     const int p0 = pix_begin + it * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = p0 + a_pg * 4 + i;
       if (a_ok) {
-        PixCoord pc = pix_decode<MODE>(g, m);
+        const PixCoord pc = pix_coord(i);
         av[i] = gather16<MODE>(g, a.x, pc, a_ks, a_j);
       } else {
         av[i] = zero16();
       }
     }
+    pix_advance();
     if (d_active) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {

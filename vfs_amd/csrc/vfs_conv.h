@@ -15,7 +15,7 @@
 #pragma once
 #include "vfs_common.h"
 
-enum { GATHER_FWD = 0, GATHER_DGRAD = 1, GATHER_STEM = 2 };
+enum { GATHER_FWD = 0, GATHER_DGRAD = 1, GATHER_STEM = 2, GATHER_DGRAD2 = 3 };
 
 struct ConvGeom {
   int N, H, W, C;   // gather-source tensor (NHWC), C = physical channels per pixel
