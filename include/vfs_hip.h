@@ -27,6 +27,8 @@ typedef uint16_t vfs_bf16;
 
 const char* vfs_last_error(void);
 int vfs_abi_version(void);
+/* tuning knobs for A/B measurements: "halo" (1 = 3x3/stride-1 convs use the halo-tile kernel) */
+int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------
  * imgs fp32 [B][2][3][T][H][W] (pipelines/formating.py:248-258) -> bf16 NHWC4 frames

@@ -56,12 +56,16 @@ def main():
         partial = torch.empty(nsplit * Cout * k * k * Cin, device=dev)
         grad = torch.zeros(Cout, Cin, k, k, device=dev)
         fl = 2.0 * M * Cout * k * k * Cin
+        lib.set_option(b'halo', 0)
+        tf0 = timeit(lambda: lib.conv_fwd(x, wf, y, None, stats, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
+        td0 = timeit(lambda: lib.conv_dgrad(dy, wd, dx, None, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
+        lib.set_option(b'halo', 1)
         tf = timeit(lambda: lib.conv_fwd(x, wf, y, None, stats, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
         td = timeit(lambda: lib.conv_dgrad(dy, wd, dx, None, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
         tw = timeit(lambda: lib.conv_wgrad(dy, x, partial, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, nsplit, pps, s))
         tot[0] += tf; tot[1] += td; tot[2] += tw
         print(f'{str((N, H, W, Cin, Cout, k, st)):44s} {fl / tf / 1e12:9.1f} {fl / td / 1e12:9.1f} {fl / tw / 1e12:9.1f}   '
-              f'{tf * 1e3:.3f} {td * 1e3:.3f} {tw * 1e3:.3f}  nsplit={nsplit}')
+              f'{tf * 1e3:.3f} {td * 1e3:.3f} {tw * 1e3:.3f}  nsplit={nsplit}  [halo off: fwd {fl / tf0 / 1e12:.0f} dgrad {fl / td0 / 1e12:.0f} TF/s]')
     print('sum ms (one call each):', [round(t * 1e3, 3) for t in tot])
 
 

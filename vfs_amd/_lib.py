@@ -24,7 +24,9 @@ def parse_header(path=HEADER):
         if args and args != 'void':
             for a in args.split(','):
                 a = ' '.join(a.split())
-                if '*' in a:
+                if 'char*' in a.replace(' ', ''):
+                    alist.append((ctypes.c_char_p, a.split('*')[-1].strip()))
+                elif '*' in a:
                     alist.append((ctypes.c_void_p, a.split('*')[-1].strip()))
                 else:
                     typ, an = a.rsplit(' ', 1)

@@ -24,6 +24,8 @@ int vfs_check_launch(const char* what) {
 
 #define S(s) ((hipStream_t)(s))
 
+int vfs_option_halo = 1;
+
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
   g.N = N; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo;
@@ -36,6 +38,10 @@ extern "C" {
 
 const char* vfs_last_error(void) { return g_err; }
 int vfs_abi_version(void) { return 1; }
+int vfs_set_option(const char* name, int value) {
+  if (!strcmp(name, "halo")) { vfs_option_halo = value; return VFS_OK; }
+  return vfs_set_error(VFS_ERR_ARG, "vfs_set_option: unknown option");
+}
 
 int vfs_imgs_to_nhwc4(const float* imgs, vfs_bf16* out, int B, int V, int T, int H, int W, int Wp, vfs_stream_t stream) {
   if (Wp < W || (Wp & 1)) return vfs_set_error(VFS_ERR_SHAPE, "imgs_to_nhwc4: Wp must be even and >= W");

@@ -270,6 +270,9 @@ static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
 
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
   if (a.g.Ktot % 64 != 0 || a.Cout % 4 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: K%64 or Cout%4");
+  if (vfs_option_halo && a.g.C % 64 == 0 && (size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 < 0xFFFFFFF0ull &&
+      vfs_conv_halo_eligible(a, mode))
+    return vfs_conv_halo_dispatch(a, mode, stream);
   if (mode != GATHER_STEM && a.g.C % 64 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: C%64");
   if (mode != GATHER_STEM && a.g.KH * a.g.KW > 32) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: more than 32 taps");
   if ((size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 >= 0xFFFFFFF0ull || (size_t)a.Cout * a.g.Ktot * 2 >= 0xFFFFFFF0ull)
