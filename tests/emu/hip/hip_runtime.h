@@ -348,6 +348,26 @@ inline v4u raw_buffer_load_b128(rsrc_t r, unsigned voff, unsigned soff, int aux)
   return v;
 }
 }  // namespace emu
+// ds_read_b64_tr_b16 (probed on gfx950): inside each 16-lane group the lanes' 8-byte chunks form a
+// 64-element array F (lane 0's 4 elements first); lane i receives F[i], F[16+i], F[32+i], F[48+i]
+namespace emu {
+typedef __attribute__((ext_vector_type(4))) short v4s;
+inline v4s ds_read_tr16_b64(uintptr_t p) {
+  WaveX& W = B->waves[wave_id()];
+  const int l = lane_id();
+  W.u64[l] = (uint64_t)p;
+  wave_barrier();
+  const int g0 = l & ~15, i = l & 15;
+  v4s v;
+  for (int e = 0; e < 4; ++e) {
+    const int f = e * 16 + i;
+    v[e] = ((const short*)(uintptr_t)W.u64[g0 + (f >> 2)])[f & 3];
+  }
+  wave_barrier();
+  return v;
+}
+}  // namespace emu
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16_b64((uintptr_t)(p))
 #define __amdgpu_buffer_rsrc_t emu::rsrc_t
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128

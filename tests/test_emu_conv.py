@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from tests.emu_util import nchw, nhwc, rb, relerr
-from vfs_amd.packing import build_pack_table, wgrad_splits
+from vfs_amd.packing import build_pack_table, wgrad_halo_eligible, wgrad_splits
 
 
 def pack(be, w, stem=False):
@@ -64,7 +64,8 @@ def run_conv_case(be, N, H, W, Cin, Cout, k, stride, pad, wgrad_blocks=12):
     dx = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=be.dev)
     lib.conv_dgrad(d(nhwc(dy)), wd, dx, d(nhwc(add)), N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
     assert relerr(nchw(dx.cpu()), xr.grad + add) < 6e-3
-    nsplit, pps = wgrad_splits(M, Cout, k * k * Cin, target_blocks=wgrad_blocks)
+    halo = (N, H, W, Cin) if wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad) else None
+    nsplit, pps = wgrad_splits(M, Cout, k * k * Cin, target_blocks=wgrad_blocks, halo_geom=halo)
     partial = torch.full((nsplit, Cout, k * k * Cin), float('nan'), device=be.dev)
     grad = torch.ones(Cout, Cin, k, k, device=be.dev)
     lib.conv_wgrad(d(nhwc(dy)), xh, partial, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, nsplit, pps, None)

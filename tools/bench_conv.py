@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vfs_amd._lib import get_lib  # noqa: E402
-from vfs_amd.packing import wgrad_splits  # noqa: E402
+from vfs_amd.packing import wgrad_halo_eligible, wgrad_splits  # noqa: E402
 
 R18 = [  # N, H, W, Cin, Cout, k, stride, pad   (N = 256 frames: 2 views x 32 videos x 4 frames)
     (256, 64, 64, 64, 64, 3, 1, 1), (256, 64, 64, 64, 128, 3, 2, 1), (256, 32, 32, 128, 128, 3, 1, 1),
@@ -52,20 +52,24 @@ def main():
         dy = torch.randn(N, Ho, Wo, Cout, device=dev).to(torch.bfloat16)
         dx = torch.empty(N, H, W, Cin, device=dev, dtype=torch.bfloat16)
         stats = torch.empty((M + 127) // 128 * 2 * Cout, device=dev)
-        nsplit, pps = wgrad_splits(M, Cout, k * k * Cin)
+        halo = (N, H, W, Cin) if wgrad_halo_eligible(N, H, W, Cin, Cout, k, st, pad) else None
+        nsplit, pps = wgrad_splits(M, Cout, k * k * Cin, halo_geom=halo)
+        nsplit0, pps0 = wgrad_splits(M, Cout, k * k * Cin)
+        partial0 = torch.empty(nsplit0 * Cout * k * k * Cin, device=dev)
         partial = torch.empty(nsplit * Cout * k * k * Cin, device=dev)
         grad = torch.zeros(Cout, Cin, k, k, device=dev)
         fl = 2.0 * M * Cout * k * k * Cin
         lib.set_option(b'halo', 0)
         tf0 = timeit(lambda: lib.conv_fwd(x, wf, y, None, stats, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
         td0 = timeit(lambda: lib.conv_dgrad(dy, wd, dx, None, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
+        tw0 = timeit(lambda: lib.conv_wgrad(dy, x, partial0, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, nsplit0, pps0, s))
         lib.set_option(b'halo', 1)
         tf = timeit(lambda: lib.conv_fwd(x, wf, y, None, stats, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
         td = timeit(lambda: lib.conv_dgrad(dy, wd, dx, None, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, s))
         tw = timeit(lambda: lib.conv_wgrad(dy, x, partial, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, st, pad, nsplit, pps, s))
         tot[0] += tf; tot[1] += td; tot[2] += tw
         print(f'{str((N, H, W, Cin, Cout, k, st)):44s} {fl / tf / 1e12:9.1f} {fl / td / 1e12:9.1f} {fl / tw / 1e12:9.1f}   '
-              f'{tf * 1e3:.3f} {td * 1e3:.3f} {tw * 1e3:.3f}  nsplit={nsplit}  [halo off: fwd {fl / tf0 / 1e12:.0f} dgrad {fl / td0 / 1e12:.0f} TF/s]')
+              f'{tf * 1e3:.3f} {td * 1e3:.3f} {tw * 1e3:.3f}  nsplit={nsplit}  [halo off: fwd {fl / tf0 / 1e12:.0f} dgrad {fl / td0 / 1e12:.0f} wgrad {fl / tw0 / 1e12:.0f} TF/s]')
     print('sum ms (one call each):', [round(t * 1e3, 3) for t in tot])
 
 

@@ -83,7 +83,12 @@ int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float*
   WgradArgs a;
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
   a.dy = dy; a.x = x; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
-  int rc = vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
+  int rc;
+  if (vfs_option_halo && vfs_wgrad_halo_eligible(a, GATHER_FWD)) {
+    rc = vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);   // may use fewer splits than offered
+  } else {
+    rc = vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
+  }
   if (rc) return rc;
   return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
 }

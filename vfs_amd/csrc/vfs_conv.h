@@ -49,6 +49,8 @@ struct WgradArgs {
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode);
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
+bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode);
+int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsplit);
 extern int vfs_option_halo;   // 1: 3x3/s1 convs use the halo-tile kernel (capi: vfs_set_option)
 int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream);
 

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import get_lib
-from .packing import build_pack_table, wgrad_splits
+from .packing import build_pack_table, wgrad_halo_eligible, wgrad_splits
 
 BF16 = torch.bfloat16
 
@@ -213,7 +213,8 @@ class Engine:
                        dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, s)
             return None
         ktot = u.k * u.k * u.cin
-        nsplit, pps = wgrad_splits(M, u.cout, ktot)
+        halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
+        nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
         partial = self.ws('ws.wgrad', nsplit * u.cout * ktot, torch.float32, dev)
         flops = 2.0 * M * u.cout * ktot
         self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho, Wo,

@@ -21,8 +21,27 @@ def build_pack_table(entries, device):
     return t, len(entries), start
 
 
-def wgrad_splits(M, Cout, Ktot, target_blocks=1024):
-    """Split-K plan for the wgrad kernel: (nsplit, pix_per_split)."""
+def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
+    """mirror of vfs_wgrad_halo_eligible (csrc/conv_wgrad_halo.hip)"""
+    if k != 3 or stride != 1 or pad != 1 or H % 8 or Cin % 64 or Cout % 64:
+        return False
+    return W % 16 == 0 or (W == 8 and H == 8)
+
+
+def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
+    """Split-K plan for the wgrad kernels: (nsplit, pix_per_split).  halo_geom = (N, H, W, Cin)
+    selects the plan of the 3x3 halo kernel (workgroup = 64 cin x 64 cout x 9 taps, split over
+    128-pixel spatial tiles)."""
+    if halo_geom is not None:
+        N, H, W, Cin = halo_geom
+        ntiles = ((N + 1) // 2) if W == 8 else N * (H // 8) * (W // 16)
+        colblocks = (Cin // 64) * (Cout // 64)
+        # every workgroup writes a 9x64x64 fp32 partial (147 KB): keep ~2 workgroups per CU so
+        # the split-K traffic (blocks x 147 KB, written then re-read) stays well below the MFMA time
+        nsplit = max(1, min(ntiles, (target_blocks // 2 + colblocks - 1) // colblocks))
+        tps = (ntiles + nsplit - 1) // nsplit
+        nsplit = (ntiles + tps - 1) // tps
+        return nsplit, tps * 128
     nkb = (Ktot + 127) // 128
     ncb = Cout // (128 if Cout % 128 == 0 else 64)
     max_split = max(1, (M + 63) // 64)
