@@ -173,8 +173,13 @@ def main():
         kind = max(agg, key=lambda k: agg[k][1])
         fl, tm, cnt = agg[kind]
         ach = fl / tm / 1e12
+        traffic = None   # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh), if present
+        tpath = os.path.join(REPO, 'profiles', f'r01_traffic_{args.model}.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('classes', {}).get(kind, {}).get('hbm_bytes_per_launch')
         res['roofline'] = {'kernel': kind, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None, 'launches': cnt,
+                           'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
+                           'algorithmic_flop_per_launch': fl / cnt, 'launches': cnt,
                            'avg_launch_ms': tm / cnt * 1e3,
                            'time_share_of_step': tm / dt,
                            'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'time_share_of_step': v[1] / dt}
