@@ -100,6 +100,16 @@ int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, co
                      double count, int relu, vfs_stream_t stream);
 int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C,
                       vfs_stream_t stream);
+/* stem: BN backward through max-pool + ReLU without materialising the full-resolution gradient
+ * (same results as vfs_maxpool_relu_bwd followed by vfs_bn_bwd_reduce / vfs_bn_bwd_apply);
+ * pass 1 -> partial[ceil(N*Hp*Wp/ppb)][2][C], pass 2 -> dx[N][H][W][C] */
+int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx,
+                                const vfs_bf16* x, const float* bnp, float* partial, int N, int H, int W,
+                                int C, int Hp, int Wp, int npg, int ppb, vfs_stream_t stream);
+int vfs_stem_pool_bn_bwd_apply(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx,
+                               const vfs_bf16* x, const float* bnp, const double* sums, vfs_bf16* dx,
+                               int N, int H, int W, int C, int Hp, int Wp, int npg, double count,
+                               vfs_stream_t stream);
 
 /* ---- head: AdaptiveAvgPool2d((1,1)) + flatten (sim_siam_head.py:117,154-157) ---------------- */
 int vfs_avgpool_fwd(const vfs_bf16* x, vfs_bf16* y, int N, int HW, int C, vfs_stream_t stream);

@@ -183,3 +183,44 @@ def test_bn_reduce_partials_two_stage(backend):
     lib.bn_reduce_partials(partial, sums, torch.zeros(G * 128 * 2 * C, dtype=torch.float64), G, bpg, C, None)
     want = partial.double().reshape(G, bpg, 2, C).sum(1)
     assert torch.allclose(sums, want, rtol=1e-12, atol=1e-9)
+
+
+def test_stem_pool_bn_bwd_fused_equals_unfused(backend):
+    """the fused stem backward (no full-resolution gradient tensor) must reproduce
+    maxpool_relu_bwd -> bn_bwd_reduce -> bn_bwd_apply"""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W, G = 4, 64, 12, 16, 2
+    x = rb(torch.randn(N, C, H, W, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    bnp, mpg = bn_forward_chain(lib, nhwc(x), gamma, beta, G, torch.zeros(C), torch.ones(C))
+    Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(N, Hp, Wp, C, dtype=torch.bfloat16)
+    idx = torch.empty(N, Hp, Wp, C, dtype=torch.uint8)
+    lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, N, H, W, C, Hp, Wp, N // G, None)
+    gp = nhwc(rb(torch.randn(N, C, Hp, Wp, generator=g)))
+    scratch = torch.zeros(G * 128 * 2 * C, dtype=torch.float64)
+    M = N * H * W
+    # unfused reference chain
+    ga = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.maxpool_relu_bwd(gp, y, idx, ga, N, H, W, C, Hp, Wp, None)
+    ppb = 32
+    partial = torch.zeros(M // ppb, 2, C)
+    lib.bn_bwd_reduce(ga, None, nhwc(x), bnp, partial, M, C, mpg, ppb, 0, None)
+    sums = torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_reduce_partials(partial, sums, scratch, G, (M // ppb) // G, C, None)
+    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.bn_bwd_apply(ga, None, nhwc(x), bnp, sums, dx, None, M, C, mpg, float(mpg), 0, None)
+    # fused
+    P = N * Hp * Wp
+    ppb2 = 24
+    partial2 = torch.zeros(P // ppb2, 2, C)
+    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(x), bnp, partial2, N, H, W, C, Hp, Wp, N // G, ppb2, None)
+    sums2 = torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_reduce_partials(partial2, sums2, scratch, G, (P // ppb2) // G, C, None)
+    # the fused pass sums the per-window contributions before any bf16 rounding of the accumulated
+    # gradient (the unfused chain rounds it when it materialises ga): equal to bf16 rounding noise
+    assert torch.allclose(sums2, sums, rtol=1e-2, atol=0.1)
+    dx2 = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.stem_pool_bn_bwd_apply(gp, y, idx, nhwc(x), bnp, sums, dx2, N, H, W, C, Hp, Wp, N // G, float(mpg), None)
+    assert torch.equal(dx2, dx)

@@ -231,26 +231,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 2 * a.C + c, mean);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
-    for (int r = rt; r < a.ppb; r += rows) {
-      const long long m = m0 + r;
-      if (m >= a.M) break;
-      const size_t o = (size_t)m * a.C + c;
-      float g[8], x[8];
-      unpack8(ld16(a.g + o), g);
-      unpack8(ld16(a.x + o), x);
-      if (a.y) {
-        float y[8];
-        unpack8(ld16(a.y + o), y);
+    // four pixel rows per trip: 8-12 independent 16-byte loads in flight per lane
+    for (int r = rt; r < a.ppb; r += 4 * rows) {
+      u32x4 gv[4], xv[4], yv[4];
+      bool ok[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
-      } else if (a.relu) {   // plain conv->BN->ReLU unit: the mask is recomputed from x (saves a read)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = (x[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const long long m = m0 + r + u * rows;
+        ok[u] = (r + u * rows < a.ppb) && (m < a.M);
+        const size_t o = (size_t)(ok[u] ? m : m0) * a.C + c;
+        gv[u] = ld16(a.g + o);
+        xv[u] = ld16(a.x + o);
+        if (a.y) yv[u] = ld16(a.y + o);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        s1[i] += g[i];
-        s2[i] += g[i] * ((x[i] - mean[i]) * inv[i]);
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        float g[8], x[8];
+        unpack8(gv[u], g);
+        unpack8(xv[u], x);
+        if (a.y) {
+          float y[8];
+          unpack8(yv[u], y);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+        } else if (a.relu) {   // plain conv->BN->ReLU unit: the mask is recomputed from x (saves a read)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g[i] = (x[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          s1[i] += g[i];
+          s2[i] += g[i] * ((x[i] - mean[i]) * inv[i]);
+        }
       }
     }
   }
@@ -272,6 +285,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const int cv = a.C >> 3;
   const long long total = a.M * cv;
   const float rc = (float)(1.0 / a.count);
+  // per-channel means of (gm, gm*xhat) as fp32 in LDS: [G][2][C] (G*C <= 4096 floats)
+  __shared__ float coef[2 * 4096];
+  const int GC = (int)((a.M + a.mpg - 1) / a.mpg) * a.C;
+  for (int i = threadIdx.x; i < 2 * GC; i += 256) {
+    const int gi = i / (2 * a.C), rem = i - gi * 2 * a.C;
+    coef[i] = (float)a.sums[(size_t)gi * 2 * a.C + rem] * rc;
+  }
+  __syncthreads();
   for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
     const long long m = v / cv;
     const int c = (int)(v - m * cv) * 8;
@@ -298,14 +319,139 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     float d[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float m1 = (float)a.sums[((size_t)gi * 2) * a.C + c + i] * rc;
-      const float m2 = (float)a.sums[((size_t)gi * 2 + 1) * a.C + c + i] * rc;
+      const float m1 = coef[(gi * 2) * a.C + c + i];
+      const float m2 = coef[(gi * 2 + 1) * a.C + c + i];
       const float xh = (x[i] - mean[i]) * inv[i];
       d[i] = sc[i] * (g[i] - m1 - xh * m2);
     }
     st16(a.dx + o, pack8(d));
     if (a.gm) st16(a.gm + o, pack8(g));
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stem: BN backward THROUGH the 3x3/s2 max-pool + ReLU without materialising the full-resolution
+// gradient.  ga[h][w] = sum over the <=4 windows whose argmax is (h,w) of gp*(yp>0); it is nonzero
+// only at argmax positions, so the statistics are gathered per pooled window (pass 1) and dx is
+// rebuilt per full-resolution pixel from the (4x smaller, cache-resident) pooled tensors (pass 2).
+__global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(StemBwdArgs a) {
+  __shared__ float red[256][17];
+  const int cv = a.C >> 3, rows = 256 / cv;
+  const int t = threadIdx.x, ct = t % cv, rt = t / cv, c = ct * 8;
+  const long long P = (long long)a.N * a.Hp * a.Wp;
+  const long long p0 = (long long)blockIdx.x * a.ppb;
+  const int gi = (int)(p0 / ((long long)a.npg * a.Hp * a.Wp));
+  float s1[8], s2[8], mean[8], inv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (rt < rows) {
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + 2 * a.C + c, mean);
+    ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
+    for (int r = rt; r < a.ppb; r += rows) {
+      long long p = p0 + r;
+      if (p >= P) break;
+      const int wp = (int)(p % a.Wp); p /= a.Wp;
+      const int hp = (int)(p % a.Hp);
+      const int n = (int)(p / a.Hp);
+      const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
+      float g[8], yp[8];
+      unpack8(ld16(a.gp + o), g);
+      unpack8(ld16(a.yp + o), yp);
+      const u32x2 id = ld8(a.idx + o);
+      unsigned code[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        code[i] = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;
+        g[i] = yp[i] > 0.f ? g[i] : 0.f;
+        s1[i] += g[i];
+      }
+      for (int dy = 0; dy < 3; ++dy) {
+        const int h = 2 * hp - 1 + dy;
+        if ((unsigned)h >= (unsigned)a.H) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+          const int w = 2 * wp - 1 + dx;
+          if ((unsigned)w >= (unsigned)a.W) continue;
+          float x[8];
+          unpack8(ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * a.C + c), x);
+          const unsigned pos = (unsigned)(dy * 3 + dx);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (code[i] == pos) s2[i] += g[i] * ((x[i] - mean[i]) * inv[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[t][i] = s1[i]; red[t][8 + i] = s2[i]; }
+  __syncthreads();
+  for (int e = t; e < cv * 16; e += 256) {
+    const int ec = e / 16, ei = e % 16;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[r * cv + ec][ei];
+    a.partial[(size_t)blockIdx.x * 2 * a.C + (ei >> 3) * a.C + ec * 8 + (ei & 7)] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_pool_bn_bwd_apply_kernel(StemBwdArgs a) {
+  const int cv = a.C >> 3;
+  const long long total = (long long)a.N * a.H * a.W * cv;
+  const float rc = (float)(1.0 / a.count);
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    long long p = v / cv;
+    const int c = (int)(v - p * cv) * 8;
+    const int w = (int)(p % a.W); p /= a.W;
+    const int h = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    const int gi = n / a.npg;
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+    for (int hp = h >> 1; hp <= (h + 1) >> 1; ++hp) {
+      if (hp >= a.Hp) continue;
+      const int dy = h - (2 * hp - 1);
+      for (int wp = w >> 1; wp <= (w + 1) >> 1; ++wp) {
+        if (wp >= a.Wp) continue;
+        const int dx = w - (2 * wp - 1);
+        const unsigned code = (unsigned)(dy * 3 + dx);
+        const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
+        const u32x2 id = ld8(a.idx + o);
+        float gp[8], yp[8];
+        unpack8(ld16(a.gp + o), gp);
+        unpack8(ld16(a.yp + o), yp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned b = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;
+          if (b == code && yp[i] > 0.f) g[i] += gp[i];
+        }
+      }
+    }
+    const size_t o = (((size_t)n * a.H + h) * a.W + w) * a.C + c;
+    float x[8], sc[8], mean[8], inv[8], d[8];
+    unpack8(ld16(a.x + o), x);
+    const float* bp = a.bnp + (size_t)gi * 4 * a.C;
+    ld8f(bp + c, sc);
+    ld8f(bp + 2 * a.C + c, mean);
+    ld8f(bp + 3 * a.C + c, inv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float m1 = (float)a.sums[((size_t)gi * 2) * a.C + c + i] * rc;
+      const float m2 = (float)a.sums[((size_t)gi * 2 + 1) * a.C + c + i] * rc;
+      // ga as the materialising path would have stored it (bf16), then the BN backward formula
+      d[i] = sc[i] * (round_bf(g[i]) - m1 - ((x[i] - mean[i]) * inv[i]) * m2);
+    }
+    st16(a.dx + o, pack8(d));
+  }
+}
+
+int vfs_stem_pool_bn_bwd_reduce_launch(const StemBwdArgs& a, int nblk, hipStream_t s) {
+  if (a.C % 8 || 256 % (a.C >> 3)) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd: C must be 8*2^k");
+  hipLaunchKernelGGL(stem_pool_bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, a);
+  return vfs_check_launch("stem_pool_bn_bwd_reduce");
+}
+int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s) {
+  long long b = ((long long)a.N * a.H * a.W * (a.C >> 3) + 255) / 256;
+  hipLaunchKernelGGL(stem_pool_bn_bwd_apply_kernel, dim3((int)(b > 8192 ? 8192 : b)), dim3(256), 0, s, a);
+  return vfs_check_launch("stem_pool_bn_bwd_apply");
 }
 
 // dgamma[c] += sum_g S2_local[g][c],  dbeta[c] += sum_g S1_local[g][c]  (local sums: DDP averages)
@@ -374,6 +520,7 @@ int vfs_bn_bwd_reduce_launch(const BnBwdArgs& a, int nblk, hipStream_t s) {
   return vfs_check_launch("bn_bwd_reduce");
 }
 int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
+  if (((a.M + a.mpg - 1) / a.mpg) * a.C > 4096) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply: groups*C > 4096");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.M * (a.C >> 3))), dim3(256), 0, s, a);
   return vfs_check_launch("bn_bwd_apply");
 }

@@ -152,6 +152,27 @@ int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, co
   a.relu = relu;
   return vfs_bn_bwd_apply_launch(a, S(stream));
 }
+int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, const vfs_bf16* x, const float* bnp,
+                                float* partial, int N, int H, int W, int C, int Hp, int Wp, int npg, int ppb,
+                                vfs_stream_t stream) {
+  const long long mpg = (long long)npg * Hp * Wp;
+  if (ppb <= 0 || mpg % ppb) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd_reduce: pooled pixels per group % ppb");
+  StemBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gp = gp; a.yp = yp; a.idx = idx; a.x = x; a.bnp = bnp; a.partial = partial;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg; a.ppb = ppb;
+  const long long P = (long long)N * Hp * Wp;
+  return vfs_stem_pool_bn_bwd_reduce_launch(a, (int)((P + ppb - 1) / ppb), S(stream));
+}
+int vfs_stem_pool_bn_bwd_apply(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, const vfs_bf16* x, const float* bnp,
+                               const double* sums, vfs_bf16* dx, int N, int H, int W, int C, int Hp, int Wp, int npg,
+                               double count, vfs_stream_t stream) {
+  StemBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gp = gp; a.yp = yp; a.idx = idx; a.x = x; a.bnp = bnp; a.sums = sums; a.dx = dx;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg; a.count = count;
+  return vfs_stem_pool_bn_bwd_apply_launch(a, S(stream));
+}
 int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C, vfs_stream_t stream) {
   return vfs_bn_param_grad_launch(sums, dgamma, dbeta, G, C, S(stream));
 }

@@ -53,6 +53,22 @@ struct BnBwdArgs {
 };
 
 #define VFS_BN_MAX_CHUNKS 128
+// stem: BN backward through max-pool + ReLU (bn.hip)
+struct StemBwdArgs {
+  const bf16_t* gp;    // [N][Hp][Wp][C] gradient wrt the pooled output
+  const bf16_t* yp;    // pooled output (ReLU mask)
+  const uint8_t* idx;  // argmax codes
+  const bf16_t* x;     // [N][H][W][C] raw stem conv output
+  const float* bnp;    // [G][4][C]
+  const double* sums;  // pass 2
+  float* partial;      // pass 1: [nblk][2][C]
+  bf16_t* dx;          // pass 2: [N][H][W][C]
+  int N, H, W, C, Hp, Wp, npg, ppb;   // images per group, pooled pixels per block (pass 1)
+  double count;
+};
+
+int vfs_stem_pool_bn_bwd_reduce_launch(const StemBwdArgs& a, int nblk, hipStream_t s);
+int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s);
 int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s);
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s);

@@ -200,6 +200,29 @@ class Engine:
         lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), rl, s)
         return dx, gm
 
+    def stem_pool_bn_bwd(self, u, gp, yp, idx, raw, N, H, W, Hp, Wp, G):
+        """BN backward of the stem through max-pool + ReLU (no full-resolution gradient tensor)."""
+        dev = raw.device
+        s = self.stream(dev)
+        lib = self.lib
+        C = u.cout
+        npg = N // G
+        mpg_p = npg * Hp * Wp
+        ppb = math.gcd(mpg_p, 256)
+        if ppb < 16:
+            ppb = mpg_p
+        nblk = (N * Hp * Wp) // ppb
+        partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
+        u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
+        lib.stem_pool_bn_bwd_reduce(gp, yp, idx, raw, u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
+        lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, nblk // G, C, s)
+        lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
+        self.allreduce(u.bsums)
+        dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
+        lib.stem_pool_bn_bwd_apply(gp, yp, idx, raw, u.bnp, u.bsums, dx, N, H, W, C, Hp, Wp, npg,
+                                   float(npg * H * W * self.world), s)
+        return dx
+
     def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None):
         """weight (and bias) gradients accumulate into .grad; returns the input gradient or None."""
         dev = dx.device

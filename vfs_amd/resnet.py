@@ -309,10 +309,8 @@ class ResNet(nn.Module):
         # stem: maxpool+relu backward -> BN backward -> wgrad
         dev = g.device
         Hs, Ws = ctx['Hs'], ctx['Ws']
-        ga = eng.buf('backbone.stem_ga', (N, Hs, Ws, 64), BF16, dev)
-        eng.lib.maxpool_relu_bwd(g, ctx['pooled'], ctx['idx'], ga, N, Hs, Ws, 64, ctx['Hp'], ctx['Wp2'], eng.stream(dev))
         stem = self.conv1.unit
-        dx, _ = eng.bn_bwd(stem, ga, None, ctx['stem_raw'], N * Hs * Ws, G)
+        dx = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G)
         eng.conv_bwd(stem, dx, ctx['x4'], N, ctx['H'], ctx['Wp'], Hs, Ws, need_dgrad=False)
 
     def _block_bwd(self, eng, bctx, g, N, G):
