@@ -91,9 +91,12 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    force_coll = os.environ.get('VFS_FORCE_COLLECTIVES') == '1'   # 1-rank RCCL group: exercises the collective calls
+    if world > 1 or force_coll:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     import vfs_amd
     from vfs_amd.engine import shared_engine
@@ -189,7 +192,7 @@ def main():
         res['cpu_baseline'] = cpu_baseline_subprocess(depth, args.size, min(os.cpu_count() or 1, 64))
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

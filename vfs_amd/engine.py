@@ -9,6 +9,7 @@ Layout of one "unit" (mmcv ConvModule = conv -> BN -> act in the reference):
 Backward of a unit: bn_bwd_reduce -> (all-reduce) -> bn_bwd_apply -> wgrad (+dgrad).
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -88,8 +89,16 @@ class Engine:
         self.prof.append((kind, flops, e0, e1))
         return rc
 
+    @property
+    def collectives_on(self):
+        """collectives run when world > 1; VFS_FORCE_COLLECTIVES=1 also runs them in a 1-rank group
+        (exercises the RCCL calls, dtypes and stream ordering on a single-GPU box)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.world > 1 or os.environ.get('VFS_FORCE_COLLECTIVES') == '1'
+
     def allreduce(self, t):
-        if self.world > 1:
+        if self.collectives_on:
             dist.all_reduce(t, group=self.process_group)
 
     # ------------------------------------------------------------------ weights

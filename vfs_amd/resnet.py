@@ -284,14 +284,16 @@ class ResNet(nn.Module):
                 ah, aw = oh, ow
         return a, ah, aw, bctx
 
-    def backward_nhwc(self, eng, ctx, grads):
+    def backward_nhwc(self, eng, ctx, grads, on_stage_done=None):
         """grads: {stage: gradient wrt that stage's output (bf16 NHWC)}; accumulates parameter
-        gradients (the stem needs no input gradient)."""
+        gradients (the stem needs no input gradient).  on_stage_done(module) is called as soon as
+        all parameter gradients of a stage / the stem are final (gradient all-reduce overlap)."""
         N, G = ctx['N'], ctx['G']
         blocks = ctx['blocks']
-        stage_end = {}
+        stage_end, stage_start = {}, {}
         bi = 0
         for si, lname in enumerate(self.res_layers):
+            stage_start[bi] = si
             bi += len(getattr(self, lname))
             stage_end[bi - 1] = si
         g = None
@@ -306,12 +308,16 @@ class ResNet(nn.Module):
             if g is None:
                 continue
             g = self._block_bwd(eng, blocks[i], g, N, G)
+            if on_stage_done is not None and i in stage_start:
+                on_stage_done(getattr(self, self.res_layers[stage_start[i]]))
         # stem: maxpool+relu backward -> BN backward -> wgrad
         dev = g.device
         Hs, Ws = ctx['Hs'], ctx['Ws']
         stem = self.conv1.unit
         dx = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G)
         eng.conv_bwd(stem, dx, ctx['x4'], N, ctx['H'], ctx['Wp'], Hs, Ws, need_dgrad=False)
+        if on_stage_done is not None:
+            on_stage_done(self.conv1)
 
     def _block_bwd(self, eng, bctx, g, N, G):
         blk = bctx['blk']

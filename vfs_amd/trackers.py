@@ -212,8 +212,10 @@ class SimSiamBaseTracker(BaseTracker):
                                 c['K'], c['neg'], c['weight'], s)
         gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
         works = self._allreduce_range(self._head_range(), async_op=True)
-        self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat})
-        works += self._allreduce_range(self._backbone_range(), async_op=True)
+
+        def stage_done(module):      # gradients of `module` are final: reduce them while earlier stages run
+            works.extend(self._allreduce_range(self._param_range(module), async_op=True))
+        self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat}, on_stage_done=stage_done)
         for wk in works:
             wk.wait()
         self._ctx = None
@@ -235,7 +237,7 @@ class SimSiamBaseTracker(BaseTracker):
 
     def _allreduce_range(self, rng, async_op=True):
         """mean-all-reduce flat_grads[lo:hi] in ~25 MB buckets (torch DDP's default bucket size)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not shared_engine().collectives_on:
             return []
         lo, hi = rng
         eng = shared_engine()
