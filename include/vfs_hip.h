@@ -50,7 +50,8 @@ int vfs_pack_weights(const void* desc, int ntensors, long long total_elems, vfs_
 int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats,
                  int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                  int pad, vfs_stream_t stream);
-/* 7x7/2 stem conv (resnet.py:422-434) on NHWC4 input, wf = [64][8][8][4] */
+/* 7x7/2 stem conv (resnet.py:422-434) on NHWC4 input, wf = [64][8][8][4].  stats rows: one per
+ * spatial tile of 8x16 output pixels, N*ceil(Ho/8)*ceil(Wo/16) rows of [2][64] (image-major) */
 int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* stats, int N, int H,
                  int Wp, int Ho, int Wo, vfs_stream_t stream);
 /* dgrad (autograd of the above): dx[N,H,W,Cin] = conv_transpose(dy[N,Ho,Wo,Cout], wd) (+ add) */
@@ -106,6 +107,13 @@ int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, in
 int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx,
                                 const vfs_bf16* x, const float* bnp, float* partial, int N, int H, int W,
                                 int C, int Hp, int Wp, int npg, int ppb, vfs_stream_t stream);
+/* stem weight gradient with the BN-backward apply pass folded into its operand load (the
+ * full-resolution dx is never materialised): grad[64][3][7][7] += ...; partial: float[nblocks][64][224],
+ * nblocks = ceil(ntiles / ceil(ntiles / nblocks)) with ntiles = N*ceil(Ho/8)*ceil(Wo/16) */
+int vfs_stem_wgrad_fused(const vfs_bf16* x4, const vfs_bf16* xraw, const vfs_bf16* gp, const vfs_bf16* yp,
+                         const uint8_t* idx, const float* bnp, const double* sums, float* partial,
+                         float* grad, int N, int Hin, int Win, int Ho, int Wo, int Hp, int Wp, int npg,
+                         double count, int nblocks, vfs_stream_t stream);
 int vfs_stem_pool_bn_bwd_apply(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx,
                                const vfs_bf16* x, const float* bnp, const double* sums, vfs_bf16* dx,
                                int N, int H, int W, int C, int Hp, int Wp, int npg, double count,

@@ -224,3 +224,48 @@ def test_stem_pool_bn_bwd_fused_equals_unfused(backend):
     dx2 = torch.empty(N, H, W, C, dtype=torch.bfloat16)
     lib.stem_pool_bn_bwd_apply(gp, y, idx, nhwc(x), bnp, sums, dx2, N, H, W, C, Hp, Wp, N // G, float(mpg), None)
     assert torch.equal(dx2, dx)
+
+
+def test_stem_wgrad_fused_equals_unfused_chain(backend):
+    """stem weight gradient with the BN-backward apply folded into the operand load vs the
+    materialising chain (stem_pool_bn_bwd_apply -> stem_wgrad) on the same inputs"""
+    from vfs_amd.packing import build_pack_table, wgrad_splits
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(8)
+    N, H, W, G = 4, 40, 36, 2                       # input frames; stem output 20x18 (ragged 8x16 tiles)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    img = rb(torch.randn(N, 3, H, W, generator=g))
+    x4 = torch.zeros(N, H, W, 4, dtype=torch.bfloat16)
+    lib.imgs_to_nhwc4(img.reshape(N, 1, 3, 1, H, W).contiguous(), x4, N, 1, 1, H, W, W, None)
+    raw = rb(torch.randn(N, 64, Ho, Wo, generator=g))     # any raw conv output works for this identity
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    bnp, mpg = bn_forward_chain(lib, nhwc(raw), gamma, beta, G, torch.zeros(64), torch.ones(64))
+    y = torch.empty(N, Hp, Wp, 64, dtype=torch.bfloat16)
+    idx = torch.empty(N, Hp, Wp, 64, dtype=torch.uint8)
+    lib.bn_relu_maxpool(nhwc(raw), bnp, y, idx, N, Ho, Wo, 64, Hp, Wp, N // G, None)
+    gp = nhwc(rb(torch.randn(N, 64, Hp, Wp, generator=g)))
+    P = N * Hp * Wp
+    ppb = P // G
+    partial = torch.zeros(P // ppb, 2, 64)
+    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(raw), bnp, partial, N, Ho, Wo, 64, Hp, Wp, N // G, ppb, None)
+    sums = torch.zeros(G, 2, 64, dtype=torch.float64)
+    lib.bn_reduce_partials(partial, sums, None, G, (P // ppb) // G, 64, None)
+    count = float(mpg)
+    # materialising chain
+    dx = torch.empty(N, Ho, Wo, 64, dtype=torch.bfloat16)
+    lib.stem_pool_bn_bwd_apply(gp, y, idx, nhwc(raw), bnp, sums, dx, N, Ho, Wo, 64, Hp, Wp, N // G, count, None)
+    M = N * Ho * Wo
+    nsplit, pps = wgrad_splits(M, 64, 256, target_blocks=6)
+    part1 = torch.zeros(nsplit, 64, 256)
+    grad1 = torch.zeros(64, 3, 7, 7)
+    lib.stem_wgrad(dx, x4, part1, grad1, N, H, W, Ho, Wo, nsplit, pps, None)
+    # fused
+    ntiles = N * ((Ho + 7) // 8) * ((Wo + 15) // 16)
+    tpb = (ntiles + 4) // 5
+    nblocks = (ntiles + tpb - 1) // tpb
+    part2 = torch.zeros(nblocks, 64, 224)
+    grad2 = torch.ones(64, 3, 7, 7)
+    lib.stem_wgrad_fused(x4, nhwc(raw), gp, y, idx, bnp, sums, part2, grad2, N, H, W, Ho, Wo, Hp, Wp, N // G, count,
+                         nblocks, None)
+    assert relerr(grad2 - 1.0, grad1) < 2e-4

@@ -119,10 +119,23 @@ def test_stem_fwd_wgrad(backend):
     assert torch.equal(x4[..., :3].float().cpu(), x.permute(0, 2, 3, 1)) and (x4[..., 3] == 0).all()
     M = N * Ho * Wo
     y = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
-    stats = torch.zeros((M + 127) // 128, 2, 64, device=dev)
+    ntile = N * ((Ho + 7) // 8) * ((Wo + 15) // 16)
+    stats = torch.full((ntile, 2, 64), float('nan'), device=dev)
     lib.stem_fwd(x4, wf, y, stats, N, H, W, Ho, Wo, None)
     ref = F.conv2d(x, w, None, 2, 3)
     assert relerr(nchw(y.cpu()), ref) < 6e-3
+    yf = y.float().cpu().reshape(M, 64).double()
+    st = stats.cpu().double()
+    assert torch.allclose(st[:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=5e-3)
+    assert torch.allclose(st[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=5e-3)
+    half = ntile // 2     # first / second half of the images = first / second half of the rows
+    assert torch.allclose(st[:half, 0].sum(0), yf[:M // 2].sum(0), rtol=1e-4, atol=5e-3)
+    # the generic implicit-GEMM stem path must agree bit-for-bit on the output
+    lib.set_option(b'stem_direct', 0)
+    y2 = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
+    lib.stem_fwd(x4, wf, y2, None, N, H, W, Ho, Wo, None)
+    lib.set_option(b'stem_direct', 1)
+    assert relerr(nchw(y2.cpu()), ref) < 6e-3
     dy = rb(torch.randn(N, 64, Ho, Wo, generator=g))
     wr = w.clone().requires_grad_(True)
     F.conv2d(x, wr, None, 2, 3).backward(dy)

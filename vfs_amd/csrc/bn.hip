@@ -10,6 +10,7 @@
 // bnp layout (per layer): float[G][4][C] = {scale = gamma*invstd, shift = beta - mean*scale,
 //                                           mean, invstd}
 #include "vfs_ops.h"
+#include "vfs_stem.h"
 
 // ------------------------------------------------------------------------------------------
 // partial[nblk][2][C] (fp32, one per producer block) -> sums[G][2][C] (fp64), fixed order.
@@ -402,44 +403,9 @@ __global__ __launch_bounds__(256) void stem_pool_bn_bwd_apply_kernel(StemBwdArgs
     const int w = (int)(p % a.W); p /= a.W;
     const int h = (int)(p % a.H);
     const int n = (int)(p / a.H);
-    const int gi = n / a.npg;
-    float g[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = 0.f;
-    for (int hp = h >> 1; hp <= (h + 1) >> 1; ++hp) {
-      if (hp >= a.Hp) continue;
-      const int dy = h - (2 * hp - 1);
-      for (int wp = w >> 1; wp <= (w + 1) >> 1; ++wp) {
-        if (wp >= a.Wp) continue;
-        const int dx = w - (2 * wp - 1);
-        const unsigned code = (unsigned)(dy * 3 + dx);
-        const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
-        const u32x2 id = ld8(a.idx + o);
-        float gp[8], yp[8];
-        unpack8(ld16(a.gp + o), gp);
-        unpack8(ld16(a.yp + o), yp);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const unsigned b = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;
-          if (b == code && yp[i] > 0.f) g[i] += gp[i];
-        }
-      }
-    }
-    const size_t o = (((size_t)n * a.H + h) * a.W + w) * a.C + c;
-    float x[8], sc[8], mean[8], inv[8], d[8];
-    unpack8(ld16(a.x + o), x);
-    const float* bp = a.bnp + (size_t)gi * 4 * a.C;
-    ld8f(bp + c, sc);
-    ld8f(bp + 2 * a.C + c, mean);
-    ld8f(bp + 3 * a.C + c, inv);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float m1 = (float)a.sums[((size_t)gi * 2) * a.C + c + i] * rc;
-      const float m2 = (float)a.sums[((size_t)gi * 2 + 1) * a.C + c + i] * rc;
-      // ga as the materialising path would have stored it (bf16), then the BN backward formula
-      d[i] = sc[i] * (round_bf(g[i]) - m1 - ((x[i] - mean[i]) * inv[i]) * m2);
-    }
-    st16(a.dx + o, pack8(d));
+    float d[8];
+    stem_dx_vec(a, n, h, w, c, rc, d);
+    st16(a.dx + (((size_t)n * a.H + h) * a.W + w) * a.C + c, pack8(d));
   }
 }
 

@@ -25,6 +25,7 @@ int vfs_check_launch(const char* what) {
 #define S(s) ((hipStream_t)(s))
 
 int vfs_option_halo = 1;
+int vfs_option_stem_direct = 1;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -40,6 +41,7 @@ const char* vfs_last_error(void) { return g_err; }
 int vfs_abi_version(void) { return 1; }
 int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo")) { vfs_option_halo = value; return VFS_OK; }
+  if (!strcmp(name, "stem_direct")) { vfs_option_stem_direct = value; return VFS_OK; }
   return vfs_set_error(VFS_ERR_ARG, "vfs_set_option: unknown option");
 }
 
@@ -66,6 +68,7 @@ int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* sta
   ConvArgs a;
   a.g = make_geom(N, H, Wp, 4, Ho, Wo, 7, 7, 2, 3, 256);
   a.src = x4; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = nullptr; a.stats = stats; a.Cout = 64;
+  if (vfs_option_stem_direct && (size_t)N * H * Wp * 8 < 0xFFFFFFF0ull) return vfs_stem_fwd_direct_launch(a, S(stream));
   return vfs_conv_igemm_dispatch(a, GATHER_STEM, S(stream));
 }
 
@@ -172,6 +175,18 @@ int vfs_stem_pool_bn_bwd_apply(const vfs_bf16* gp, const vfs_bf16* yp, const uin
   a.gp = gp; a.yp = yp; a.idx = idx; a.x = x; a.bnp = bnp; a.sums = sums; a.dx = dx;
   a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg; a.count = count;
   return vfs_stem_pool_bn_bwd_apply_launch(a, S(stream));
+}
+int vfs_stem_wgrad_fused(const vfs_bf16* x4, const vfs_bf16* xraw, const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx,
+                         const float* bnp, const double* sums, float* partial, float* grad, int N, int Hin, int Win, int Ho,
+                         int Wo, int Hp, int Wp, int npg, double count, int nblocks, vfs_stream_t stream) {
+  StemBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gp = gp; a.yp = yp; a.idx = idx; a.x = xraw; a.bnp = bnp; a.sums = sums;
+  a.N = N; a.H = Ho; a.W = Wo; a.C = 64; a.Hp = Hp; a.Wp = Wp; a.npg = npg; a.count = count;
+  if ((size_t)N * Hin * Win * 8 >= 0xFFFFFFF0ull) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: input >= 4 GiB");
+  int rc = vfs_stem_wgrad_fused_launch(a, x4, Hin, Win, partial, nblocks, S(stream));
+  if (rc) return rc;
+  return vfs_wgrad_reduce_launch(partial, grad, nblocks, 64, 224, 3, 7, 7, 1, S(stream));
 }
 int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C, vfs_stream_t stream) {
   return vfs_bn_param_grad_launch(sums, dgamma, dbeta, G, C, S(stream));

@@ -145,6 +145,9 @@ class Engine:
         mpg = Ng * Ho * Wo
         fused = G == 1 or mpg % 128 == 0
         nblk_g = (mpg + 127) // 128
+        if u.kind == 'stem':      # the stem kernel emits one statistics row per 8x16 spatial tile
+            fused = True
+            nblk_g = Ng * ((Ho + 7) // 8) * ((Wo + 15) // 16)
         partial = self.ws('ws.stats', G * nblk_g * 2 * u.cout, torch.float32, dev) if want_stats else None
         bias = u.bias.data if u.bias is not None else None
         groups = [(0, N, partial)] if fused else [
@@ -227,10 +230,18 @@ class Engine:
         lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, nblk // G, C, s)
         lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
         self.allreduce(u.bsums)
-        dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
-        lib.stem_pool_bn_bwd_apply(gp, yp, idx, raw, u.bnp, u.bsums, dx, N, H, W, C, Hp, Wp, npg,
-                                   float(npg * H * W * self.world), s)
-        return dx
+        return float(npg * H * W * self.world)
+
+    def stem_wgrad_fused(self, u, x4, Hin, Win, gp, yp, idx, raw, N, H, W, Hp, Wp, G, count):
+        """stem weight gradient; the BN-backward apply pass is folded into its operand load"""
+        dev = raw.device
+        ntiles = N * ((H + 7) // 8) * ((W + 15) // 16)
+        tpb = (ntiles + 511) // 512
+        nblocks = (ntiles + tpb - 1) // tpb
+        partial = self.ws('ws.wgrad', nblocks * 64 * 224, torch.float32, dev)
+        self.timed('conv_wgrad', 2.0 * N * H * W * 64 * 147, dev, self.lib.stem_wgrad_fused,
+                   x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
+                   N // G, count, nblocks, self.stream(dev))
 
     def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None):
         """weight (and bias) gradients accumulate into .grad; returns the input gradient or None."""

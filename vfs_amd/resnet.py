@@ -314,8 +314,9 @@ class ResNet(nn.Module):
         dev = g.device
         Hs, Ws = ctx['Hs'], ctx['Ws']
         stem = self.conv1.unit
-        dx = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G)
-        eng.conv_bwd(stem, dx, ctx['x4'], N, ctx['H'], ctx['Wp'], Hs, Ws, need_dgrad=False)
+        count = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G)
+        eng.stem_wgrad_fused(stem, ctx['x4'], ctx['H'], ctx['Wp'], g, ctx['pooled'], ctx['idx'], ctx['stem_raw'],
+                             N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G, count)
         if on_stage_done is not None:
             on_stage_done(self.conv1)
 
