@@ -394,18 +394,19 @@ __global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(StemBwdArg
 }
 
 __global__ __launch_bounds__(256) void stem_pool_bn_bwd_apply_kernel(StemBwdArgs a) {
-  const int cv = a.C >> 3;
-  const long long total = (long long)a.N * a.H * a.W * cv;
-  const float rc = (float)(1.0 / a.count);
+  __shared__ float tab[STEM_MAX_GROUPS * STEM_TAB];
+  stem_fill_table(a, tab, (float)(1.0 / a.count));
+  __syncthreads();
+  const long long total = (long long)a.N * a.H * a.W * 8;
   for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
-    long long p = v / cv;
-    const int c = (int)(v - p * cv) * 8;
+    long long p = v >> 3;
+    const int c = (int)(v & 7) * 8;
     const int w = (int)(p % a.W); p /= a.W;
     const int h = (int)(p % a.H);
     const int n = (int)(p / a.H);
     float d[8];
-    stem_dx_vec(a, n, h, w, c, rc, d);
-    st16(a.dx + (((size_t)n * a.H + h) * a.W + w) * a.C + c, pack8(d));
+    stem_dx_vec(a, tab, n, h, w, c, d);
+    st16(a.dx + (((size_t)n * a.H + h) * a.W + w) * 64 + c, pack8(d));
   }
 }
 
@@ -415,6 +416,7 @@ int vfs_stem_pool_bn_bwd_reduce_launch(const StemBwdArgs& a, int nblk, hipStream
   return vfs_check_launch("stem_pool_bn_bwd_reduce");
 }
 int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s) {
+  if (a.C != 64 || (a.N + a.npg - 1) / a.npg > STEM_MAX_GROUPS) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd_apply: C == 64, <= 8 groups");
   long long b = ((long long)a.N * a.H * a.W * (a.C >> 3) + 255) / 256;
   hipLaunchKernelGGL(stem_pool_bn_bwd_apply_kernel, dim3((int)(b > 8192 ? 8192 : b)), dim3(256), 0, s, a);
   return vfs_check_launch("stem_pool_bn_bwd_apply");

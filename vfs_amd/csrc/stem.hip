@@ -163,11 +163,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_fused_kernel(StemBwdArgs a, co
   // a.x = raw stem output [N][Ho][Wo][64] (a.H, a.W = Ho, Wo); x4 = NHWC4 input [N][Hin][Win][4]
   __shared__ __attribute__((aligned(16))) bf16_t sX[ST_PH * ST_PROW];
   __shared__ __attribute__((aligned(16))) bf16_t sD[128 * SD_RS];
+  __shared__ float sTab[STEM_MAX_GROUPS * STEM_TAB];  // per-group BN backward coefficients
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wk = wave >> 1, wn = wave & 1;            // wave: 7 k-column tiles x 32 cout
   const int lr = lane & 15, lq = lane >> 4;
   const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
   const float rc = (float)(1.0 / a.count);
+  stem_fill_table(a, sTab, rc);
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)x4, 0, (unsigned)((size_t)a.N * Hin * Win * 4 * 2), 0x00020000);
 
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_fused_kernel(StemBwdArgs a, co
       const int y = y0 + (p >> 4), x = x0 + (p & 15);
       float d[8];
       if (y < a.H && x < a.W) {
-        stem_dx_vec(a, n, y, x, j * 8, rc, d);
+        stem_dx_vec(a, sTab, n, y, x, j * 8, d);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] = 0.f;
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_fused_kernel(StemBwdArgs a, co
 int vfs_stem_wgrad_fused_launch(const StemBwdArgs& a, const bf16_t* x4, int Hin, int Win, float* partial, int nblocks,
                                 hipStream_t stream) {
   const int ntiles = vfs_stem_tiles(a.N, a.H, a.W);
+  if ((a.N + a.npg - 1) / a.npg > 8) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: more than 8 BN groups");
   if (nblocks > ntiles) nblocks = ntiles;
   const int tpb = (ntiles + nblocks - 1) / nblocks;
   if ((ntiles + tpb - 1) / tpb != nblocks) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: nblocks must equal ceil(ntiles / ceil(ntiles/nblocks))");

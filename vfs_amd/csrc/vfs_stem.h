@@ -3,49 +3,65 @@
 #pragma once
 #include "vfs_ops.h"
 
-__device__ __forceinline__ void stem_ld8f(const float* p, float* f) {
-  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
-  f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+#define STEM_MAX_GROUPS 8
+#define STEM_TAB (5 * 64)   // per group: scale, mean, invstd, S1/count, S2/count for 64 channels
+
+// fill the per-group coefficient table (LDS) once per workgroup; caller syncs afterwards
+__device__ __forceinline__ void stem_fill_table(const StemBwdArgs& a, float* tab, float rc) {
+  const int ngroups = (a.N + a.npg - 1) / a.npg;
+  for (int i = threadIdx.x; i < ngroups * STEM_TAB; i += blockDim.x) {
+    const int gi = i / STEM_TAB, rem = i - gi * STEM_TAB, k = rem >> 6, c = rem & 63;
+    float v;
+    if (k == 0) v = a.bnp[(size_t)gi * 4 * 64 + c];
+    else if (k == 1) v = a.bnp[(size_t)gi * 4 * 64 + 2 * 64 + c];
+    else if (k == 2) v = a.bnp[(size_t)gi * 4 * 64 + 3 * 64 + c];
+    else v = (float)a.sums[((size_t)gi * 2 + (k - 3)) * 64 + c] * rc;
+    tab[i] = v;
+  }
 }
 
-// d[8] = scale * (bf16(ga) - m1 - xhat*m2) for pixel (n,h,w), channels c..c+7
-__device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, int n, int h, int w, int c, float rc, float* d) {
+// d[8] = scale * (bf16(ga) - m1 - xhat*m2) for pixel (n,h,w), channels c..c+7 (C = 64).
+// ga = sum over the <=4 pooling windows whose argmax is (h,w) of gp*(yp>0); all window loads are
+// issued up front (clamped addresses + predicates) so ~13 independent loads are in flight.
+__device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* tab, int n, int h, int w, int c, float* d) {
   const int gi = n / a.npg;
+  const int hp[2] = {h >> 1, (h + 1) >> 1}, wp[2] = {w >> 1, (w + 1) >> 1};
+  u32x2 id[4];
+  u32x4 gv[4], yv[4];
+  unsigned code[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int hh = hp[k >> 1], ww = wp[k & 1];
+    ok[k] = hh < a.Hp && ww < a.Wp && !((k >> 1) && hp[1] == hp[0]) && !((k & 1) && wp[1] == wp[0]);
+    const int hc = hh < a.Hp ? hh : a.Hp - 1, wc = ww < a.Wp ? ww : a.Wp - 1;
+    code[k] = (unsigned)((h - (2 * hh - 1)) * 3 + (w - (2 * ww - 1)));
+    const size_t o = ((((size_t)n * a.Hp + hc) * a.Wp) + wc) * 64 + c;
+    id[k] = ld8(a.idx + o);
+    gv[k] = ld16(a.gp + o);
+    yv[k] = ld16(a.yp + o);
+  }
+  const u32x4 xv = ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * 64 + c);
   float g[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) g[i] = 0.f;
-  for (int hp = h >> 1; hp <= (h + 1) >> 1; ++hp) {
-    if (hp >= a.Hp) continue;
-    const int dy = h - (2 * hp - 1);
-    for (int wp = w >> 1; wp <= (w + 1) >> 1; ++wp) {
-      if (wp >= a.Wp) continue;
-      const int dx = w - (2 * wp - 1);
-      const unsigned code = (unsigned)(dy * 3 + dx);
-      const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
-      const u32x2 id = ld8(a.idx + o);
-      float gp[8], yp[8];
-      unpack8(ld16(a.gp + o), gp);
-      unpack8(ld16(a.yp + o), yp);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned b = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;
-        if (b == code && yp[i] > 0.f) g[i] += gp[i];
-      }
+  for (int k = 0; k < 4; ++k) {
+    float gp[8], yp[8];
+    unpack8(gv[k], gp);
+    unpack8(yv[k], yp);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned b = ((i < 4 ? id[k].x : id[k].y) >> (8 * (i & 3))) & 0xffu;
+      if (ok[k] && b == code[k] && yp[i] > 0.f) g[i] += gp[i];
     }
   }
-  const size_t o = (((size_t)n * a.H + h) * a.W + w) * a.C + c;
-  float x[8], sc[8], mean[8], inv[8];
-  unpack8(ld16(a.x + o), x);
-  const float* bp = a.bnp + (size_t)gi * 4 * a.C;
-  stem_ld8f(bp + c, sc);
-  stem_ld8f(bp + 2 * a.C + c, mean);
-  stem_ld8f(bp + 3 * a.C + c, inv);
+  float x[8];
+  unpack8(xv, x);
+  const float* tb = tab + gi * STEM_TAB + c;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float m1 = (float)a.sums[((size_t)gi * 2) * a.C + c + i] * rc;
-    const float m2 = (float)a.sums[((size_t)gi * 2 + 1) * a.C + c + i] * rc;
     // ga as a materialising path would have stored it (bf16), then the BN backward formula
-    d[i] = sc[i] * (round_bf(g[i]) - m1 - ((x[i] - mean[i]) * inv[i]) * m2);
+    d[i] = tb[i] * (round_bf(g[i]) - tb[3 * 64 + i] - ((x[i] - tb[64 + i]) * tb[2 * 64 + i]) * tb[4 * 64 + i]);
   }
 }

@@ -236,7 +236,7 @@ class Engine:
         """stem weight gradient; the BN-backward apply pass is folded into its operand load"""
         dev = raw.device
         ntiles = N * ((H + 7) // 8) * ((W + 15) // 16)
-        tpb = (ntiles + 511) // 512
+        tpb = (ntiles + 1535) // 1536        # ~6 workgroups per CU: the operand gather is latency-bound
         nblocks = (ntiles + tpb - 1) // tpb
         partial = self.ws('ws.wgrad', nblocks * 64 * 224, torch.float32, dev)
         self.timed('conv_wgrad', 2.0 * N * H * W * 64 * 147, dev, self.lib.stem_wgrad_fused,

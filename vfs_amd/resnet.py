@@ -4,6 +4,8 @@
 Parameters live in torch.nn containers with the reference's module names so state_dicts are
 interchangeable (`conv1.conv.weight`, `layer2.0.downsample.bn.running_mean`, ...); the arithmetic
 is done by vfs_amd.engine on NHWC bf16 buffers.  There is no torch fallback."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -315,8 +317,14 @@ class ResNet(nn.Module):
         Hs, Ws = ctx['Hs'], ctx['Ws']
         stem = self.conv1.unit
         count = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G)
-        eng.stem_wgrad_fused(stem, ctx['x4'], ctx['H'], ctx['Wp'], g, ctx['pooled'], ctx['idx'], ctx['stem_raw'],
-                             N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G, count)
+        if os.environ.get('VFS_STEM_FUSED', '1') == '1':
+            eng.stem_wgrad_fused(stem, ctx['x4'], ctx['H'], ctx['Wp'], g, ctx['pooled'], ctx['idx'], ctx['stem_raw'],
+                                 N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G, count)
+        else:   # materialise dx, then the generic implicit-GEMM stem wgrad
+            dx = eng.buf('backbone.conv1.dx', ctx['stem_raw'].shape, BF16, dev)
+            eng.lib.stem_pool_bn_bwd_apply(g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], stem.bnp, stem.bsums, dx, N, Hs,
+                                           Ws, 64, ctx['Hp'], ctx['Wp2'], N // G, count, eng.stream(dev))
+            eng.conv_bwd(stem, dx, ctx['x4'], N, ctx['H'], ctx['Wp'], Hs, Ws, need_dgrad=False)
         if on_stage_done is not None:
             on_stage_done(self.conv1)
 
