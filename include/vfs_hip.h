@@ -79,6 +79,13 @@ int vfs_bn_reduce_partials(const float* partial, double* sums, double* scratch, 
 int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp,
                     float* running_mean, float* running_var, int G, int C, double count, float eps,
                     float momentum, vfs_stream_t stream);
+/* single-process fast paths (no SyncBN all-reduce in between): vfs_bn_reduce_partials fused with
+ * vfs_bn_finalize, resp. with vfs_bn_param_grad (sums are still written for the apply pass) */
+int vfs_bn_stats_finalize(const float* partial, double* sums, double* scratch, const float* gamma,
+                          const float* beta, float* bnp, float* running_mean, float* running_var, int G,
+                          int bpg, int C, double count, float eps, float momentum, vfs_stream_t stream);
+int vfs_bn_bwd_sums_paramgrad(const float* partial, double* sums, double* scratch, float* dgamma,
+                              float* dbeta, int G, int bpg, int C, vfs_stream_t stream);
 int vfs_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float* bnp, int C, float eps, vfs_stream_t stream);
 /* y = [relu](x*scale+shift [+res] [+ rres*rscale+rshift])   (resnet.py:102-111,221-230) */

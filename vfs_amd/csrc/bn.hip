@@ -74,6 +74,70 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   if (running_var) running_var[c] = rv;
 }
 
+// Single-process fast path: the last reduction stage fused with bn_finalize (MODE 0) or with
+// bn_param_grad (MODE 1) -- one launch less per BatchNorm layer and direction.  One workgroup owns
+// 32 channels and walks the groups in order (the running statistics are updated group by group).
+template <typename TIN, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restrict__ in, double* __restrict__ sums, int G, int rows,
+                                                              int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ bnp, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, double count, float eps,
+                                                              float momentum, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[8][2][32];
+  const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float rm = 0.f, rv = 0.f;
+  double g1 = 0.0, g2 = 0.0;
+  if (MODE == 0 && sl == 0 && c < C) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 0.f; }
+  for (int gi = 0; gi < G; ++gi) {
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+      const TIN* p = in + (size_t)gi * rows * 2 * C;
+      for (int b = sl; b < rows; b += 8) {
+        a0 += (double)p[(size_t)b * 2 * C + c];
+        a1 += (double)p[(size_t)b * 2 * C + C + c];
+      }
+    }
+    __syncthreads();
+    sh[sl][0][cl] = a0;
+    sh[sl][1][cl] = a1;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0 += sh[k][0][cl]; r1 += sh[k][1][cl]; }
+      sums[((size_t)gi * 2 + 0) * C + c] = r0;
+      sums[((size_t)gi * 2 + 1) * C + c] = r1;
+      if (MODE == 0) {
+        const double mean = r0 / count;
+        double var = r1 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * invstd;
+        float* o = bnp + (size_t)gi * 4 * C;
+        o[c] = scale;
+        o[C + c] = beta[c] - (float)mean * scale;
+        o[2 * C + c] = (float)mean;
+        o[3 * C + c] = invstd;
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      } else {
+        g1 += r0; g2 += r1;
+      }
+    }
+  }
+  if (sl == 0 && c < C) {
+    if (MODE == 0) {
+      if (running_mean) running_mean[c] = rm;
+      if (running_var) running_var[c] = rv;
+    } else {
+      dbeta[c] += (float)g1;
+      dgamma[c] += (float)g2;
+    }
+  }
+}
+
 // eval-mode BN: bnp from running statistics (G = 1)
 __global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ running_mean,
@@ -216,14 +280,17 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(PoolBwdArgs a) {
 
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+  // workgroup = ppb pixels x one slab of <= 64 channels (blockIdx.y): wide layers (C up to 2048 with
+  // few pixels) still fill the chip, and every lane keeps 8-12 independent 16-byte loads in flight
   __shared__ float red[256][17];
-  const int cv = a.C >> 3;          // chunk-threads per pixel (<=256)
+  const int cslab = a.C < 64 ? a.C : 64;
+  const int cv = cslab >> 3;        // chunk-threads per pixel (<= 8)
   const int rows = 256 / cv;        // pixels processed per step
   const int t = threadIdx.x;
   const int ct = t % cv, rt = t / cv;
   const long long m0 = (long long)blockIdx.x * a.ppb;
   const int gi = (int)(m0 / a.mpg);
-  const int c = ct * 8;
+  const int c = blockIdx.y * cslab + ct * 8;
   float s1[8], s2[8], mean[8], inv[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -276,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     const int ec = e / 16, ei = e % 16;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[r * cv + ec][ei];
-    const int ch = ec * 8 + (ei & 7);
+    const int ch = blockIdx.y * cslab + ec * 8 + (ei & 7);
     a.partial[(size_t)blockIdx.x * 2 * a.C + (ei >> 3) * a.C + ch] = s;
   }
 }
@@ -457,6 +524,31 @@ int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* sc
                      nchunks, 1);
   return vfs_check_launch("bn_reduce_partials");
 }
+// mode 0: statistics -> bnp + running stats ; mode 1: backward sums -> bsums + dgamma/dbeta
+int vfs_bn_reduce_fused_launch(int mode, const float* partial, double* sums, double* scratch, int G, int bpg, int C,
+                               const float* gamma, const float* beta, float* bnp, float* rm, float* rv, double count, float eps,
+                               float momentum, float* dgamma, float* dbeta, hipStream_t s) {
+  const int cb = (C + 31) / 32;
+  const void* in = partial;
+  int rows = bpg;
+  bool dbl = false;
+  if (bpg > 64 && scratch != nullptr) {   // stage 1: parallel row chunks -> fp64 chunk sums
+    int nchunks = (bpg + 31) / 32;
+    if (nchunks > VFS_BN_MAX_CHUNKS) nchunks = VFS_BN_MAX_CHUNKS;
+    const int rpc = (bpg + nchunks - 1) / nchunks;
+    nchunks = (bpg + rpc - 1) / rpc;
+    hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, nchunks), dim3(256), 0, s, partial, scratch, bpg, C, rpc, nchunks);
+    in = scratch; rows = nchunks; dbl = true;
+  }
+  if (mode == 0) {
+    if (dbl) hipLaunchKernelGGL((bn_reduce_fused_kernel<double, 0>), dim3(cb), dim3(256), 0, s, (const double*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+    else hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 0>), dim3(cb), dim3(256), 0, s, (const float*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+  } else {
+    if (dbl) hipLaunchKernelGGL((bn_reduce_fused_kernel<double, 1>), dim3(cb), dim3(256), 0, s, (const double*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+    else hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 1>), dim3(cb), dim3(256), 0, s, (const float*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+  }
+  return vfs_check_launch("bn_reduce_fused");
+}
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, gamma, beta, bnp, rm, rv, G, C,
@@ -483,8 +575,9 @@ int vfs_maxpool_relu_bwd_launch(const PoolBwdArgs& a, hipStream_t s) {
   return vfs_check_launch("maxpool_relu_bwd");
 }
 int vfs_bn_bwd_reduce_launch(const BnBwdArgs& a, int nblk, hipStream_t s) {
-  if (a.C % 8 || a.C > 2048 || 256 % (a.C >> 3)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_reduce: C must be 8*2^k <= 2048");
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, a);
+  if (a.C % 8 || (a.C < 64 && 256 % (a.C >> 3)) || (a.C >= 64 && a.C % 64))
+    return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_reduce: C must be 8*2^k below 64, a multiple of 64 above");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, a.C < 64 ? 1 : a.C / 64), dim3(256), 0, s, a);
   return vfs_check_launch("bn_bwd_reduce");
 }
 int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {

@@ -117,6 +117,17 @@ int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, f
                     float* running_var, int G, int C, double count, float eps, float momentum, vfs_stream_t stream) {
   return vfs_bn_finalize_launch(sums, gamma, beta, bnp, running_mean, running_var, G, C, count, eps, momentum, S(stream));
 }
+int vfs_bn_stats_finalize(const float* partial, double* sums, double* scratch, const float* gamma, const float* beta, float* bnp,
+                          float* running_mean, float* running_var, int G, int bpg, int C, double count, float eps, float momentum,
+                          vfs_stream_t stream) {
+  return vfs_bn_reduce_fused_launch(0, partial, sums, scratch, G, bpg, C, gamma, beta, bnp, running_mean, running_var, count, eps,
+                                    momentum, nullptr, nullptr, S(stream));
+}
+int vfs_bn_bwd_sums_paramgrad(const float* partial, double* sums, double* scratch, float* dgamma, float* dbeta, int G, int bpg,
+                              int C, vfs_stream_t stream) {
+  return vfs_bn_reduce_fused_launch(1, partial, sums, scratch, G, bpg, C, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.f, 0.f,
+                                    dgamma, dbeta, S(stream));
+}
 int vfs_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* bnp,
                        int C, float eps, vfs_stream_t stream) {
   return vfs_bn_eval_params_launch(gamma, beta, running_mean, running_var, bnp, C, eps, S(stream));

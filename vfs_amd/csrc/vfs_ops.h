@@ -72,6 +72,9 @@ int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s);
 int vfs_stem_wgrad_fused_launch(const StemBwdArgs& a, const bf16_t* x4, int Hin, int Win, float* partial, int nblocks,
                                 hipStream_t stream);
 int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s);
+int vfs_bn_reduce_fused_launch(int mode, const float* partial, double* sums, double* scratch, int G, int bpg, int C,
+                               const float* gamma, const float* beta, float* bnp, float* rm, float* rv, double count, float eps,
+                               float momentum, float* dgamma, float* dbeta, hipStream_t s);
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s);
 int vfs_bn_eval_params_launch(const float* gamma, const float* beta, const float* rm, const float* rv, float* bnp, int C,

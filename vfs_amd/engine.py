@@ -165,11 +165,16 @@ class Engine:
             if train:
                 u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
                 u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
-                lib.bn_reduce_partials(partial, u.sums, self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
-                self.allreduce(u.sums)
-                lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
-                                u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
-                bn.num_batches_tracked += G
+                if self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
+                    lib.bn_reduce_partials(partial, u.sums, self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
+                    self.allreduce(u.sums)
+                    lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
+                                    u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
+                else:
+                    lib.bn_stats_finalize(partial, u.sums, self.bn_scratch(G, u.cout, dev), bn.weight.data, bn.bias.data,
+                                          u.bnp, bn.running_mean, bn.running_var, G, nblk_g, u.cout, float(mpg),
+                                          float(bn.eps), float(bn.momentum), s)
+                u.nbt_pending = getattr(u, 'nbt_pending', 0) + G   # num_batches_tracked, flushed lazily
             else:
                 u.bnp = self.buf(f'{u.name}.bnp_eval', (1, 4, u.cout), torch.float32, dev)
                 lib.bn_eval_params(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, u.bnp, u.cout,
@@ -204,13 +209,30 @@ class Engine:
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
         rl = 1 if relu else 0
         lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, rl, s)
-        lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, nblk // G, C, s)
-        lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
-        self.allreduce(u.bsums)
+        self._bwd_sums(u, partial, G, nblk // G, C, dev)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
         lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), rl, s)
         return dx, gm
+
+    def _bwd_sums(self, u, partial, G, bpg, C, dev):
+        """partial (S1, S2) rows -> u.bsums (all-reduced for SyncBN) and dgamma / dbeta (local sums)"""
+        s = self.stream(dev)
+        if self.collectives_on:
+            self.lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, bpg, C, s)
+            self.lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
+            self.allreduce(u.bsums)
+        else:
+            self.lib.bn_bwd_sums_paramgrad(partial, u.bsums, self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad,
+                                           G, bpg, C, s)
+
+    def flush_counters(self):
+        """materialise the lazily counted BatchNorm.num_batches_tracked buffers"""
+        for u in self.units:
+            n = getattr(u, 'nbt_pending', 0)
+            if n and u.bn is not None:
+                u.bn.num_batches_tracked += n
+                u.nbt_pending = 0
 
     def stem_pool_bn_bwd(self, u, gp, yp, idx, raw, N, H, W, Hp, Wp, G):
         """BN backward of the stem through max-pool + ReLU (no full-resolution gradient tensor)."""
@@ -227,9 +249,7 @@ class Engine:
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
         lib.stem_pool_bn_bwd_reduce(gp, yp, idx, raw, u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
-        lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, nblk // G, C, s)
-        lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
-        self.allreduce(u.bsums)
+        self._bwd_sums(u, partial, G, nblk // G, C, dev)
         return float(npg * H * W * self.world)
 
     def stem_wgrad_fused(self, u, x4, Hin, Win, gp, yp, idx, raw, N, H, W, Hp, Wp, G, count):
@@ -281,6 +301,13 @@ def shared_engine(device=None):
     if eng is None:
         eng = _ENGINES['default'] = Engine()
     return eng
+
+
+def flush_counters_hook(module, prefix, keep_vars):
+    """state_dict pre-hook of the VFS modules: num_batches_tracked is counted on the host"""
+    eng = _ENGINES.get('default')
+    if eng is not None:
+        eng.flush_counters()
 
 
 def set_shared_engine(eng):

@@ -47,8 +47,11 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
         return nsplit, tps * 128
     nkb = (Ktot + 127) // 128
     ncb = Cout // (128 if Cout % 128 == 0 else 64)
-    max_split = max(1, (M + 63) // 64)
+    # every split writes (and wgrad_reduce re-reads) a full Cout x Ktot fp32 partial: aim for ~2-4
+    # workgroups per CU, at least 8 pixel steps (512 pixels) per split, and <= 48 MB of partials
+    max_split = max(1, M // 512)
     nsplit = max(1, min(max_split, (target_blocks + nkb * ncb - 1) // (nkb * ncb)))
+    nsplit = max(1, min(nsplit, (48 << 20) // (Cout * Ktot * 4)))
     pps = ((M + nsplit - 1) // nsplit + 63) // 64 * 64
     nsplit = (M + pps - 1) // pps
     return nsplit, pps

@@ -119,6 +119,8 @@ class ResNet(nn.Module):
         self.feat_dim = self.block.expansion * 64 * 2 ** (len(self.stage_blocks) - 1)
         self._engine = None
         self._freeze_stages()
+        from .engine import flush_counters_hook
+        self.register_state_dict_pre_hook(flush_counters_hook)
 
     # ------------------------------------------------------------------ reference-compatible API
     def init_weights(self):

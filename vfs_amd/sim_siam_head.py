@@ -61,6 +61,8 @@ class SimSiamHead(nn.Module):
         self.avg_pool = nn.AdaptiveAvgPool2d((1, 1))
         self.units = None
         self._engine = None
+        from .engine import flush_counters_hook
+        self.register_state_dict_pre_hook(flush_counters_hook)
 
     def init_weights(self):
         pass  # the reference keeps torch's Linear defaults (sim_siam_head.py:127-129)
