@@ -151,10 +151,12 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
 /* masked_attention_efficient (local_attention.py:237-348) + spatial_neighbor 'circle'
  * (affinity_utils.py:144-156): fbank [frames][H*W][C] normalised bf16, sbank [frames][H*W][CO]
  * fp32; key frames kslot[0..nkeys) in the reference's order (first frame first, duplicates
- * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), topk <= 10. */
-int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, int qframe, const int* kslot,
-                  int nkeys, int H, int W, int C, int CO, int radius, int topk, float temperature,
-                  vfs_stream_t stream);
+ * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), topk <= 10.
+ * workspace: 24*H*W*10*8 bytes (per-split partial top-k lists: key frames are split over
+ * workgroups because a DAVIS frame has only 8x14 query tiles) */
+int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe,
+                  const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int topk,
+                  float temperature, vfs_stream_t stream);
 /* bilinear upsample (align_corners=False) + per-channel min-max normalisation where max > 0 +
  * argmax -> uint8 [Ho][Wo] (vanilla_tracker.py:162-181); partial: workspace float[64*CO*2] */
 int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho,

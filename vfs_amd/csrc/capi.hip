@@ -239,11 +239,13 @@ int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream) { return 
 int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stream_t stream) {
   return vfs_l2norm_rows_launch(x, y, P, C, S(stream));
 }
-int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, int qframe, const int* kslot, int nkeys, int H, int W,
-                  int C, int CO, int radius, int topk, float temperature, vfs_stream_t stream) {
+int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
+                  int H, int W, int C, int CO, int radius, int topk, float temperature, vfs_stream_t stream) {
   if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 24");
   LabelPropArgs a;
   a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;
+  a.pval = (float*)workspace;
+  a.pidx = workspace ? (int*)((float*)workspace + (size_t)LP_MAX_SPLIT * H * W * 10) : nullptr;
   for (int i = 0; i < LP_MAX_KEYS; ++i) a.kslot[i] = i < nkeys ? kslot[i] : 0;   // kslot is a HOST array
   a.H = H; a.W = W; a.C = C; a.CO = CO; a.radius = radius; a.topk = topk; a.inv_temp = 1.0f / temperature;
   return vfs_labelprop_launch(a, S(stream));

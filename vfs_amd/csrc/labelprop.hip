@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256) void labelprop_kernel(LabelPropArgs a) {
 #pragma unroll
   for (int i = 0; i < LP_TOPK; ++i) { tv[i] = -INFINITY; ti[i] = -1; }
 
-  for (int f = 0; f < a.nkeys; ++f) {
+  // key frames are split over blockIdx.y (a DAVIS frame has only 8x14 query tiles: one workgroup
+  // per tile would leave most of the 256 CUs idle); every split emits a partial top-k per query
+  const int fpb = (a.nkeys + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * fpb, f_end = min(a.nkeys, f_begin + fpb);
+  for (int f = f_begin; f < f_end; ++f) {
     const int slot = a.kslot[f];
     for (int kb = 0; kb < nkb; ++kb) {
       // key rows of this block
@@ -188,36 +192,58 @@ __global__ __launch_bounds__(256) void labelprop_kernel(LabelPropArgs a) {
     if (y < H && x < W) {
       float* cv = mv + t * 4 * LP_TOPK;
       int* ci = mi + t * 4 * LP_TOPK;
-      float bv[LP_TOPK];
-      int bi[LP_TOPK];
-      const int K = a.topk < LP_TOPK ? a.topk : LP_TOPK;
-      for (int k = 0; k < K; ++k) {
+      // top-k of this split's 4 x 10 candidates -> partial list [split][query][LP_TOPK]
+      float* pv = a.pval + ((size_t)blockIdx.y * HW + (y * W + x)) * LP_TOPK;
+      int* pi = a.pidx + ((size_t)blockIdx.y * HW + (y * W + x)) * LP_TOPK;
+      for (int k = 0; k < LP_TOPK; ++k) {
         int best = 0;
         float bvv = cv[0];
         for (int c = 1; c < 4 * LP_TOPK; ++c)
           if (cv[c] > bvv) { bvv = cv[c]; best = c; }
-        bv[k] = bvv; bi[k] = ci[best];
+        pv[k] = bvv; pi[k] = ci[best];
         cv[best] = -INFINITY;
       }
-      const float m = bv[0];
-      float wgt[LP_TOPK], z = 0.f;
-      for (int k = 0; k < K; ++k) {
-        wgt[k] = (bi[k] >= 0 && bv[k] > -INFINITY) ? expf(bv[k] - m) : 0.f;
-        z += wgt[k];
-      }
-      const float iz = 1.0f / z;
-      float* o = a.out + (size_t)(y * W + x) * a.CO;
-      for (int c = 0; c < a.CO; ++c) {
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) {
-          if (wgt[k] > 0.f) {
-            const int fr = bi[k] / HW, px = bi[k] - fr * HW;
-            s += (wgt[k] * iz) * a.sbank[((size_t)a.kslot[fr] * HW + px) * a.CO + c];
-          }
-        }
-        o[c] = s;
+    }
+  }
+}
+
+// merge the per-split partial lists, softmax over the top-k, weighted sum of the value logits
+__global__ __launch_bounds__(256) void labelprop_merge_kernel(LabelPropArgs a, int nsplit) {
+  const int HW = a.H * a.W;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= HW) return;
+  const int K = a.topk < LP_TOPK ? a.topk : LP_TOPK;
+  float bv[LP_TOPK];
+  int bi[LP_TOPK];
+#pragma unroll
+  for (int k = 0; k < LP_TOPK; ++k) { bv[k] = -INFINITY; bi[k] = -1; }
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float* pv = a.pval + ((size_t)sp * HW + q) * LP_TOPK;
+    const int* pi = a.pidx + ((size_t)sp * HW + q) * LP_TOPK;
+    for (int c = 0; c < LP_TOPK; ++c) {
+      const float v = pv[c];
+      if (v > bv[LP_TOPK - 1]) topk_insert(bv, bi, v, pi[c]);
+    }
+  }
+  const float m = bv[0];
+  float wgt[LP_TOPK], z = 0.f;
+#pragma unroll
+  for (int k = 0; k < LP_TOPK; ++k) {
+    wgt[k] = (k < K && bi[k] >= 0 && bv[k] > -INFINITY) ? expf(bv[k] - m) : 0.f;
+    z += wgt[k];
+  }
+  const float iz = 1.0f / z;
+  float* o = a.out + (size_t)q * a.CO;
+  for (int c = 0; c < a.CO; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LP_TOPK; ++k) {
+      if (wgt[k] > 0.f) {
+        const int fr = bi[k] / HW, px = bi[k] - fr * HW;
+        s += (wgt[k] * iz) * a.sbank[((size_t)a.kslot[fr] * HW + px) * a.CO + c];
       }
     }
+    o[c] = s;
   }
 }
 
@@ -227,8 +253,17 @@ int vfs_labelprop_launch(const LabelPropArgs& a, hipStream_t s) {
   if (a.topk < 1 || a.topk > LP_TOPK) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= topk <= 10");
   if (a.H >= 65536 || a.W >= 65536) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: H,W < 65536");
   const int tiles = ((a.H + 7) / 8) * ((a.W + 7) / 8);
-  hipLaunchKernelGGL(labelprop_kernel, dim3(tiles), dim3(256), 0, s, a);
-  return vfs_check_launch("labelprop");
+  if (a.pval == nullptr || a.pidx == nullptr) return vfs_set_error(VFS_ERR_ARG, "labelprop: partial workspace missing");
+  int nsplit = (768 + tiles - 1) / tiles;                 // ~3 workgroups per CU
+  if (nsplit > a.nkeys) nsplit = a.nkeys;
+  if (nsplit > LP_MAX_SPLIT) nsplit = LP_MAX_SPLIT;
+  const int fpb = (a.nkeys + nsplit - 1) / nsplit;
+  nsplit = (a.nkeys + fpb - 1) / fpb;
+  hipLaunchKernelGGL(labelprop_kernel, dim3(tiles, nsplit), dim3(256), 0, s, a);
+  int rc = vfs_check_launch("labelprop");
+  if (rc) return rc;
+  hipLaunchKernelGGL(labelprop_merge_kernel, dim3((a.H * a.W + 255) / 256), dim3(256), 0, s, a, nsplit);
+  return vfs_check_launch("labelprop_merge");
 }
 
 // ---------------------------------------------------------------------------------------------

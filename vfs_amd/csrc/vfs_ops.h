@@ -129,10 +129,13 @@ int vfs_scale_launch(float* p, long long n, float scale, hipStream_t s);
 #define LP_MAX_KEYS 24
 #define LP_MAX_CLASSES 256
 #define LP_POST_BLOCKS 64
+#define LP_MAX_SPLIT 24
 struct LabelPropArgs {
   const bf16_t* fbank;  // [frames][H*W][C] L2-normalised bf16 features (the clip's feature bank)
   const float* sbank;   // [frames][H*W][CO] fp32 value logits (frame 0 = one-hot labels)
   float* out;           // [H*W][CO] propagated logits of the query frame
+  float* pval;          // workspace [LP_MAX_SPLIT][H*W][10] partial top-k values ...
+  int* pidx;            // ... and key ids
   int qframe;           // bank index of the query frame
   int nkeys;            // number of key frames, in the reference's order (first frame first)
   int kslot[LP_MAX_KEYS];

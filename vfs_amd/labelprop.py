@@ -77,6 +77,7 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
     preds = torch.empty(clip_len, out_h, out_w, dtype=torch.uint8, device=dev)
     preds[0] = torch.from_numpy(np.ascontiguousarray(torch_nearest_resize(ref, out_h, out_w))).to(dev)
     partial = eng.ws('ws.segpost', 64 * CO * 2, torch.float32, dev)
+    lpws = eng.ws('ws.labelprop', 24 * h * w * 10 * 2, torch.float32, dev)
 
     nr = tc.get('neighbor_range', None)
     radius = int(nr) // 2 if nr is not None else 0
@@ -92,6 +93,6 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
         if tc.get('with_first', True):
             slots = [0] + slots                                 # frame 0 twice while f <= precede (as the reference)
         ks = (ctypes.c_int * len(slots))(*slots)
-        eng.lib.labelprop(bank, sbank, sbank[f], f, ks, len(slots), h, w, C, CO, radius, topk, temp, s)
+        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, topk, temp, s)
         eng.lib.seg_postprocess(sbank[f], partial, preds[f], h, w, CO, out_h, out_w, s)
     return [preds.cpu().numpy()]
