@@ -205,3 +205,38 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape):
     pooled, _ = two_views(stem, O.round_bf16(frames), g_in)
     assert _maxrel(_nchw(ctx['bctx']['pooled']), pooled) < 1.2e-2
     check_param_grads('backbone.conv1', ref.backbone.conv1)
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager(gpu_backend, monkeypatch):
+    """hipGraph replay of the captured forward / backward chains must reproduce the eager step
+    bit for bit (same kernels, same order, deterministic reductions)."""
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', 'vfs_r18.py'))
+    dev = gpu_backend.dev
+    shape = [8, 2, 3, 2, 64, 64]
+    batches = [O.fill_tensor(shape, seed=100 + i, scale=2.0).to(dev) for i in range(6)]
+
+    def run(graphs):
+        monkeypatch.setenv('VFS_GRAPHS', '1' if graphs else '0')
+        model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        model.load_state_dict(_filled(18).state_dict())
+        model.to(dev).train()
+        opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+        losses = []
+        for b in batches:
+            out = model.train_step(dict(imgs=b, label=torch.zeros(shape[0], 1)), opt)
+            opt.zero_grad()
+            out['loss'].backward()
+            opt.step()
+            losses.append(out['log_vars']['loss'])
+        torch.cuda.synchronize()
+        used = getattr(model, '_gs', None) is not None and model._gs.fwd is not None and model._gs.bwd is not None
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, used
+
+    l0, sd0, used0 = run(False)
+    l1, sd1, used1 = run(True)
+    assert not used0 and used1
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
