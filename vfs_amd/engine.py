@@ -43,6 +43,8 @@ class Engine:
         self._pack = None
         self._pack_key = None
         self.process_group = None
+        self._side = {}
+        self._side_dirty = False
         self.prof = None     # list collecting (kind, flops, start_event, end_event) when profiling
 
     # ------------------------------------------------------------------ plumbing
@@ -70,6 +72,8 @@ class Engine:
         """grow-only flat workspace"""
         t = self.bufs.get(key)
         if t is None or t.numel() < numel or t.dtype != dtype or t.device != dev:
+            if t is not None and dev.type == 'cuda':
+                torch.cuda.synchronize(dev)     # the old block may still be in use on the side stream
             t = torch.empty(int(numel), dtype=dtype, device=dev)
             self.bufs[key] = t
         return t
@@ -252,6 +256,28 @@ class Engine:
         self._bwd_sums(u, partial, G, nblk // G, C, dev)
         return float(npg * H * W * self.world)
 
+    # ------------------------------------------------------------------ side stream for weight gradients
+    def on_side_stream(self, dev):
+        """context: subsequent launches go to the side stream, ordered after everything already
+        enqueued on the current stream (no-op on the CPU / when VFS_SIDE_STREAM=0)"""
+        import contextlib
+        if dev.type != 'cuda' or os.environ.get('VFS_SIDE_STREAM', '1') != '1':
+            return contextlib.nullcontext()
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self._side_dirty = True
+        return torch.cuda.stream(side)
+
+    def wgrad_join(self, dev):
+        """the current stream waits for every weight-gradient kernel issued so far"""
+        if dev.type == 'cuda' and getattr(self, '_side_dirty', False):
+            side = self._side.get(dev)
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+            self._side_dirty = False
+
     def stem_wgrad_fused(self, u, x4, Hin, Win, gp, yp, idx, raw, N, H, W, Hp, Wp, G, count):
         """stem weight gradient; the BN-backward apply pass is folded into its operand load"""
         dev = raw.device
@@ -259,9 +285,10 @@ class Engine:
         tpb = (ntiles + 1535) // 1536        # ~6 workgroups per CU: the operand gather is latency-bound
         nblocks = (ntiles + tpb - 1) // tpb
         partial = self.ws('ws.wgrad', nblocks * 64 * 224, torch.float32, dev)
-        self.timed('conv_wgrad', 2.0 * N * H * W * 64 * 147, dev, self.lib.stem_wgrad_fused,
-                   x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
-                   N // G, count, nblocks, self.stream(dev))
+        with self.on_side_stream(dev):      # ws.wgrad belongs to the side stream
+            self.timed('conv_wgrad', 2.0 * N * H * W * 64 * 147, dev, self.lib.stem_wgrad_fused,
+                       x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
+                       N // G, count, nblocks, self.stream(dev))
 
     def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None):
         """weight (and bias) gradients accumulate into .grad; returns the input gradient or None."""
@@ -272,18 +299,23 @@ class Engine:
         if u.kind == 'stem':
             nsplit, pps = wgrad_splits(M, 64, 256)
             partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)
-            self.timed('conv_wgrad', 2.0 * M * 64 * 147, dev, lib.stem_wgrad,
-                       dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, s)
+            with self.on_side_stream(dev):
+                self.timed('conv_wgrad', 2.0 * M * 64 * 147, dev, lib.stem_wgrad,
+                           dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, self.stream(dev))
             return None
         ktot = u.k * u.k * u.cin
         halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
         partial = self.ws('ws.wgrad', nsplit * u.cout * ktot, torch.float32, dev)
         flops = 2.0 * M * u.cout * ktot
-        self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho, Wo,
-                   u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, s)
-        if u.bias is not None:
-            lib.bias_grad(dx, u.bias.grad, M, u.cout, s)
+        # the weight gradient only feeds the optimizer: it runs on the side stream, concurrently
+        # with the dgrad / BatchNorm-backward kernels of the critical path (joined by wgrad_join)
+        with self.on_side_stream(dev):
+            ss = self.stream(dev)
+            self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
+                       Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+            if u.bias is not None:
+                lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)
         if not need_dgrad:
             return None
         gin = g_out if g_out is not None else self.buf(f'{u.name}.gin', (N, H, W, u.cin), BF16, dev)

@@ -278,11 +278,16 @@ class SimSiamBaseTracker(BaseTracker):
         eng.lib.cosine_loss_bwd(p[:Nv], z[:Nv], p[Nv:], z[Nv:], gl, dp[:Nv], dp[Nv:], Nv, p.shape[1], c['T'],
                                 c['K'], c['neg'], c['weight'], s)
         gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
+        if eng.collectives_on:
+            eng.wgrad_join(dev)
         works = self._allreduce_range(self._head_range(), async_op=True)
 
         def stage_done(module):      # gradients of `module` are final: reduce them while earlier stages run
-            works.extend(self._allreduce_range(self._param_range(module), async_op=True))
+            if eng.collectives_on:
+                eng.wgrad_join(dev)
+                works.extend(self._allreduce_range(self._param_range(module), async_op=True))
         self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat}, on_stage_done=stage_done)
+        eng.wgrad_join(dev)
         for wk in works:
             wk.wait()
         self._ctx = None
