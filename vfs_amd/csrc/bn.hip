@@ -160,52 +160,110 @@ __device__ __forceinline__ void ld8f(const float* p, float* f) {
 }
 
 
-__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
-  const int cv = a.C >> 3;
-  const long long total = a.M * cv;
-  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
-    const long long m = v / cv;
-    const int c = (int)(v - m * cv) * 8;
-    const int gi = (int)(m / a.mpg);
-    const size_t o = (size_t)m * a.C + c;
-    float x[8], sc[8], sh[8];
-    unpack8(ld16(a.x + o), x);
-    ld8f(a.bnp + (size_t)gi * 4 * a.C + c, sc);
-    ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
+// Streaming geometry shared by the elementwise BatchNorm kernels: a workgroup owns `ppb` pixels of ONE
+// statistics group x one slab of <= 64 channels (blockIdx.y); thread = (pixel lane rt, 8-channel chunk
+// ct).  The per-channel coefficients stay in registers for the whole block and four pixel rows
+// (8-12 independent 16-byte loads per lane) are in flight per trip; no per-element index division.
+struct SlabGeom {
+  int cv, rows, rt, c, gi;
+  long long m0, mend;
+};
+__device__ __forceinline__ SlabGeom slab_geom(long long M, int C, int mpg, int ppb) {
+  SlabGeom s;
+  const int cslab = C < 64 ? C : 64;
+  s.cv = cslab >> 3;
+  s.rows = 256 / s.cv;
+  const int t = threadIdx.x;
+  s.rt = t / s.cv;
+  s.c = blockIdx.y * cslab + (t - s.rt * s.cv) * 8;
+  const int bpg = (mpg + ppb - 1) / ppb;
+  s.gi = blockIdx.x / bpg;
+  s.m0 = (long long)s.gi * mpg + (long long)(blockIdx.x - s.gi * bpg) * ppb;
+  long long e = s.m0 + ppb;
+  const long long ge = (long long)(s.gi + 1) * mpg;
+  if (e > ge) e = ge;
+  if (e > M) e = M;
+  s.mend = e;
+  return s;
+}
+// host side: pixels per block (a multiple of the 4-row trip) for ~4096 workgroups, and the grid
+static inline dim3 slab_grid(long long M, int C, int mpg, int* ppb_out) {
+  const int cslab = C < 64 ? C : 64, rows = 256 / (cslab >> 3), unit = 4 * rows;
+  const int slabs = C < 64 ? 1 : C / 64;
+  long long per = (M * slabs + 4095) / 4096;
+  long long ppb = ((per + unit - 1) / unit) * unit;
+  if (ppb < unit) ppb = unit;
+  const int bpg = (int)((mpg + ppb - 1) / ppb);
+  const int G = (int)((M + mpg - 1) / mpg);
+  *ppb_out = (int)ppb;
+  return dim3(G * bpg, slabs);
+}
+static inline bool slab_ok(int C) { return C % 8 == 0 && (C < 64 ? 256 % (C >> 3) == 0 : C % 64 == 0); }
+
+__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int ppb) {
+  const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb);
+  if (s.rt >= s.rows) return;
+  float sc[8], sh[8], rsc[8], rsh[8];
+  const float* bp = a.bnp + (size_t)s.gi * 4 * a.C + s.c;
+  ld8f(bp, sc);
+  ld8f(bp + a.C, sh);
+  if (a.rres) {
+    const float* rp = a.rbnp + (size_t)s.gi * 4 * a.C + s.c;
+    ld8f(rp, rsc);
+    ld8f(rp + a.C, rsh);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = x[i] * sc[i] + sh[i];
-    if (a.res) {
-      float r[8];
-      unpack8(ld16(a.res + o), r);
+    for (int i = 0; i < 8; ++i) sh[i] += rsh[i];
+  }
+  for (long long r = s.m0 + s.rt; r < s.mend; r += 4 * s.rows) {
+    u32x4 xv[4], rv[4], qv[4];
+    bool ok[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] += r[i];
+    for (int u = 0; u < 4; ++u) {
+      const long long m = r + (long long)u * s.rows;
+      ok[u] = m < s.mend;
+      const size_t o = (size_t)(ok[u] ? m : s.m0) * a.C + s.c;
+      xv[u] = ld16(a.x + o);
+      if (a.res) rv[u] = ld16(a.res + o);
+      if (a.rres) qv[u] = ld16(a.rres + o);
     }
-    if (a.rres) {
-      float r[8];
-      unpack8(ld16(a.rres + o), r);
-      ld8f(a.rbnp + (size_t)gi * 4 * a.C + c, sc);
-      ld8f(a.rbnp + (size_t)gi * 4 * a.C + a.C + c, sh);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] += r[i] * sc[i] + sh[i];
-    }
-    if (a.relu) {
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      float x[8];
+      unpack8(xv[u], x);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = fmaxf(x[i], 0.f);
+      for (int i = 0; i < 8; ++i) x[i] = x[i] * sc[i] + sh[i];
+      if (a.res) {
+        float q[8];
+        unpack8(rv[u], q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] += q[i];
+      }
+      if (a.rres) {
+        float q[8];
+        unpack8(qv[u], q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] += q[i] * rsc[i];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = fmaxf(x[i], 0.f);
+      }
+      st16(a.y + (size_t)(r + (long long)u * s.rows) * a.C + s.c, pack8(x));
     }
-    st16(a.y + o, pack8(x));
   }
 }
 
 
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
-  const int cv = a.C >> 3;
-  const long long total = (long long)a.N * a.Hp * a.Wp * cv;
-  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
-    long long p = v / cv;
+  const unsigned cv = a.C >> 3;
+  const unsigned total = (unsigned)a.N * a.Hp * a.Wp * cv;   // < 2^31 (checked by the launcher): 32-bit index math
+  for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < total; v += gridDim.x * 256u) {
+    unsigned p = v / cv;
     const int c = (int)(v - p * cv) * 8;
-    const int wp = (int)(p % a.Wp); p /= a.Wp;
-    const int hp = (int)(p % a.Hp);
-    const int n = (int)(p / a.Hp);
+    const int wp = (int)(p % (unsigned)a.Wp); p /= (unsigned)a.Wp;
+    const int hp = (int)(p % (unsigned)a.Hp);
+    const int n = (int)(p / (unsigned)a.Hp);
     const int gi = n / a.npg;
     float sc[8], sh[8], best[8];
     int bi[8];
@@ -348,52 +406,61 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   }
 }
 
-// pass 2: dx = scale * (gm - S1/count - xhat * S2/count)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
-  const int cv = a.C >> 3;
-  const long long total = a.M * cv;
-  const float rc = (float)(1.0 / a.count);
-  // per-channel means of (gm, gm*xhat) as fp32 in LDS: [G][2][C] (G*C <= 4096 floats)
-  __shared__ float coef[2 * 4096];
-  const int GC = (int)((a.M + a.mpg - 1) / a.mpg) * a.C;
-  for (int i = threadIdx.x; i < 2 * GC; i += 256) {
-    const int gi = i / (2 * a.C), rem = i - gi * 2 * a.C;
-    coef[i] = (float)a.sums[(size_t)gi * 2 * a.C + rem] * rc;
-  }
-  __syncthreads();
-  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
-    const long long m = v / cv;
-    const int c = (int)(v - m * cv) * 8;
-    const int gi = (int)(m / a.mpg);
-    const size_t o = (size_t)m * a.C + c;
-    float g[8], x[8], sc[8], mean[8], inv[8];
-    unpack8(ld16(a.g + o), g);
-    unpack8(ld16(a.x + o), x);
-    const float* bp = a.bnp + (size_t)gi * 4 * a.C;
-    ld8f(bp + c, sc);
-    ld8f(bp + 2 * a.C + c, mean);
-    ld8f(bp + 3 * a.C + c, inv);
-    if (a.y) {
-      float y[8];
-      unpack8(ld16(a.y + o), y);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
-    } else if (a.relu) {
-      float sh[8];
-      ld8f(bp + a.C + c, sh);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] = (x[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
-    }
-    float d[8];
+// pass 2: dx = scale * (gm - S1/count - xhat * S2/count) = A*gm + B*x + D with per-channel
+// A = scale, B = -scale*invstd*m2, D = scale*(mean*invstd*m2 - m1) held in registers
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int ppb) {
+  const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb);
+  if (s.rt >= s.rows) return;
+  float A[8], B[8], D[8], sh[8];
+  {
+    float mean[8], inv[8];
+    const float* bp = a.bnp + (size_t)s.gi * 4 * a.C + s.c;
+    ld8f(bp, A);
+    ld8f(bp + a.C, sh);
+    ld8f(bp + 2 * a.C, mean);
+    ld8f(bp + 3 * a.C, inv);
+    const float rc = (float)(1.0 / a.count);
+    const double* sp = a.sums + (size_t)s.gi * 2 * a.C + s.c;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float m1 = coef[(gi * 2) * a.C + c + i];
-      const float m2 = coef[(gi * 2 + 1) * a.C + c + i];
-      const float xh = (x[i] - mean[i]) * inv[i];
-      d[i] = sc[i] * (g[i] - m1 - xh * m2);
+      const float m1 = (float)sp[i] * rc, m2 = (float)sp[a.C + i] * rc;
+      B[i] = -A[i] * inv[i] * m2;
+      D[i] = A[i] * (mean[i] * inv[i] * m2 - m1);
     }
-    st16(a.dx + o, pack8(d));
-    if (a.gm) st16(a.gm + o, pack8(g));
+  }
+  for (long long r = s.m0 + s.rt; r < s.mend; r += 4 * s.rows) {
+    u32x4 gv[4], xv[4], yv[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long m = r + (long long)u * s.rows;
+      ok[u] = m < s.mend;
+      const size_t o = (size_t)(ok[u] ? m : s.m0) * a.C + s.c;
+      gv[u] = ld16(a.g + o);
+      xv[u] = ld16(a.x + o);
+      if (a.y) yv[u] = ld16(a.y + o);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      float g[8], x[8], d[8];
+      unpack8(gv[u], g);
+      unpack8(xv[u], x);
+      if (a.y) {
+        float y[8];
+        unpack8(yv[u], y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+      } else if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = (x[i] * A[i] + sh[i] > 0.f) ? g[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = A[i] * g[i] + (B[i] * x[i] + D[i]);
+      const size_t o = (size_t)(r + (long long)u * s.rows) * a.C + s.c;
+      st16(a.dx + o, pack8(d));
+      if (a.gm) st16(a.gm + o, pack8(g));
+    }
   }
 }
 
@@ -561,12 +628,16 @@ int vfs_bn_eval_params_launch(const float* gamma, const float* beta, const float
   return vfs_check_launch("bn_eval_params");
 }
 int vfs_bn_act_launch(const BnActArgs& a, hipStream_t s) {
-  if (a.C % 8) return vfs_set_error(VFS_ERR_SHAPE, "bn_act: C%8");
-  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(a.M * (a.C >> 3))), dim3(256), 0, s, a);
+  if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_act: C must be 8*2^k below 64, a multiple of 64 above");
+  if (a.M <= 0) return VFS_OK;
+  int ppb;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
+  hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, s, a, ppb);
   return vfs_check_launch("bn_act");
 }
 int vfs_bn_relu_maxpool_launch(const BnPoolArgs& a, hipStream_t s) {
   if (a.C % 8) return vfs_set_error(VFS_ERR_SHAPE, "bn_relu_maxpool: C%8");
+  if ((long long)a.N * a.Hp * a.Wp * (a.C >> 3) >= (1ll << 31)) return vfs_set_error(VFS_ERR_SHAPE, "bn_relu_maxpool: too many elements");
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for((long long)a.N * a.Hp * a.Wp * (a.C >> 3))), dim3(256), 0, s, a);
   return vfs_check_launch("bn_relu_maxpool");
 }
@@ -581,8 +652,11 @@ int vfs_bn_bwd_reduce_launch(const BnBwdArgs& a, int nblk, hipStream_t s) {
   return vfs_check_launch("bn_bwd_reduce");
 }
 int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
-  if (((a.M + a.mpg - 1) / a.mpg) * a.C > 4096) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply: groups*C > 4096");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.M * (a.C >> 3))), dim3(256), 0, s, a);
+  if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply: C must be 8*2^k below 64, a multiple of 64 above");
+  if (a.M <= 0) return VFS_OK;
+  int ppb;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, a, ppb);
   return vfs_check_launch("bn_bwd_apply");
 }
 int vfs_bn_param_grad_launch(const double* sums, float* dgamma, float* dbeta, int G, int C, hipStream_t s) {

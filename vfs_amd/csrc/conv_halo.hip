@@ -13,24 +13,48 @@
 // as conv_igemm.hip.
 #include "vfs_conv.h"
 
-#define OOB_OFFSET 0xFFFFFFF0u
+// any offset >= num_records reads as zero; 2^31 leaves room for a scalar offset on top without wrapping
+#define OOB_OFFSET 0x80000000u
+
+// LDS rows are 64 bf16 + 16 pad = 160 bytes (32 B x odd): the ds_read_b128 fragment reads of 16
+// consecutive rows are bank-conflict free on gfx950 and, being linear, every tap / k-step / MFMA
+// tile is an IMMEDIATE offset from one per-lane base register (no address VALU in the main loop).
+#define HALO_RS 80
+
+// lane column lr of 16-pixel group tn of half wp -> pixel of the spatial tile.  For the 8-wide tile a
+// group is two 8-pixel rows, 10 patch rows apart; the second row is permuted so that the patch rows of
+// each ds_read_b128 lane group stay distinct mod 8 (conflict free).
+template <bool SMALLW>
+__device__ __forceinline__ void halo_pixel(int wp, int tn, int lr, int& ti, int& py, int& px) {
+  if (SMALLW) {
+    const int c = lr & 7;
+    ti = wp;
+    py = tn * 2 + (lr >> 3);
+    px = lr < 8 ? c : (c < 2 ? c : (c < 4 ? c + 4 : c - 2));
+  } else {
+    ti = 0;
+    py = wp * 4 + tn;
+    px = lr;
+  }
+}
 
 template <int BC, bool DGRAD, bool SMALLW>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   constexpr int TW = SMALLW ? 8 : 16, TH = 8, TI = SMALLW ? 2 : 1;
   constexpr int PW = TW + 2, PH = TH + 2;
   constexpr int PROWS = TI * PH * PW;            // 180 or 200 patch rows of 64 channels
   constexpr int PLD = (PROWS * 8 + 255) / 256;   // 16-byte patch loads per thread (6 or 7)
   constexpr int WC = BC / 2, TM = WC / 16, TN = 4, WLD = BC / 32;
-  __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * 64];
-  __shared__ __attribute__((aligned(16))) bf16_t sW[2][BC * 64];
+  constexpr int RS = HALO_RS;
+  __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * RS];
+  __shared__ __attribute__((aligned(16))) bf16_t sW[2 * BC * RS];
   __shared__ float sRed[2][BC][2];
 
   const ConvGeom g = a.g;                        // FWD: H,W,C = input; DGRAD: H,W,C = dY (same H,W)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wc = wave >> 1, wp = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
-  const int ncb = (a.Cout + BC - 1) / BC;
+  const int ncb = a.Cout / BC;
   const int tile = blockIdx.x / ncb, cb = blockIdx.x - tile * ncb;
   const int c0 = cb * BC;
   const int tiles_x = g.W / TW, tiles_y = g.H / TH;
@@ -54,12 +78,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
     }
     poff[k] = off;
   }
-  unsigned wbase[WLD];
-#pragma unroll
-  for (int i = 0; i < WLD; ++i) {
-    const int c = c0 + row0 + 32 * i;
-    wbase[i] = c < a.Cout ? (unsigned)(((size_t)c * g.Ktot + j * 8) * 2) : OOB_OFFSET;
-  }
+  // weight rows c0 + row0 + 32 i, chunk j (Cout % BC == 0: never out of range)
+  const unsigned wbase = (unsigned)(((size_t)(c0 + row0) * g.Ktot + j * 8) * 2);
+  const unsigned wrow32 = (unsigned)(32 * g.Ktot * 2);
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -68,41 +89,34 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
   u32x4 pr_[PLD], wr[WLD];
   auto load_patch = [&](int cc) {
 #pragma unroll
-    for (int k = 0; k < PLD; ++k) {
-      const unsigned off = poff[k] == OOB_OFFSET ? OOB_OFFSET : poff[k] + (unsigned)(cc * 128);
-      pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
-    }
+    for (int k = 0; k < PLD; ++k) pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[k], cc * 128, 0);
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int k = 0; k < PLD; ++k) {
       const int pr = row0 + 32 * k;
-      if (pr < PROWS) st16(&sP[lds_off(pr, j)], pr_[k]);
+      if (pr < PROWS) st16(&sP[pr * RS + j * 8], pr_[k]);
     }
   };
   auto load_w = [&](int cc, int tap) {
-    const unsigned wcol = (unsigned)((tap * g.C + cc * 64) * 2);
+    const int wcol = (tap * g.C + cc * 64) * 2;
 #pragma unroll
-    for (int i = 0; i < WLD; ++i) {
-      const unsigned off = wbase[i] == OOB_OFFSET ? OOB_OFFSET : wbase[i] + wcol;
-      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0);
-    }
+    for (int i = 0; i < WLD; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wbase + i * wrow32, wcol, 0);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < WLD; ++i) st16(&sW[buf][lds_off(row0 + 32 * i, j)], wr[i]);
+    for (int i = 0; i < WLD; ++i) st16(&sW[buf * (BC * RS) + (row0 + 32 * i) * RS + j * 8], wr[i]);
   };
 
-  // ---- this lane's four B-fragment pixels (one per 16-pixel tile): patch row of tap (0,0)
-  int prow[TN];
+  // ---- per-lane fragment bases: everything else in the main loop is an immediate offset
+  int pbase[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int p = wp * 64 + tn * 16 + lr;
     int ti, py, px;
-    if (SMALLW) { ti = p >> 6; py = (p >> 3) & 7; px = p & 7; }
-    else { ti = 0; py = p >> 4; px = p & 15; }
-    prow[tn] = ti * (PH * PW) + py * PW + px;
+    halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
+    pbase[tn] = (ti * (PH * PW) + py * PW + px) * RS + lq * 8;
   }
+  const int abase = (wc * WC + lr) * RS + lq * 8;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -119,23 +133,24 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
   for (int cc = 0; cc < nchunk; ++cc) {
     const bool more_chunks = cc + 1 < nchunk;
     if (more_chunks) load_patch(cc + 1);          // in flight during the nine taps of this chunk
-#pragma unroll 1
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const bool last_tap = tap == 8;
       const bool more = !last_tap || more_chunks;
       if (more) load_w(last_tap ? cc + 1 : cc, last_tap ? 0 : tap + 1);
       const int r = tap / 3, s = tap - 3 * r;
       const int shift = DGRAD ? (2 - r) * PW + (2 - s) : r * PW + s;
+      const bf16_t* wsrc = sW + wbuf * (BC * RS) + abase;
       // one 64-deep K-step: A = weights (rows wc*WC..), B = patch rows shifted by the tap
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[TM], bfr[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-          af[tm] = *reinterpret_cast<const bf16x8*>(&sW[wbuf][lds_off(wc * WC + tm * 16 + lr, kk * 4 + lq)]);
+          af[tm] = *reinterpret_cast<const bf16x8*>(wsrc + tm * 16 * RS + kk * 32);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-          bfr[tn] = *reinterpret_cast<const bf16x8*>(&sP[lds_off(prow[tn] + shift, kk * 4 + lq)]);
+          bfr[tn] = *reinterpret_cast<const bf16x8*>(&sP[pbase[tn] + shift * RS + kk * 32]);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -161,17 +176,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
     for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int p = wp * 64 + tn * 16 + lr;
     int ti, py, px;
-    if (SMALLW) { ti = p >> 6; py = (p >> 3) & 7; px = p & 7; }
-    else { ti = 0; py = p >> 4; px = p & 15; }
+    halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
     const int n = tn0 + ti;
     const bool mok = n < g.N;
     const size_t mdst = ((size_t)n * g.H + (y0 + py)) * g.W + (x0 + px);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int c = c0 + wc * WC + tm * 16 + lq * 4;
-      if (mok && c < a.Cout) {
+      if (mok) {
         float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
         if (a.bias) {
 #pragma unroll
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
         }
       }
     __syncthreads();
-    if (t < BC && c0 + t < a.Cout) {
+    if (t < BC) {
       float* dst = a.stats + (size_t)tile * 2 * a.Cout;   // one partial per spatial tile (128 pixels)
       dst[c0 + t] = sRed[0][t][0] + sRed[1][t][0];
       dst[a.Cout + c0 + t] = sRed[0][t][1] + sRed[1][t][1];
@@ -226,7 +239,7 @@ template <int BC, bool DGRAD, bool SMALLW>
 static int launch_halo(const ConvArgs& a, hipStream_t stream) {
   const int TW = SMALLW ? 8 : 16, TI = SMALLW ? 2 : 1;
   const int tiles = ((a.g.N + TI - 1) / TI) * (a.g.H / 8) * (a.g.W / TW);
-  const int ncb = (a.Cout + BC - 1) / BC;
+  const int ncb = a.Cout / BC;
   hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   return vfs_check_launch("conv3x3_halo");
 }
@@ -237,6 +250,7 @@ bool vfs_conv_halo_eligible(const ConvArgs& a, int mode) {
   const ConvGeom& g = a.g;
   if (mode != GATHER_FWD && mode != GATHER_DGRAD) return false;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
+  if (a.Cout % 64 || g.C % 64) return false;
   if (g.H != g.Ho || g.W != g.Wo || g.H % 8) return false;
   if (g.W % 16 == 0) return true;
   return g.W == 8 && g.H == 8 && g.N % 2 == 0;

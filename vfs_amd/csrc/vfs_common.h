@@ -21,16 +21,16 @@ __device__ __forceinline__ float bflo(uint32_t packed) {  // low bf16 of a dword
 __device__ __forceinline__ float bfhi(uint32_t packed) {  // high bf16 of a dword
   return __builtin_bit_cast(float, packed & 0xffff0000u);
 }
-// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16: the compiler lowers the __bf16 vector conversion to ONE
+// v_cvt_pk_bf16_f32 per pair on gfx950 (tools/probe_cvt.hip: identical to the integer
+// "+0x7fff+lsb" rounding for all 2^32 non-NaN patterns; the emulator build converts in software)
+typedef __attribute__((ext_vector_type(2))) float vfs_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vfs_bf16x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const vfs_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vfs_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }

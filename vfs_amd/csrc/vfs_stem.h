@@ -4,23 +4,24 @@
 #include "vfs_ops.h"
 
 #define STEM_MAX_GROUPS 8
-#define STEM_TAB (5 * 64)   // per group: scale, mean, invstd, S1/count, S2/count for 64 channels
+#define STEM_TAB (3 * 64)   // per group: A, B, D of dx = A*ga + B*x + D (as bn_bwd_apply_kernel) for 64 channels
 
 // fill the per-group coefficient table (LDS) once per workgroup; caller syncs afterwards
 __device__ __forceinline__ void stem_fill_table(const StemBwdArgs& a, float* tab, float rc) {
   const int ngroups = (a.N + a.npg - 1) / a.npg;
-  for (int i = threadIdx.x; i < ngroups * STEM_TAB; i += blockDim.x) {
-    const int gi = i / STEM_TAB, rem = i - gi * STEM_TAB, k = rem >> 6, c = rem & 63;
-    float v;
-    if (k == 0) v = a.bnp[(size_t)gi * 4 * 64 + c];
-    else if (k == 1) v = a.bnp[(size_t)gi * 4 * 64 + 2 * 64 + c];
-    else if (k == 2) v = a.bnp[(size_t)gi * 4 * 64 + 3 * 64 + c];
-    else v = (float)a.sums[((size_t)gi * 2 + (k - 3)) * 64 + c] * rc;
-    tab[i] = v;
+  for (int i = threadIdx.x; i < ngroups * 64; i += blockDim.x) {
+    const int gi = i >> 6, c = i & 63;
+    const float* bp = a.bnp + (size_t)gi * 4 * 64 + c;
+    const float A = bp[0], mean = bp[2 * 64], inv = bp[3 * 64];
+    const float m1 = (float)a.sums[((size_t)gi * 2) * 64 + c] * rc, m2 = (float)a.sums[((size_t)gi * 2 + 1) * 64 + c] * rc;
+    float* tb = tab + gi * STEM_TAB + c;
+    tb[0] = A;
+    tb[64] = -A * inv * m2;
+    tb[128] = A * (mean * inv * m2 - m1);
   }
 }
 
-// d[8] = scale * (bf16(ga) - m1 - xhat*m2) for pixel (n,h,w), channels c..c+7 (C = 64).
+// d[8] = A*bf16(ga) + B*x + D  (= scale * (ga - m1 - xhat*m2)) for pixel (n,h,w), channels c..c+7 (C = 64).
 // ga = sum over the <=4 pooling windows whose argmax is (h,w) of gp*(yp>0); all window loads are
 // issued up front (clamped addresses + predicates) so ~13 independent loads are in flight.
 __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* tab, int n, int h, int w, int c, float* d) {
@@ -62,6 +63,6 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     // ga as a materialising path would have stored it (bf16), then the BN backward formula
-    d[i] = tb[i] * (round_bf(g[i]) - tb[3 * 64 + i] - ((x[i] - tb[64 + i]) * tb[2 * 64 + i]) * tb[4 * 64 + i]);
+    d[i] = tb[i] * round_bf(g[i]) + (tb[64 + i] * x[i] + tb[128 + i]);
   }
 }
