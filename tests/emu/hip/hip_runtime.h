@@ -328,6 +328,27 @@ inline int __ffsll(unsigned long long x) { return __builtin_ffsll(x); }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_readfirstlane(x) __shfl((x), 0)
+// v_mov_b32 with a DPP control (gfx9 encodings): quad_perm 0x00-0xFF, row_shl 0x101-0x10F,
+// row_shr 0x111-0x11F, row_ror 0x121-0x12F, row_mirror 0x140, row_half_mirror 0x141.
+// All lanes active, full row/bank masks (the only form the kernels use).
+namespace emu {
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  (void)row_mask; (void)bank_mask;
+  const int l = lane_id(), row = l & ~15, i = l & 15;
+  int from = -1;
+  if (ctrl >= 0 && ctrl <= 0xFF) from = row | (i & ~3) | ((ctrl >> (2 * (i & 3))) & 3);
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) from = (i + (ctrl & 15) < 16) ? row | (i + (ctrl & 15)) : -1;
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) from = (i - (ctrl & 15) >= 0) ? row | (i - (ctrl & 15)) : -1;
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) from = row | ((i - (ctrl & 15)) & 15);
+  else if (ctrl == 0x140) from = row | (15 - i);
+  else if (ctrl == 0x141) from = row | (i & 8) | (7 - (i & 7));
+  else { fprintf(stderr, "emu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+  const uint32_t got = shfl_u32((uint32_t)src, from < 0 ? l : from);
+  if (from < 0) return bound_ctrl ? 0 : old;
+  return (int)got;
+}
+}  // namespace emu
+#define __builtin_amdgcn_update_dpp emu::update_dpp
 
 // raw buffer descriptor + bounds-checked 16-byte load (out of range -> zeros, as the hardware)
 namespace emu {
@@ -371,6 +392,16 @@ inline v4s ds_read_tr16_b64(uintptr_t p) {
 #define __amdgpu_buffer_rsrc_t emu::rsrc_t
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128
+// LDS-DMA helpers of csrc/vfs_common.h (inline asm on the device): host versions.  Lane i's 16 bytes
+// land at lds_wave_base + 16*i; the transfer completes immediately (no asynchrony to emulate).
+#define VFS_EMU 1
+typedef emu::rsrc_t vfs_rsrc_words;
+inline vfs_rsrc_words vfs_make_rsrc_words(const void* p, unsigned bytes) { return emu::rsrc_t{(const char*)p, bytes}; }
+inline void vfs_dma16_async(vfs_rsrc_words rsrc, void* lds_wave_base, unsigned voffset, unsigned soffset) {
+  const emu::v4u v = emu::raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+  memcpy((char*)lds_wave_base + 16 * emu::lane_id(), &v, 16);
+}
+inline void vfs_dma_wait_all() {}
 
 template <typename T>
 inline T atomicAdd(T* p, T v) {

@@ -1,17 +1,22 @@
 // 3x3 / stride-1 / pad-1 convolution (forward and dgrad) with the input HALO TILE resident in LDS.
 //
 // The generic implicit-GEMM kernel (conv_igemm.hip) re-fetches a pixel's 128-byte channel chunk
-// once per tap: 9x the L1/L2 traffic and 9x the LDS stores of the activation operand, which on
-// MI355X leaves the 64..128-channel layers bound by the vector-memory / LDS-store path, not by
-// MFMA (measured 390-820 TFLOP/s).  Here one workgroup owns a SPATIAL tile of 128 output pixels
-// (8 rows x 16 columns of one image, or two whole 8x8 images), stages the (TH+2)x(TW+2) halo
-// patch of a 64-channel chunk ONCE, and the nine taps read it with shifted row indices:
+// once per tap: 9x the L1/L2 traffic and 9x the LDS stores of the activation operand.  Here one
+// workgroup owns a SPATIAL tile of output pixels, stages the (TH+2)x(TW+2) halo patch of a
+// 64-channel chunk ONCE, and the nine taps read it with shifted row indices:
 //     B-fragment row of tap (r,s), pixel (py,px)  =  patch[(py + r') * (TW+2) + px + s']
-// (r' = r forward, 2-r dgrad).  Per tap only the BC x 64 weight tile is fetched.  Same MFMA
-// tiling (v_mfma_f32_16x16x32_bf16, rows = channels, cols = pixels, wave = (BC/2) x 64), same
-// swizzled LDS rows and the same epilogue (bias / residual add / BatchNorm partial statistics)
-// as conv_igemm.hip.
+// (r' = r forward, 2-r dgrad).  Per tap only the BC x 64 weight tile is fetched.
+//
+// Tiling (v_mfma_f32_16x16x32_bf16, rows = channels, cols = pixels): every wave owns 64 channels x
+// 64 pixels (4x4 MFMA tiles, 0.5 KB of LDS fragment reads per MFMA - the main loop is bound by the
+// LDS pipe as much as by the matrix pipe, measured with per-phase s_memtime stamps).  The four waves
+// are arranged to cover all BC output channels of the block:
+//     BC = 128: 2 (channels) x 2 (pixels)  -> 8x16 pixel tile, or two whole 8x8 images
+//     BC =  64: 1 (channels) x 4 (pixels)  -> 16x16 pixel tile (less halo, weights amortised 2x)
+// Fragment reads are software-pipelined across the k-steps and across the per-tap barrier (the patch
+// does not change at a tap boundary), so a wave's LDS reads overlap its own and its neighbours' MFMAs.
 #include "vfs_conv.h"
+#include <type_traits>
 
 // any offset >= num_records reads as zero; 2^31 leaves room for a scalar offset on top without wrapping
 #define OOB_OFFSET 0x80000000u
@@ -21,9 +26,9 @@
 // tile is an IMMEDIATE offset from one per-lane base register (no address VALU in the main loop).
 #define HALO_RS 80
 
-// lane column lr of 16-pixel group tn of half wp -> pixel of the spatial tile.  For the 8-wide tile a
-// group is two 8-pixel rows, 10 patch rows apart; the second row is permuted so that the patch rows of
-// each ds_read_b128 lane group stay distinct mod 8 (conflict free).
+// lane column lr of 16-pixel group tn of pixel-wave wp -> pixel of the spatial tile.  For the 8-wide
+// tile a group is two 8-pixel rows, 10 patch rows apart; the second row is permuted so that the patch
+// rows of each ds_read_b128 lane group stay distinct mod 8 (conflict free).
 template <bool SMALLW>
 __device__ __forceinline__ void halo_pixel(int wp, int tn, int lr, int& ti, int& py, int& px) {
   if (SMALLW) {
@@ -40,19 +45,20 @@ __device__ __forceinline__ void halo_pixel(int wp, int tn, int lr, int& ti, int&
 
 template <int BC, bool DGRAD, bool SMALLW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
-  constexpr int TW = SMALLW ? 8 : 16, TH = 8, TI = SMALLW ? 2 : 1;
+  constexpr int WAVES_C = BC / 64, WAVES_P = 4 / WAVES_C;      // wave grid: channels x pixels
+  constexpr int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
   constexpr int PW = TW + 2, PH = TH + 2;
-  constexpr int PROWS = TI * PH * PW;            // 180 or 200 patch rows of 64 channels
-  constexpr int PLD = (PROWS * 8 + 255) / 256;   // 16-byte patch loads per thread (6 or 7)
-  constexpr int WC = BC / 2, TM = WC / 16, TN = 4, WLD = BC / 32;
+  constexpr int PROWS = TI * PH * PW;            // patch rows of 64 channels: 180 / 200 / 324
+  constexpr int PLD = (PROWS * 8 + 255) / 256;   // 16-byte patch loads per thread
+  constexpr int TM = 4, TN = 4;
   constexpr int RS = HALO_RS;
   __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * RS];
   __shared__ __attribute__((aligned(16))) bf16_t sW[2 * BC * RS];
-  __shared__ float sRed[2][BC][2];
+  __shared__ __attribute__((aligned(16))) float sRed[WAVES_P][2][BC];
 
   const ConvGeom g = a.g;                        // FWD: H,W,C = input; DGRAD: H,W,C = dY (same H,W)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wc = wave >> 1, wp = wave & 1;
+  const int wc = wave / WAVES_P, wp = wave - wc * WAVES_P;
   const int lr = lane & 15, lq = lane >> 4;
   const int ncb = a.Cout / BC;
   const int tile = blockIdx.x / ncb, cb = blockIdx.x - tile * ncb;
@@ -78,15 +84,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
     }
     poff[k] = off;
   }
-  // weight rows c0 + row0 + 32 i, chunk j (Cout % BC == 0: never out of range)
-  const unsigned wbase = (unsigned)(((size_t)(c0 + row0) * g.Ktot + j * 8) * 2);
-  const unsigned wrow32 = (unsigned)(32 * g.Ktot * 2);
+  // weights by LDS-DMA: the padded BC x 160-byte tile is NQ consecutive 1-KB pieces; wave w moves
+  // pieces w, w+4, ...; lane l of piece q fills bytes q*1024 + 16*l = (row, col) of the tile (lanes
+  // that land in the 32-byte row padding fetch column 0 - never read).  Cout % BC == 0: in range.
+  const vfs_rsrc_words wrs = vfs_make_rsrc_words(a.wgt, (unsigned)((size_t)a.Cout * g.Ktot * 2));
+  constexpr int NQ = BC * RS * 2 / 1024, WQ = (NQ + 3) / 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned wvoff[WQ];
+#pragma unroll
+  for (int i = 0; i < WQ; ++i) {
+    const int pos = (i * 4 + wave_u) * 1024 + lane * 16;
+    const int row = pos / (RS * 2), col = pos - row * (RS * 2);
+    wvoff[i] = (unsigned)(((size_t)(c0 + (row < BC ? row : 0)) * g.Ktot) * 2 + (col < 128 ? col : 0));
+  }
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.wgt, 0, (unsigned)((size_t)a.Cout * g.Ktot * 2), 0x00020000);
 
-  u32x4 pr_[PLD], wr[WLD];
+  u32x4 pr_[PLD];
   auto load_patch = [&](int cc) {
 #pragma unroll
     for (int k = 0; k < PLD; ++k) pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[k], cc * 128, 0);
@@ -98,14 +112,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
       if (pr < PROWS) st16(&sP[pr * RS + j * 8], pr_[k]);
     }
   };
-  auto load_w = [&](int cc, int tap) {
+  auto dma_w = [&](int cc, int tap, int buf) {
     const int wcol = (tap * g.C + cc * 64) * 2;
 #pragma unroll
-    for (int i = 0; i < WLD; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wbase + i * wrow32, wcol, 0);
-  };
-  auto store_w = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < WLD; ++i) st16(&sW[buf * (BC * RS) + (row0 + 32 * i) * RS + j * 8], wr[i]);
+    for (int i = 0; i < WQ; ++i) {
+      const int q = i * 4 + wave_u;
+      if (NQ % 4 == 0 || q < NQ) vfs_dma16_async(wrs, sW + buf * (BC * RS) + q * 512, wvoff[i], wcol);
+    }
   };
 
   // ---- per-lane fragment bases: everything else in the main loop is an immediate offset
@@ -116,91 +129,113 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
     halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
     pbase[tn] = (ti * (PH * PW) + py * PW + px) * RS + lq * 8;
   }
-  const int abase = (wc * WC + lr) * RS + lq * 8;
+  const int abase = (wc * 64 + lr) * RS + lq * 8;
+  auto tap_shift = [](int tap) {
+    const int r = tap / 3, s = tap - 3 * r;
+    return (DGRAD ? (2 - r) * PW + (2 - s) : r * PW + s) * RS;
+  };
+  auto read_b = [&](bf16x8* f, int tap, int kk) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) f[tn] = *reinterpret_cast<const bf16x8*>(&sP[pbase[tn] + tap_shift(tap) + kk * 32]);
+  };
+  auto read_a = [&](bf16x8* f, const bf16_t* wsrc, int kk) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) f[tm] = *reinterpret_cast<const bf16x8*>(wsrc + tm * 16 * RS + kk * 32);
+  };
 
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](const bf16x8* af, const bf16x8* bf) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+  };
 
   load_patch(0);
-  load_w(0, 0);
+  dma_w(0, 0, 0);
   store_patch();
-  store_w(0);
+  vfs_dma_wait_all();
   __syncthreads();
   int wbuf = 0;
+  bf16x8 b0[TN], b1[TN], a0[TM], a1[TM];
+  read_b(b0, 0, 0);
   for (int cc = 0; cc < nchunk; ++cc) {
     const bool more_chunks = cc + 1 < nchunk;
-    if (more_chunks) load_patch(cc + 1);          // in flight during the nine taps of this chunk
+    if (more_chunks) load_patch(cc + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const bool last_tap = tap == 8;
       const bool more = !last_tap || more_chunks;
-      if (more) load_w(last_tap ? cc + 1 : cc, last_tap ? 0 : tap + 1);
-      const int r = tap / 3, s = tap - 3 * r;
-      const int shift = DGRAD ? (2 - r) * PW + (2 - s) : r * PW + s;
+      // next tap's weights: DMA issued FIRST so that the L2 round trip hides under this tap's MFMAs
+      if (more) dma_w(last_tap ? cc + 1 : cc, last_tap ? 0 : tap + 1, wbuf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
       const bf16_t* wsrc = sW + wbuf * (BC * RS) + abase;
-      // one 64-deep K-step: A = weights (rows wc*WC..), B = patch rows shifted by the tap
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 af[TM], bfr[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          af[tm] = *reinterpret_cast<const bf16x8*>(wsrc + tm * 16 * RS + kk * 32);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          bfr[tn] = *reinterpret_cast<const bf16x8*>(&sP[pbase[tn] + shift * RS + kk * 32]);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
-      }
+      // k-step 0 operands: b0 was read before the barrier; k-step 1 operands are read now and
+      // consumed after the first MFMA block
+      read_a(a0, wsrc, 0);
+      read_a(a1, wsrc, 1);
+      read_b(b1, tap, 1);
+      mma(a0, b0);
+      if (!last_tap) read_b(b0, tap + 1, 0);      // next tap, same patch: in flight across the barrier
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
       if (last_tap && more_chunks) {
         __syncthreads();                           // every wave is done with this chunk's patch
         store_patch();
       }
-      if (more) store_w(wbuf ^ 1);
+      vfs_dma_wait_all();                          // this wave's pieces of the next weight tile landed
       __syncthreads();
+      if (last_tap && more_chunks) read_b(b0, 0, 0);
       wbuf ^= 1;
     }
   }
 
-  // ---------------- epilogue (as conv_igemm.hip) ----------------
-  const bool do_stats = a.stats != nullptr;
-  float s1[TM][4], s2[TM][4];
+  // ---------------- epilogue ----------------
+  // F = compile-time superset of {1: BatchNorm partial statistics, 2: residual add, 4: bias}: the three
+  // combinations the training step uses get branch-free bodies, anything else the runtime-checked one
+  auto epilogue = [&](auto FT) {
+    constexpr int F = decltype(FT)::value;
+    const bool do_stats = (F & 1) && a.stats != nullptr;
+    const bool do_add = (F & 2) && a.add != nullptr;
+    const bool do_bias = (F & 4) && a.bias != nullptr;
+    float s1[TM][4], s2[TM][4];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
+      for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    int ti, py, px;
-    halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
-    const int n = tn0 + ti;
-    const bool mok = n < g.N;
-    const size_t mdst = ((size_t)n * g.H + (y0 + py)) * g.W + (x0 + px);
+    for (int tn = 0; tn < TN; ++tn) {
+      int ti, py, px;
+      halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
+      const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
+      const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
+      u32x2 ad[TM];
+      if (do_add) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int c = c0 + wc * WC + tm * 16 + lq * 4;
-      if (mok) {
+        for (int tm = 0; tm < TM; ++tm) ad[tm] = ld8(a.add + obase + tm * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
         float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-        if (a.bias) {
+        if (do_bias) {
+          const int c = c0 + wc * 64 + tm * 16 + lq * 4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
         }
-        const size_t o = mdst * a.Cout + c;
-        if (a.add) {
-          u32x2 ad = ld8(a.add + o);
-          v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
+        if (do_add) {
+          v[0] += bflo(ad[tm].x); v[1] += bfhi(ad[tm].x); v[2] += bflo(ad[tm].y); v[3] += bfhi(ad[tm].y);
         }
         u32x2 pk;
         pk.x = pack2bf(v[0], v[1]);
         pk.y = pack2bf(v[2], v[3]);
-        st8(a.out + o, pk);
-        if (do_stats) {
-          float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
+        st8(a.out + obase + tm * 16, pk);
+        if (do_stats) {   // statistics of the STORED (bf16) values
+          const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
           s1[tm][0] += q0; s2[tm][0] += q0 * q0;
           s1[tm][1] += q1; s2[tm][1] += q1 * q1;
           s1[tm][2] += q2; s2[tm][2] += q2 * q2;
@@ -208,52 +243,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
         }
       }
     }
-  }
-  if (do_stats) {
+    if (do_stats) {
+      // lanes of one DPP row hold the same channels for 16 different pixels: VALU row reduction, then
+      // the pixel-waves of the tile meet in LDS ([pixel wave][stat][channel], 16-byte stores)
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm) {
+        f32x4 r1, r2;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x1 = s1[tm][r], x2 = s2[tm][r];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-          x1 += __shfl_xor(x1, d);
-          x2 += __shfl_xor(x2, d);
+        for (int r = 0; r < 4; ++r) {
+          r1[r] = row16_sum(s1[tm][r]);
+          r2[r] = row16_sum(s2[tm][r]);
         }
         if (lr == 0) {
-          int cl = wc * WC + tm * 16 + lq * 4 + r;
-          sRed[wp][cl][0] = x1;
-          sRed[wp][cl][1] = x2;
+          const int cl = wc * 64 + tm * 16 + lq * 4;
+          *reinterpret_cast<f32x4*>(&sRed[wp][0][cl]) = r1;
+          *reinterpret_cast<f32x4*>(&sRed[wp][1][cl]) = r2;
         }
       }
-    __syncthreads();
-    if (t < BC) {
-      float* dst = a.stats + (size_t)tile * 2 * a.Cout;   // one partial per spatial tile (128 pixels)
-      dst[c0 + t] = sRed[0][t][0] + sRed[1][t][0];
-      dst[a.Cout + c0 + t] = sRed[0][t][1] + sRed[1][t][1];
+      __syncthreads();
+      // one partial row per 128 pixels = per pair of pixel-waves (rows tile*WAVES_P/2 + h)
+      for (int e = t; e < WAVES_P * BC; e += 256) {
+        const int h = e / (2 * BC), rem = e - h * 2 * BC, st = rem / BC, cl = rem - st * BC;
+        float* dst = a.stats + ((size_t)tile * (WAVES_P / 2) + h) * 2 * a.Cout;
+        dst[st * a.Cout + c0 + cl] = sRed[2 * h][st][cl] + sRed[2 * h + 1][st][cl];
+      }
     }
-  }
+  };
+  const int flags = (a.stats ? 1 : 0) | (a.add ? 2 : 0) | (a.bias ? 4 : 0);
+  if (flags == 1) epilogue(std::integral_constant<int, 1>{});
+  else if (flags == 2) epilogue(std::integral_constant<int, 2>{});
+  else if (flags == 0) epilogue(std::integral_constant<int, 0>{});
+  else epilogue(std::integral_constant<int, 7>{});
 }
 
 template <int BC, bool DGRAD, bool SMALLW>
 static int launch_halo(const ConvArgs& a, hipStream_t stream) {
-  const int TW = SMALLW ? 8 : 16, TI = SMALLW ? 2 : 1;
-  const int tiles = ((a.g.N + TI - 1) / TI) * (a.g.H / 8) * (a.g.W / TW);
+  const int WAVES_P = 4 / (BC / 64);
+  const int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
+  const int tiles = ((a.g.N + TI - 1) / TI) * (a.g.H / TH) * (a.g.W / TW);
   const int ncb = a.Cout / BC;
   hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   return vfs_check_launch("conv3x3_halo");
 }
 
-// eligibility: 3x3 / stride 1 / pad 1, H % 8 == 0 and (W % 16 == 0, or W == 8 with N even so that
-// the 128-pixel statistics blocks coincide with the generic kernel's)
+// eligibility: 3x3 / stride 1 / pad 1, 64-channel granularity, and a spatial tiling that keeps the
+// per-128-pixel statistics rows aligned with the two halves of the batch:
+//   Cout % 128 == 0:  8x16 tiles (H % 8, W % 16), or whole 8x8 images in pairs (N even)
+//   otherwise      : 16x16 tiles (H % 16, W % 16)
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode) {
   const ConvGeom& g = a.g;
   if (mode != GATHER_FWD && mode != GATHER_DGRAD) return false;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
   if (a.Cout % 64 || g.C % 64) return false;
-  if (g.H != g.Ho || g.W != g.Wo || g.H % 8) return false;
-  if (g.W % 16 == 0) return true;
-  return g.W == 8 && g.H == 8 && g.N % 2 == 0;
+  if (g.H != g.Ho || g.W != g.Wo) return false;
+  if (a.Cout % 128 == 0) {
+    if (g.H % 8 == 0 && g.W % 16 == 0) return true;
+    return g.W == 8 && g.H == 8 && g.N % 2 == 0;
+  }
+  return g.H % 16 == 0 && g.W % 16 == 0;
 }
 
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
@@ -262,6 +309,5 @@ int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
     if (dg) return smallw ? launch_halo<128, true, true>(a, stream) : launch_halo<128, true, false>(a, stream);
     return smallw ? launch_halo<128, false, true>(a, stream) : launch_halo<128, false, false>(a, stream);
   }
-  if (dg) return smallw ? launch_halo<64, true, true>(a, stream) : launch_halo<64, true, false>(a, stream);
-  return smallw ? launch_halo<64, false, true>(a, stream) : launch_halo<64, false, false>(a, stream);
+  return dg ? launch_halo<64, true, false>(a, stream) : launch_halo<64, false, false>(a, stream);
 }

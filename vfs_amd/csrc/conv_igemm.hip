@@ -234,11 +234,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x1 = s1[tm][r], x2 = s2[tm][r];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-          x1 += __shfl_xor(x1, d);
-          x2 += __shfl_xor(x2, d);
-        }
+        x1 = row16_sum(x1);   // VALU (DPP) reduction over the 16 pixel lanes
+        x2 = row16_sum(x2);
         if (lr == 0) {
           int cl = wc * WC + tm * 16 + lq * 4 + r;
           sRed[wp][cl][0] = x1;

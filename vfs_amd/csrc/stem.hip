@@ -119,11 +119,8 @@ __global__ __launch_bounds__(256) void stem_fwd_direct_kernel(ConvArgs a, int ti
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float x1 = s1[tm][q], x2 = s2[tm][q];
-#pragma unroll
-          for (int d = 1; d < 16; d <<= 1) {
-            x1 += __shfl_xor(x1, d);
-            x2 += __shfl_xor(x2, d);
-          }
+          x1 = row16_sum(x1);   // VALU (DPP) reduction over the 16 pixel lanes
+          x2 = row16_sum(x2);
           if (lr == 0) {
             const int cl = wc * 32 + tm * 16 + lq * 4 + q;
             sRed[wp][cl][0] = x1;
