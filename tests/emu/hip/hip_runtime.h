@@ -47,6 +47,9 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
   return hipSuccess;
 }
 static const int hipMemcpyDeviceToDevice = 3;
+static const int hipDeviceAttributeMultiprocessorCount = 63;
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }   // "8 CUs"
 
 #define __global__
 #define __device__
@@ -290,6 +293,8 @@ inline v16f mfma_32x32x16_bf16(v8s a, v8s b, v16f c) {
 inline void __syncthreads() { emu::block_barrier(); }
 #define __builtin_amdgcn_s_barrier() emu::block_barrier()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// lanes are fibers here, not lockstep: the (code-free on hardware) wave barrier is a real rendezvous
+#define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 
 template <typename T>

@@ -16,7 +16,6 @@
 // Fragment reads are software-pipelined across the k-steps and across the per-tap barrier (the patch
 // does not change at a tap boundary), so a wave's LDS reads overlap its own and its neighbours' MFMAs.
 #include "vfs_conv.h"
-#include <type_traits>
 
 // any offset >= num_records reads as zero; 2^31 leaves room for a scalar offset on top without wrapping
 #define OOB_OFFSET 0x80000000u
@@ -43,6 +42,116 @@ __device__ __forceinline__ void halo_pixel(int wp, int tn, int lr, int& ti, int&
   }
 }
 
+// ---------------- epilogue shared by the halo kernels ----------------
+// acc[tm][tn]: wave tile of 64 channels (wc) x 64 pixels (wp).  F = compile-time superset of
+// {1: BatchNorm partial statistics, 2: residual add, 4: bias}: the three combinations the training step
+// uses get branch-free bodies, anything else the runtime-checked one.  sRed: [WAVES_P][2][BC] floats.
+//
+// The MFMA accumulator layout gives a lane 4 channels (8 bytes) of one pixel per tile; storing that
+// directly is 16 dwordx2 stores per lane in 32-byte fragments - store-ISSUE bound (measured: the
+// waves of a workgroup queue ~9k cycles behind one another).  Instead each wave transposes its
+// 64 x 64 outputs through a private LDS slab `stage` (64 pixel rows of 144 bytes; the caller
+// guarantees nobody still reads that memory) and writes whole 128-byte pixel rows: 8 dwordx4 stores
+// per lane, 1 KB contiguous per wave instruction.  LDS operations of one wave execute in order, so
+// the write -> read hand-over inside the wave needs no barrier.
+#define HALO_STAGE_ROW 72   // bf16 elements per staged pixel row (64 + 8 pad)
+#define HALO_STAGE_WAVE (64 * HALO_STAGE_ROW)
+template <int F, int BC, bool SMALLW>
+__device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&acc)[4][4], float* sRed, bf16_t* stage,
+                                              int tile, int tn0, int y0, int x0, int c0, int wc, int wp, int lr, int lq, int t) {
+  constexpr int TM = 4, TN = 4, WAVES_P = 4 / (BC / 64);
+  const ConvGeom& g = a.g;
+  const bool do_stats = (F & 1) && a.stats != nullptr;
+  const bool do_add = (F & 2) && a.add != nullptr;
+  const bool do_bias = (F & 4) && a.bias != nullptr;
+  const int lane = t & 63;
+  bf16_t* slab = stage + (t >> 6) * HALO_STAGE_WAVE;
+  float s1[TM][4], s2[TM][4];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    u32x2 ad[TM];
+    if (do_add) {
+      int ti, py, px;
+      halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
+      const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
+      const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) ad[tm] = ld8(a.add + obase + tm * 16);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+      if (do_bias) {
+        const int c = c0 + wc * 64 + tm * 16 + lq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
+      }
+      if (do_add) {
+        v[0] += bflo(ad[tm].x); v[1] += bfhi(ad[tm].x); v[2] += bflo(ad[tm].y); v[3] += bfhi(ad[tm].y);
+      }
+      u32x2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      st8(&slab[(tn * 16 + lr) * HALO_STAGE_ROW + tm * 16 + lq * 4], pk);
+      if (do_stats) {   // statistics of the STORED (bf16) values
+        const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
+        s1[tm][0] += q0; s2[tm][0] += q0 * q0;
+        s1[tm][1] += q1; s2[tm][1] += q1 * q1;
+        s1[tm][2] += q2; s2[tm][2] += q2 * q2;
+        s1[tm][3] += q3; s2[tm][3] += q3 * q3;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
+  // whole pixel rows out: lane = (pixel p = 8 i + lane/8, 16-byte chunk lane%8)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = i * 8 + (lane >> 3), ch = lane & 7;
+    int ti, py, px;
+    halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
+    const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
+    st16(a.out + mdst * a.Cout + c0 + wc * 64 + ch * 8, ld16(&slab[p * HALO_STAGE_ROW + ch * 8]));
+  }
+  if (do_stats) {
+    // lanes of one DPP row hold the same channels for 16 different pixels: VALU row reduction, then
+    // the pixel-waves of the tile meet in LDS ([pixel wave][stat][channel], 16-byte stores)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      f32x4 r1, r2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        r1[r] = row16_sum(s1[tm][r]);
+        r2[r] = row16_sum(s2[tm][r]);
+      }
+      if (lr == 0) {
+        const int cl = wc * 64 + tm * 16 + lq * 4;
+        *reinterpret_cast<f32x4*>(&sRed[(wp * 2 + 0) * BC + cl]) = r1;
+        *reinterpret_cast<f32x4*>(&sRed[(wp * 2 + 1) * BC + cl]) = r2;
+      }
+    }
+    __syncthreads();
+    // one partial row per 128 pixels = per pair of pixel-waves (rows tile*WAVES_P/2 + h)
+    for (int e = t; e < WAVES_P * BC; e += 256) {
+      const int h = e / (2 * BC), rem = e - h * 2 * BC, st = rem / BC, cl = rem - st * BC;
+      float* dst = a.stats + ((size_t)tile * (WAVES_P / 2) + h) * 2 * a.Cout;
+      dst[st * a.Cout + c0 + cl] = sRed[((2 * h) * 2 + st) * BC + cl] + sRed[((2 * h + 1) * 2 + st) * BC + cl];
+    }
+  }
+}
+template <int BC, bool SMALLW>
+__device__ __forceinline__ void halo_epilogue_dispatch(const ConvArgs& a, const f32x4 (&acc)[4][4], float* sRed, bf16_t* stage,
+                                                       int tile, int tn0, int y0, int x0, int c0, int wc, int wp, int lr, int lq, int t) {
+  const int flags = (a.stats ? 1 : 0) | (a.add ? 2 : 0) | (a.bias ? 4 : 0);
+  if (flags == 1) halo_epilogue<1, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 2) halo_epilogue<2, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 0) halo_epilogue<0, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else halo_epilogue<7, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+}
+
 template <int BC, bool DGRAD, bool SMALLW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   constexpr int WAVES_C = BC / 64, WAVES_P = 4 / WAVES_C;      // wave grid: channels x pixels
@@ -52,9 +161,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   constexpr int PLD = (PROWS * 8 + 255) / 256;   // 16-byte patch loads per thread
   constexpr int TM = 4, TN = 4;
   constexpr int RS = HALO_RS;
-  __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * RS];
-  __shared__ __attribute__((aligned(16))) bf16_t sW[2 * BC * RS];
+  // one arena: [patch | 2 weight tiles]; after the last tap the epilogue re-uses it as output stage
+  __shared__ __attribute__((aligned(16))) bf16_t smem[PROWS * RS + 2 * BC * RS];
   __shared__ __attribute__((aligned(16))) float sRed[WAVES_P][2][BC];
+  static_assert(PROWS * RS + 2 * BC * RS >= 4 * HALO_STAGE_WAVE, "output stage does not fit");
+  bf16_t* const sP = smem;
+  bf16_t* const sW = smem + PROWS * RS;
 
   const ConvGeom g = a.g;                        // FWD: H,W,C = input; DGRAD: H,W,C = dY (same H,W)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -195,85 +307,159 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
     }
   }
 
-  // ---------------- epilogue ----------------
-  // F = compile-time superset of {1: BatchNorm partial statistics, 2: residual add, 4: bias}: the three
-  // combinations the training step uses get branch-free bodies, anything else the runtime-checked one
-  auto epilogue = [&](auto FT) {
-    constexpr int F = decltype(FT)::value;
-    const bool do_stats = (F & 1) && a.stats != nullptr;
-    const bool do_add = (F & 2) && a.add != nullptr;
-    const bool do_bias = (F & 4) && a.bias != nullptr;
-    float s1[TM][4], s2[TM][4];
+  // the loop's final barrier has passed: no wave reads the patch / weight tiles any more
+  halo_epilogue_dispatch<BC, SMALLW>(a, acc, &sRed[0][0][0], smem, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+}
+
+// ------------------------------------------------------------------------------------------
+// Cin = Cout = 64 (ResNet layer1, the largest feature maps): the layer is as much HBM- as MFMA-bound
+// (288 flop per byte of activations), and per-tile staging of patch + weights left the matrix pipe
+// idle ~70 % of the time.  Here a PERSISTENT workgroup (one per CU, 146 KB of LDS) keeps the whole
+// 3x3x64x64 filter resident - 9 taps x 64 rows x 160 B, loaded once by LDS-DMA - and walks over 16x16
+// pixel tiles: the nine taps of a tile are 288 back-to-back MFMAs per wave with no barrier and no
+// weight traffic, while the NEXT tile's halo patch is already in flight (registers) and is written
+// to LDS between two barriers at the tile boundary.  Tiles are assigned so that the workgroups of one
+// XCD walk a contiguous range (vertically adjacent tiles share halo rows in that XCD's L2).
+template <bool DGRAD>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(ConvArgs a, int ntiles) {
+  constexpr int TW = 16, TH = 16, PW = TW + 2, PH = TH + 2, PROWS = PH * PW;   // 324 patch rows
+  constexpr int PLD = (PROWS * 8 + 255) / 256;                                 // 11 loads / thread
+  constexpr int TM = 4, TN = 4, RS = HALO_RS;
+  static_assert(PROWS * RS >= 4 * HALO_STAGE_WAVE, "output stage does not fit in the patch");
+  __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * RS];
+  __shared__ __attribute__((aligned(16))) bf16_t sW[9 * 64 * RS];
+  __shared__ __attribute__((aligned(16))) float sRed[4][2][64];
+
+  const ConvGeom g = a.g;
+  const int t = threadIdx.x, lane = t & 63, wp = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int j = t & 7, row0 = t >> 3;
+  const int tiles_x = g.W / TW, tiles_y = g.H / TH;
+
+  // XCD-contiguous tile walk: workgroup b runs on XCD b % 8; XCD x owns tiles [x*per, (x+1)*per)
+  const int nwg = gridDim.x;
+  int first, stride, last;
+  if (nwg % 8 == 0 && ntiles % 8 == 0) {
+    const int per = ntiles / 8, xcd = blockIdx.x & 7;
+    first = xcd * per + (blockIdx.x >> 3);
+    stride = nwg >> 3;
+    last = (xcd + 1) * per;
+  } else {
+    first = blockIdx.x; stride = nwg; last = ntiles;
+  }
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * 64 * 2), 0x00020000);
+  unsigned poff[PLD];
+  u32x4 pr_[PLD];
+  auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % tiles_x, r = tile / tiles_x;
+    x0 = tx * TW; y0 = (r % tiles_y) * TH; n = r / tiles_y;
+  };
+  auto load_patch = [&](int tile) {
+    int n, y0, x0;
+    tile_origin(tile, n, y0, x0);
+#pragma unroll
+    for (int k = 0; k < PLD; ++k) {
+      const int pr = row0 + 32 * k;
+      unsigned off = OOB_OFFSET;
+      if (pr < PROWS) {
+        const int py = pr / PW, px = pr - py * PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
+          off = (unsigned)((((size_t)(n * g.H + y) * g.W + x) * 64 + j * 8) * 2);
+      }
+      poff[k] = off;
+    }
+#pragma unroll
+    for (int k = 0; k < PLD; ++k) pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[k], 0, 0);
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int k = 0; k < PLD; ++k) {
+      const int pr = row0 + 32 * k;
+      if (pr < PROWS) st16(&sP[pr * RS + j * 8], pr_[k]);
+    }
+  };
+
+  if (first >= last) return;
+  load_patch(first);
+  {  // the whole filter: 90 one-KB pieces of the padded [tap][row][160 B] image, wave w moves w, w+4, ...
+    const vfs_rsrc_words wrs = vfs_make_rsrc_words(a.wgt, (unsigned)(64 * 576 * 2));
+    for (int q = wp; q < 90; q += 4) {
+      const int pos = q * 1024 + lane * 16;
+      const int row = pos / (RS * 2), col = pos - row * (RS * 2);   // row = tap*64 + channel row
+      const int tap = row >> 6, cr = row & 63;
+      vfs_dma16_async(wrs, sW + q * 512, (unsigned)((cr * 576 + tap * 64) * 2 + (col < 128 ? col : 0)), 0);
+    }
+  }
+  store_patch();
+  vfs_dma_wait_all();
+  __syncthreads();
+
+  int pbase[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) pbase[tn] = ((wp * 4 + tn) * PW + lr) * RS + lq * 8;
+  const int abase = lr * RS + lq * 8;
+
+  for (int tile = first; tile < last; tile += stride) {
+    const int next = tile + stride;
+    if (next < last) load_patch(next);            // in flight during the nine taps of this tile
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      int ti, py, px;
-      halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
-      const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
-      const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
-      u32x2 ad[TM];
-      if (do_add) {
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, sx = tap - 3 * r;
+      const int shift = (DGRAD ? (2 - r) * PW + (2 - sx) : r * PW + sx) * RS;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) ad[tm] = ld8(a.add + obase + tm * 16);
-      }
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-        if (do_bias) {
-          const int c = c0 + wc * 64 + tm * 16 + lq * 4;
+        for (int tm = 0; tm < TM; ++tm)
+          af[tm] = *reinterpret_cast<const bf16x8*>(&sW[abase + (tap * 64 + tm * 16) * RS + kk * 32]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
-        }
-        if (do_add) {
-          v[0] += bflo(ad[tm].x); v[1] += bfhi(ad[tm].x); v[2] += bflo(ad[tm].y); v[3] += bfhi(ad[tm].y);
-        }
-        u32x2 pk;
-        pk.x = pack2bf(v[0], v[1]);
-        pk.y = pack2bf(v[2], v[3]);
-        st8(a.out + obase + tm * 16, pk);
-        if (do_stats) {   // statistics of the STORED (bf16) values
-          const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
-          s1[tm][0] += q0; s2[tm][0] += q0 * q0;
-          s1[tm][1] += q1; s2[tm][1] += q1 * q1;
-          s1[tm][2] += q2; s2[tm][2] += q2 * q2;
-          s1[tm][3] += q3; s2[tm][3] += q3 * q3;
-        }
+        for (int tn = 0; tn < TN; ++tn)
+          bfr[tn] = *reinterpret_cast<const bf16x8*>(&sP[pbase[tn] + shift + kk * 32]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
       }
     }
-    if (do_stats) {
-      // lanes of one DPP row hold the same channels for 16 different pixels: VALU row reduction, then
-      // the pixel-waves of the tile meet in LDS ([pixel wave][stat][channel], 16-byte stores)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        f32x4 r1, r2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          r1[r] = row16_sum(s1[tm][r]);
-          r2[r] = row16_sum(s2[tm][r]);
-        }
-        if (lr == 0) {
-          const int cl = wc * 64 + tm * 16 + lq * 4;
-          *reinterpret_cast<f32x4*>(&sRed[wp][0][cl]) = r1;
-          *reinterpret_cast<f32x4*>(&sRed[wp][1][cl]) = r2;
-        }
-      }
-      __syncthreads();
-      // one partial row per 128 pixels = per pair of pixel-waves (rows tile*WAVES_P/2 + h)
-      for (int e = t; e < WAVES_P * BC; e += 256) {
-        const int h = e / (2 * BC), rem = e - h * 2 * BC, st = rem / BC, cl = rem - st * BC;
-        float* dst = a.stats + ((size_t)tile * (WAVES_P / 2) + h) * 2 * a.Cout;
-        dst[st * a.Cout + c0 + cl] = sRed[2 * h][st][cl] + sRed[2 * h + 1][st][cl];
-      }
-    }
-  };
-  const int flags = (a.stats ? 1 : 0) | (a.add ? 2 : 0) | (a.bias ? 4 : 0);
-  if (flags == 1) epilogue(std::integral_constant<int, 1>{});
-  else if (flags == 2) epilogue(std::integral_constant<int, 2>{});
-  else if (flags == 0) epilogue(std::integral_constant<int, 0>{});
-  else epilogue(std::integral_constant<int, 7>{});
+    __builtin_amdgcn_sched_barrier(0);
+    int n, y0, x0;
+    tile_origin(tile, n, y0, x0);
+    __syncthreads();                              // every wave is done with this tile's patch ...
+    halo_epilogue_dispatch<64, false>(a, acc, &sRed[0][0][0], sP, tile, n, y0, x0, 0, 0, wp, lr, lq, t);   // ... now the output stage
+    __syncthreads();                              // staged rows are out (and sRed is free again)
+    if (next < last) store_patch();
+    __syncthreads();
+  }
+}
+
+static int vfs_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
+template <bool DGRAD>
+static int launch_c64(const ConvArgs& a, hipStream_t stream) {
+  const int ntiles = a.g.N * (a.g.H / 16) * (a.g.W / 16);
+  int grid = vfs_option_c64_wgs > 0 ? vfs_option_c64_wgs : vfs_num_cus();   // one persistent workgroup per CU
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((conv3x3_c64_kernel<DGRAD>), dim3(grid), dim3(256), 0, stream, a, ntiles);
+  return vfs_check_launch("conv3x3_c64");
 }
 
 template <int BC, bool DGRAD, bool SMALLW>
@@ -309,5 +495,7 @@ int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
     if (dg) return smallw ? launch_halo<128, true, true>(a, stream) : launch_halo<128, true, false>(a, stream);
     return smallw ? launch_halo<128, false, true>(a, stream) : launch_halo<128, false, false>(a, stream);
   }
+  if (a.Cout == 64 && a.g.C == 64 && vfs_option_c64)   // persistent kernel, resident filter
+    return dg ? launch_c64<true>(a, stream) : launch_c64<false>(a, stream);
   return dg ? launch_halo<64, true, false>(a, stream) : launch_halo<64, false, false>(a, stream);
 }
