@@ -27,9 +27,8 @@ typedef uint16_t vfs_bf16;
 
 const char* vfs_last_error(void);
 int vfs_abi_version(void);
-/* tuning knobs for A/B measurements and tests: "halo" (1 = 3x3/stride-1 convs use the halo-tile
- * kernels), "c64" (1 = 64->64-channel ones use the persistent resident-filter kernel), "c64_wgs"
- * (its grid; 0 = one workgroup per CU), "stem_direct" */
+/* tuning knobs for A/B measurements: "halo" (1 = 3x3/stride-1 convs use the halo-tile kernels),
+ * "stem_direct" */
 int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------

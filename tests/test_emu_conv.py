@@ -80,29 +80,13 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (2, 9, 11, 64, 64, 3, 2, 1),      # odd sizes: unequal parity classes in the stride-2 dgrad
     (1, 16, 32, 128, 64, 3, 1, 1),    # halo-tile kernel: 8x16 spatial tiles, two channel chunks
     (4, 8, 8, 64, 128, 3, 1, 1),      # halo-tile kernel: two whole 8x8 images per workgroup
+    (2, 32, 32, 64, 64, 3, 1, 1),     # halo-tile kernel, 64 output channels: 16x16 tiles, 4 pixel waves
 ]
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', CASES)
 def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
-
-
-@pytest.mark.parametrize('wgs', [0, 8, 3, 1])
-def test_conv_c64_persistent_tile_walk(backend, wgs):
-    """64->64 channel 3x3 conv: persistent resident-filter kernel.  16 tiles walked by 8 workgroups
-    (XCD-contiguous assignment, 2 tiles each), by 3 (plain striding, ragged) and by ONE (all tiles,
-    every patch hand-over), and with the default one-workgroup-per-CU grid; plus the generic halo
-    kernel on the same inputs ("c64" off) - all against torch."""
-    try:
-        backend.lib.set_option(b'c64_wgs', wgs)
-        run_conv_case(backend, 4, 32, 32, 64, 64, 3, 1, 1)
-        if wgs == 0:
-            backend.lib.set_option(b'c64', 0)
-            run_conv_case(backend, 4, 32, 32, 64, 64, 3, 1, 1)
-    finally:
-        backend.lib.set_option(b'c64_wgs', 0)
-        backend.lib.set_option(b'c64', 1)
 
 
 BIG_CASES = [  # the layer shapes of the bench configs (per-GPU batch reduced), ragged M included

@@ -16,6 +16,9 @@ def main():
     if os.environ.get('VFS_HIP_LIB'):      # A/B a variant build of the library
         set_lib(VfsLib(os.environ['VFS_HIP_LIB']))
     lib = get_lib()
+    for opt in ('halo',):
+        if os.environ.get('VFS_OPT_' + opt.upper()):
+            lib.set_option(opt.encode(), int(os.environ['VFS_OPT_' + opt.upper()]))
     dev = torch.device('cuda:0')
     s = torch.cuda.current_stream().cuda_stream
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -311,157 +311,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   halo_epilogue_dispatch<BC, SMALLW>(a, acc, &sRed[0][0][0], smem, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
 
-// ------------------------------------------------------------------------------------------
-// Cin = Cout = 64 (ResNet layer1, the largest feature maps): the layer is as much HBM- as MFMA-bound
-// (288 flop per byte of activations), and per-tile staging of patch + weights left the matrix pipe
-// idle ~70 % of the time.  Here a PERSISTENT workgroup (one per CU, 146 KB of LDS) keeps the whole
-// 3x3x64x64 filter resident - 9 taps x 64 rows x 160 B, loaded once by LDS-DMA - and walks over 16x16
-// pixel tiles: the nine taps of a tile are 288 back-to-back MFMAs per wave with no barrier and no
-// weight traffic, while the NEXT tile's halo patch is already in flight (registers) and is written
-// to LDS between two barriers at the tile boundary.  Tiles are assigned so that the workgroups of one
-// XCD walk a contiguous range (vertically adjacent tiles share halo rows in that XCD's L2).
-template <bool DGRAD>
-__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(ConvArgs a, int ntiles) {
-  constexpr int TW = 16, TH = 16, PW = TW + 2, PH = TH + 2, PROWS = PH * PW;   // 324 patch rows
-  constexpr int PLD = (PROWS * 8 + 255) / 256;                                 // 11 loads / thread
-  constexpr int TM = 4, TN = 4, RS = HALO_RS;
-  static_assert(PROWS * RS >= 4 * HALO_STAGE_WAVE, "output stage does not fit in the patch");
-  __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * RS];
-  __shared__ __attribute__((aligned(16))) bf16_t sW[9 * 64 * RS];
-  __shared__ __attribute__((aligned(16))) float sRed[4][2][64];
-
-  const ConvGeom g = a.g;
-  const int t = threadIdx.x, lane = t & 63, wp = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lr = lane & 15, lq = lane >> 4;
-  const int j = t & 7, row0 = t >> 3;
-  const int tiles_x = g.W / TW, tiles_y = g.H / TH;
-
-  // XCD-contiguous tile walk: workgroup b runs on XCD b % 8; XCD x owns tiles [x*per, (x+1)*per)
-  const int nwg = gridDim.x;
-  int first, stride, last;
-  if (nwg % 8 == 0 && ntiles % 8 == 0) {
-    const int per = ntiles / 8, xcd = blockIdx.x & 7;
-    first = xcd * per + (blockIdx.x >> 3);
-    stride = nwg >> 3;
-    last = (xcd + 1) * per;
-  } else {
-    first = blockIdx.x; stride = nwg; last = ntiles;
-  }
-
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * 64 * 2), 0x00020000);
-  unsigned poff[PLD];
-  u32x4 pr_[PLD];
-  auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
-    const int tx = tile % tiles_x, r = tile / tiles_x;
-    x0 = tx * TW; y0 = (r % tiles_y) * TH; n = r / tiles_y;
-  };
-  auto load_patch = [&](int tile) {
-    int n, y0, x0;
-    tile_origin(tile, n, y0, x0);
-#pragma unroll
-    for (int k = 0; k < PLD; ++k) {
-      const int pr = row0 + 32 * k;
-      unsigned off = OOB_OFFSET;
-      if (pr < PROWS) {
-        const int py = pr / PW, px = pr - py * PW;
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
-          off = (unsigned)((((size_t)(n * g.H + y) * g.W + x) * 64 + j * 8) * 2);
-      }
-      poff[k] = off;
-    }
-#pragma unroll
-    for (int k = 0; k < PLD; ++k) pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[k], 0, 0);
-  };
-  auto store_patch = [&]() {
-#pragma unroll
-    for (int k = 0; k < PLD; ++k) {
-      const int pr = row0 + 32 * k;
-      if (pr < PROWS) st16(&sP[pr * RS + j * 8], pr_[k]);
-    }
-  };
-
-  if (first >= last) return;
-  load_patch(first);
-  {  // the whole filter: 90 one-KB pieces of the padded [tap][row][160 B] image, wave w moves w, w+4, ...
-    const vfs_rsrc_words wrs = vfs_make_rsrc_words(a.wgt, (unsigned)(64 * 576 * 2));
-    for (int q = wp; q < 90; q += 4) {
-      const int pos = q * 1024 + lane * 16;
-      const int row = pos / (RS * 2), col = pos - row * (RS * 2);   // row = tap*64 + channel row
-      const int tap = row >> 6, cr = row & 63;
-      vfs_dma16_async(wrs, sW + q * 512, (unsigned)((cr * 576 + tap * 64) * 2 + (col < 128 ? col : 0)), 0);
-    }
-  }
-  store_patch();
-  vfs_dma_wait_all();
-  __syncthreads();
-
-  int pbase[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) pbase[tn] = ((wp * 4 + tn) * PW + lr) * RS + lq * 8;
-  const int abase = lr * RS + lq * 8;
-
-  for (int tile = first; tile < last; tile += stride) {
-    const int next = tile + stride;
-    if (next < last) load_patch(next);            // in flight during the nine taps of this tile
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, sx = tap - 3 * r;
-      const int shift = (DGRAD ? (2 - r) * PW + (2 - sx) : r * PW + sx) * RS;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 af[TM], bfr[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          af[tm] = *reinterpret_cast<const bf16x8*>(&sW[abase + (tap * 64 + tm * 16) * RS + kk * 32]);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          bfr[tn] = *reinterpret_cast<const bf16x8*>(&sP[pbase[tn] + shift + kk * 32]);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    int n, y0, x0;
-    tile_origin(tile, n, y0, x0);
-    __syncthreads();                              // every wave is done with this tile's patch ...
-    halo_epilogue_dispatch<64, false>(a, acc, &sRed[0][0][0], sP, tile, n, y0, x0, 0, 0, wp, lr, lq, t);   // ... now the output stage
-    __syncthreads();                              // staged rows are out (and sRed is free again)
-    if (next < last) store_patch();
-    __syncthreads();
-  }
-}
-
-static int vfs_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
-
-template <bool DGRAD>
-static int launch_c64(const ConvArgs& a, hipStream_t stream) {
-  const int ntiles = a.g.N * (a.g.H / 16) * (a.g.W / 16);
-  int grid = vfs_option_c64_wgs > 0 ? vfs_option_c64_wgs : vfs_num_cus();   // one persistent workgroup per CU
-  if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((conv3x3_c64_kernel<DGRAD>), dim3(grid), dim3(256), 0, stream, a, ntiles);
-  return vfs_check_launch("conv3x3_c64");
-}
-
 template <int BC, bool DGRAD, bool SMALLW>
 static int launch_halo(const ConvArgs& a, hipStream_t stream) {
   const int WAVES_P = 4 / (BC / 64);
@@ -495,7 +344,5 @@ int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
     if (dg) return smallw ? launch_halo<128, true, true>(a, stream) : launch_halo<128, true, false>(a, stream);
     return smallw ? launch_halo<128, false, true>(a, stream) : launch_halo<128, false, false>(a, stream);
   }
-  if (a.Cout == 64 && a.g.C == 64 && vfs_option_c64)   // persistent kernel, resident filter
-    return dg ? launch_c64<true>(a, stream) : launch_c64<false>(a, stream);
   return dg ? launch_halo<64, true, false>(a, stream) : launch_halo<64, false, false>(a, stream);
 }

@@ -54,9 +54,7 @@ int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsp
 int vfs_stem_tiles(int N, int Ho, int Wo);
 int vfs_stem_fwd_direct_launch(const ConvArgs& a, hipStream_t stream);
 extern int vfs_option_stem_direct;
-extern int vfs_option_halo;
-extern int vfs_option_c64_wgs;  // 0: one workgroup per CU; > 0: fixed grid (tests exercise the tile walk)
-extern int vfs_option_c64;      // persistent resident-filter kernel for 64->64 channel 3x3 convs   // 1: 3x3/s1 convs use the halo-tile kernel (capi: vfs_set_option)
+extern int vfs_option_halo;   // 1: 3x3/s1 convs use the halo-tile kernel (capi: vfs_set_option)
 int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream);
 
 struct PixCoord {
