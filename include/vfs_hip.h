@@ -39,9 +39,11 @@ int vfs_imgs_to_nhwc4(const float* imgs, vfs_bf16* out, int B, int V, int T, int
                       vfs_stream_t stream);
 
 /* table-driven repack of ALL fp32 master weights into the bf16 MFMA layouts in one launch.
- * desc: device array of ntensors records {w, wf, wd, start, Cout, Cin, KH, KW, kind, 0}
- * (8-byte pointers/int64 then 6 int32; kind 1 = 7x7 stem -> [64][8][8][4]) */
-int vfs_pack_weights(const void* desc, int ntensors, long long total_elems, vfs_stream_t stream);
+ * desc: device array of ntensors records {w, wf, wd, start, Cout, Cin, KH, KW, kind, tile_start}
+ * (8-byte pointers/int64 then 6 int32; kind 1 = 7x7 stem -> [64][8][8][4]).  One workgroup per
+ * 32x32 (cout x cin) tile of a tensor (per 256 elements of the stem); tile_start = running sum,
+ * total_tiles = its end (KH*KW <= 25 except the stem). */
+int vfs_pack_weights(const void* desc, int ntensors, long long total_tiles, vfs_stream_t stream);
 
 /* ---- convolution / linear: torch conv2d & linear call sites ---------------------------------
  * forward  (resnet.py:51-73,163-191,267-277 via mmcv ConvModule; sim_siam_head.py:78-111):

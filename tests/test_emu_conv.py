@@ -89,6 +89,24 @@ def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
 
 
+@pytest.mark.parametrize('shape', [(48, 40, 3, 3), (70, 33, 1, 1), (5, 3, 5, 5), (64, 64, 3, 3), (130, 257, 1, 1)])
+def test_pack_weights_ragged(backend, shape):
+    """tiled LDS transpose of the weight repack on tile-ragged / odd shapes, several tensors per launch"""
+    g = torch.Generator().manual_seed(shape[0])
+    dev = backend.dev
+    ws = [torch.randn(*shape, generator=g), torch.randn(shape[1], shape[0], 1, 1, generator=g)]
+    entries = []
+    for w in ws:
+        co, ci, kh, kw = w.shape
+        entries.append((w.to(dev), torch.full((co, kh, kw, ci), float('nan'), dtype=torch.bfloat16, device=dev),
+                        torch.full((ci, kh, kw, co), float('nan'), dtype=torch.bfloat16, device=dev), 0))
+    tab, n, total = build_pack_table(entries, dev)
+    backend.lib.pack_weights(tab, n, total, None)
+    for (w, wf, wd, _), w0 in zip(entries, ws):
+        assert torch.equal(wf.float().cpu(), rb(w0).permute(0, 2, 3, 1))
+        assert torch.equal(wd.float().cpu(), rb(w0).permute(1, 2, 3, 0))
+
+
 BIG_CASES = [  # the layer shapes of the bench configs (per-GPU batch reduced), ragged M included
     (8, 64, 64, 64, 64, 3, 1, 1),      # R18 layer1 @256
     (8, 64, 64, 64, 128, 3, 2, 1),     # R18 layer2.0.conv1

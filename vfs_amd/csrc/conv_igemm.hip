@@ -35,9 +35,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int TM = WC / 16;  // 16-channel tiles per wave
   constexpr int TN = 4;        // 16-pixel tiles per wave
   constexpr int WLD = BC / 32; // weight rows loaded per thread
-  __shared__ __attribute__((aligned(16))) bf16_t sW[2][BC * 64];
-  __shared__ __attribute__((aligned(16))) bf16_t sX[2][BP * 64];
+  // one arena [2 weight tiles | 2 pixel tiles]; after the K loop the epilogue re-uses it as output stage
+  constexpr int SROW = WC + 8;                    // staged pixel row: WC channels + 16 bytes of padding
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BC * 64 + 2 * BP * 64];
+  static_assert(2 * BC * 64 + 2 * BP * 64 >= 4 * 64 * SROW, "output stage does not fit");
   __shared__ float sRed[2][BC][2];
+  bf16_t (*sW)[BC * 64] = reinterpret_cast<bf16_t (*)[BC * 64]>(smem);
+  bf16_t (*sX)[BP * 64] = reinterpret_cast<bf16_t (*)[BP * 64]>(smem + 2 * BC * 64);
 
   const ConvGeom g = a.g;
   const int t = threadIdx.x;
@@ -173,15 +177,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int cur = kt & 1;
       const bool more = kt + 1 < nk;
       if (more) load_tiles(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the MFMAs (the scheduler sinks them)
       mma_kstep<TM, TN, false>(sW[cur], sX[cur], wc * WC, wp * 64, lane, acc);
+      __builtin_amdgcn_sched_barrier(0);
       if (more) store_tiles(cur ^ 1);
       __syncthreads();
     }
   }
 
   // ---------------- epilogue ----------------
+  // (as conv_halo.hip) the accumulator layout gives a lane 8 bytes of one pixel per MFMA tile; each wave
+  // transposes its WC x 64 outputs through a private LDS slab and writes 16-byte pieces of whole pixel
+  // rows.  The K loop ended with a barrier: nobody reads the operand tiles any more.
   const int lr = lane & 15, lq = lane >> 4;
-  const bool do_stats = a.stats != nullptr;
+  const bool do_stats = a.stats != nullptr, do_add = a.add != nullptr, do_bias = a.bias != nullptr;
+  bf16_t* slab = smem + wave * (64 * SROW);
+  auto pixel_dst = [&](int m) -> size_t {         // class-local pixel -> row of the output matrix
+    if (MODE != GATHER_DGRAD2) return (size_t)m;
+    const int hw = Hc * Wc;
+    const int n = m / hw;
+    const int rem = m - n * hw;
+    const int hc = rem / Wc, wcx = rem - hc * Wc;
+    return ((size_t)n * g.Ho + (2 * hc + ph)) * g.Wo + (2 * wcx + pw);
+  };
   float s1[TM][4], s2[TM][4];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
@@ -192,40 +210,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int tn = 0; tn < TN; ++tn) {
     const int m = m0 + wp * 64 + tn * 16 + lr;
     const bool mok = m < Mc;
-    size_t mdst = (size_t)m;
-    if (MODE == GATHER_DGRAD2 && mok) {   // class-local pixel -> position in the full gradient
-      const int hw = Hc * Wc;
-      const int n = m / hw;
-      const int rem = m - n * hw;
-      const int hc = rem / Wc, wcx = rem - hc * Wc;
-      mdst = ((size_t)n * g.Ho + (2 * hc + ph)) * g.Wo + (2 * wcx + pw);
-    }
+    const size_t mdst = (do_add && mok) ? pixel_dst(m) : 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int c = c0 + wc * WC + tm * 16 + lq * 4;
-      if (mok && c < a.Cout) {
-        float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-        if (a.bias) {
+      const bool ok = mok && c < a.Cout;
+      float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+      if (do_bias && ok) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
-        }
-        const size_t o = mdst * a.Cout + c;
-        if (a.add) {
-          u32x2 ad = ld8(a.add + o);
-          v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
-        }
-        u32x2 pk;
-        pk.x = pack2bf(v[0], v[1]);
-        pk.y = pack2bf(v[2], v[3]);
-        st8(a.out + o, pk);
-        if (do_stats) {
-          float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
-          s1[tm][0] += q0; s2[tm][0] += q0 * q0;
-          s1[tm][1] += q1; s2[tm][1] += q1 * q1;
-          s1[tm][2] += q2; s2[tm][2] += q2 * q2;
-          s1[tm][3] += q3; s2[tm][3] += q3 * q3;
-        }
+        for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
       }
+      if (do_add && ok) {
+        const u32x2 ad = ld8(a.add + mdst * a.Cout + c);
+        v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
+      }
+      u32x2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      st8(&slab[(tn * 16 + lr) * SROW + tm * 16 + lq * 4], pk);
+      if (do_stats && ok) {   // statistics of the STORED (bf16) values
+        const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
+        s1[tm][0] += q0; s2[tm][0] += q0 * q0;
+        s1[tm][1] += q1; s2[tm][1] += q1 * q1;
+        s1[tm][2] += q2; s2[tm][2] += q2 * q2;
+        s1[tm][3] += q3; s2[tm][3] += q3 * q3;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
+  {
+    constexpr int CPR = WC / 8, PPI = 64 / CPR;   // 16-byte chunks per staged row, pixels per store instruction
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) {
+      const int p = i * PPI + lane / CPR, ch = lane % CPR;
+      const int m = m0 + wp * 64 + p, c = c0 + wc * WC + ch * 8;
+      if (m < Mc && c < a.Cout) st16(a.out + pixel_dst(m) * a.Cout + c, ld16(&slab[p * SROW + ch * 8]));
     }
   }
   if (do_stats) {
@@ -266,7 +285,7 @@ static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
 }
 
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
-  if (a.g.Ktot % 64 != 0 || a.Cout % 4 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: K%64 or Cout%4");
+  if (a.g.Ktot % 64 != 0 || a.Cout % 8 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: K%64 or Cout%8");
   if (vfs_option_halo && a.g.C % 64 == 0 && (size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 < 0xFFFFFFF0ull &&
       vfs_conv_halo_eligible(a, mode))
     return vfs_conv_halo_dispatch(a, mode, stream);

@@ -172,51 +172,83 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
 // partial[nsplit][Cout][Ktot] -> grad (+=) in the reference's parameter layout (OIHW fp32):
 //   FWD  : k = (r*KW + s)*Cin + cin          -> grad[cout][cin][r][s]
 //   STEM : k = (r*8 + (s+1))*4 + c           -> grad[cout][c][r][s]   (r<7, 0<=s<7, c<3)
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad,
                                                            int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
                                                            int stem) {
-  // 64 consecutive elements x 4 split-slices per workgroup: coalesced 256-byte rows, the split
-  // loop is 4x shorter, and the final 4-way sum runs in a fixed order (deterministic)
-  __shared__ float sh[4][64];
+  // workgroup = EL lanes x 4 consecutive elements (one 16-byte load each) x SL split-slices; a lane
+  // walks its slice's splits four at a time (four independent 16-byte loads in flight), the SL slice
+  // sums meet in LDS and are added in a fixed order (deterministic).  total % 4 == 0 (Ktot % 4 == 0).
+  constexpr int EL = 256 / SL;
+  __shared__ __attribute__((aligned(16))) float sh[SL][EL * 4];
   const size_t total = (size_t)Cout * Ktot;
-  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
-    const size_t i = base + el;
-    float sum = 0.f;
-    if (i < total)
-      for (int sp = sl; sp < nsplit; sp += 4) sum += partial[(size_t)sp * total + i];
-    sh[sl][el] = sum;
+  const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+  for (size_t base = (size_t)blockIdx.x * (EL * 4); base < total; base += (size_t)gridDim.x * (EL * 4)) {
+    const size_t i = base + (size_t)el * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (i < total) {
+      const float* p = partial + i;
+      int sp = sl;
+      for (; sp + 3 * SL < nsplit; sp += 4 * SL) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sp * total);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + SL) * total);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 2 * SL) * total);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 3 * SL) * total);
+        sum += (v0 + v1) + (v2 + v3);
+      }
+      for (; sp < nsplit; sp += SL) sum += *reinterpret_cast<const f32x4*>(p + (size_t)sp * total);
+    }
+    *reinterpret_cast<f32x4*>(&sh[sl][el * 4]) = sum;
     __syncthreads();
-    if (sl == 0 && i < total) {
-      sum = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
-      const int cout = (int)(i / Ktot), k = (int)(i - (size_t)cout * Ktot);
-      int cin, r, s;
+    // EL*4 elements, one per thread (EL*4 <= 256 only for SL >= 4; below that a thread takes several)
+    for (int e = threadIdx.x; e < EL * 4; e += 256) {
+      const size_t ii = base + e;
+      if (ii >= total) continue;
+      float tot = sh[0][e];
+#pragma unroll
+      for (int q = 1; q < SL; ++q) tot += sh[q][e];
+      const int cout = (int)(ii / Ktot), k = (int)(ii - (size_t)cout * Ktot);
+      int cin, r, s2;
       bool ok = true;
       if (stem) {
         cin = k & 3;
         const int si = (k >> 2) & 7;
-        r = k >> 5; s = si - 1;
+        r = k >> 5; s2 = si - 1;
         ok = (cin < 3) && (r < 7) && (si >= 1);
       } else {
         const int tap = k / Cin;
         cin = k - tap * Cin;
-        r = tap / KW; s = tap - r * KW;
+        r = tap / KW; s2 = tap - r * KW;
       }
       if (ok) {
         const int cin_n = stem ? 3 : Cin;
-        grad[(((size_t)cout * cin_n + cin) * KH + r) * KW + s] += sum;
+        grad[(((size_t)cout * cin_n + cin) * KH + r) * KW + s2] += tot;
       }
     }
     __syncthreads();
   }
 }
 
+template <int SL>
+static void launch_reduce(const float* partial, float* grad, int nsplit, int Cout, int Ktot, int Cin, int KH, int KW, int stem,
+                          hipStream_t stream) {
+  const size_t total = (size_t)Cout * Ktot;
+  const int per = (256 / SL) * 4;
+  int blocks = (int)((total + per - 1) / per);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((wgrad_reduce_kernel<SL>), dim3(blocks), dim3(256), 0, stream, partial, grad, nsplit, Cout, Ktot, Cin,
+                     KH, KW, stem);
+}
+
 int vfs_wgrad_reduce_launch(const float* partial, float* grad, int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
                             int stem, hipStream_t stream) {
-  size_t total = (size_t)Cout * Ktot;
-  int blocks = (int)((total + 63) / 64);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, grad, nsplit, Cout, Ktot, Cin, KH,
-                     KW, stem);
+  if (Ktot % 4) return vfs_set_error(VFS_ERR_SHAPE, "wgrad_reduce: Ktot % 4");
+  // as many split-slices per workgroup as there are splits to share (<= 16), the rest of the 256 lanes
+  // go to consecutive elements; small tensors with many splits (layer1: 37k elements x 256 splits)
+  // still launch hundreds of workgroups
+  if (nsplit >= 16) launch_reduce<16>(partial, grad, nsplit, Cout, Ktot, Cin, KH, KW, stem, stream);
+  else if (nsplit >= 8) launch_reduce<8>(partial, grad, nsplit, Cout, Ktot, Cin, KH, KW, stem, stream);
+  else if (nsplit >= 4) launch_reduce<4>(partial, grad, nsplit, Cout, Ktot, Cin, KH, KW, stem, stream);
+  else launch_reduce<1>(partial, grad, nsplit, Cout, Ktot, Cin, KH, KW, stem, stream);
   return vfs_check_launch("wgrad_reduce");
 }

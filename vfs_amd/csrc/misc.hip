@@ -33,32 +33,99 @@ int vfs_imgs_to_nhwc4_launch(const float* imgs, bf16_t* out, int B, int V, int T
 }
 
 // ------------------------------------------------------------------ weight packing
-__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ table, int n, long long total) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (table[mid].start <= i) lo = mid; else hi = mid - 1;
+// fp32 master weights [Cout][Cin][T] (T = KH*KW) -> bf16 wf [Cout][T][Cin] (forward operand) and
+// wd [Cin][T][Cout] (dgrad operand), every step after the optimizer.  A workgroup transposes one
+// TC x TC (cout x cin) tile through LDS: whole contiguous row segments in (coalesced), 2 packed
+// elements (4 bytes) per lane out along cin for wf and along cout for wd.  T is 1 or 9 for every
+// layer but the stem (kind 1: [64][3][7][7] -> [64][8][8][4], a few thousand elements).
+#define PACK_TC 32
+template <int T>
+__device__ __forceinline__ void pack_tile(const PackDesc& d, int tile, bf16_t* sT, int KT) {
+  constexpr int TC = PACK_TC;
+  const int Tn = T > 0 ? T : KT;                  // taps (compile-time for the common cases)
+  const int pitch = TC * Tn + 2;                  // bf16 elements per staged cout row (odd dword count)
+  const int t = threadIdx.x;
+  const int tiles_ci = (d.Cin + TC - 1) / TC;
+  const int co0 = (tile / tiles_ci) * TC, ci0 = (tile - (tile / tiles_ci) * tiles_ci) * TC;
+  const int ncout = min(TC, d.Cout - co0), ncin = min(TC, d.Cin - ci0);
+  const int rowlen = ncin * Tn;
+  // in: thread (row r = t / 32 + 8 i, k = t % 32 + 32 j) over the contiguous segment of each cout row
+  for (int r = t >> 5; r < ncout; r += 8) {
+    const float* src = d.w + ((size_t)(co0 + r) * d.Cin + ci0) * Tn;
+    for (int k = t & 31; k < rowlen; k += 32) sT[r * pitch + k] = f2bf(src[k]);
+  }
+  __syncthreads();
+  // wf[cout][tap][cin]: lane pair index = cin pair
+  const int hp = (ncin + 1) >> 1;
+  for (int q = t / 16; q < ncout * Tn; q += 16) {
+    const int r = q / Tn, tap = q - r * Tn;
+    const int cp = t & 15;
+    if (cp < hp) {
+      const int c = cp * 2;
+      const bf16_t lo = sT[r * pitch + c * Tn + tap];
+      bf16_t* dst = d.wf + ((size_t)(co0 + r) * Tn + tap) * d.Cin + ci0 + c;
+      if (c + 1 < ncin && ((d.Cin | ci0) & 1) == 0) {
+        const bf16_t hi = sT[r * pitch + (c + 1) * Tn + tap];
+        *reinterpret_cast<uint32_t*>(dst) = (uint32_t)lo | ((uint32_t)hi << 16);
+      } else {
+        dst[0] = lo;
+        if (c + 1 < ncin) dst[1] = sT[r * pitch + (c + 1) * Tn + tap];
+      }
     }
-    const PackDesc d = table[lo];
-    long long e = i - d.start;
-    const int s = (int)(e % d.KW); e /= d.KW;
-    const int r = (int)(e % d.KH); e /= d.KH;
-    const int cin = (int)(e % d.Cin);
-    const int cout = (int)(e / d.Cin);
-    const bf16_t v = f2bf(d.w[i - d.start]);
-    if (d.kind == 1) {
-      d.wf[(((size_t)cout * 8 + r) * 8 + (s + 1)) * 4 + cin] = v;
-    } else {
-      d.wf[(((size_t)cout * d.KH + r) * d.KW + s) * d.Cin + cin] = v;
-      if (d.wd) d.wd[(((size_t)cin * d.KH + r) * d.KW + s) * d.Cout + cout] = v;
+  }
+  if (d.wd) {   // wd[cin][tap][cout]: lane pair index = cout pair
+    const int hq = (ncout + 1) >> 1;
+    for (int q = t / 16; q < ncin * Tn; q += 16) {
+      const int ci = q / Tn, tap = q - ci * Tn;
+      const int rp = t & 15;
+      if (rp < hq) {
+        const int r = rp * 2;
+        const bf16_t lo = sT[r * pitch + ci * Tn + tap];
+        bf16_t* dst = d.wd + ((size_t)(ci0 + ci) * Tn + tap) * d.Cout + co0 + r;
+        if (r + 1 < ncout && ((d.Cout | co0) & 1) == 0) {
+          const bf16_t hi = sT[(r + 1) * pitch + ci * Tn + tap];
+          *reinterpret_cast<uint32_t*>(dst) = (uint32_t)lo | ((uint32_t)hi << 16);
+        } else {
+          dst[0] = lo;
+          if (r + 1 < ncout) dst[1] = sT[(r + 1) * pitch + ci * Tn + tap];
+        }
+      }
     }
   }
 }
-int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total, hipStream_t s) {
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((int)blocks), dim3(256), 0, s, table, ntensors, total);
+
+#define PACK_MAX_T 25
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ table, int n) {
+  __shared__ __attribute__((aligned(16))) bf16_t sT[PACK_TC * (PACK_TC * PACK_MAX_T + 2)];
+  // uniform: which tensor does this workgroup's tile belong to
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = table[lo];
+  const int tile = (int)blockIdx.x - d.tile_start;
+  if (d.kind == 1) {   // stem, 256 elements per workgroup
+    const long long total = (long long)d.Cout * d.Cin * d.KH * d.KW;
+    long long e = (long long)tile * 256 + threadIdx.x;
+    if (e < total) {
+      const bf16_t v = f2bf(d.w[e]);
+      const int s = (int)(e % d.KW); e /= d.KW;
+      const int r = (int)(e % d.KH); e /= d.KH;
+      const int cin = (int)(e % d.Cin);
+      const int cout = (int)(e / d.Cin);
+      d.wf[(((size_t)cout * 8 + r) * 8 + (s + 1)) * 4 + cin] = v;
+    }
+    return;
+  }
+  const int KT = d.KH * d.KW;
+  if (KT == 1) pack_tile<1>(d, tile, sT, 1);
+  else if (KT == 9) pack_tile<9>(d, tile, sT, 9);
+  else pack_tile<0>(d, tile, sT, KT);
+}
+int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total_tiles, hipStream_t s) {
+  if (total_tiles <= 0 || ntensors <= 0) return VFS_OK;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, table, ntensors);
   return vfs_check_launch("pack_weights");
 }
 

@@ -98,11 +98,12 @@ struct PackDesc {
   const float* w;   // [Cout][Cin][KH][KW]
   bf16_t* wf;       // kind 0: [Cout][KH][KW][Cin]   kind 1 (stem): [Cout][8][8][4] (pre-zeroed)
   bf16_t* wd;       // kind 0: [Cin][KH][KW][Cout] or null
-  long long start;  // first global element index of this tensor
+  long long start;  // first global element index of this tensor (informational)
   int Cout, Cin, KH, KW;
-  int kind, pad0;
+  int kind;         // 0: conv / linear   1: 7x7 stem
+  int tile_start;   // first workgroup of this tensor: 32x32 (cout x cin) tiles, or 256-element pieces (stem)
 };
-int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total, hipStream_t s);
+int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total_tiles, hipStream_t s);
 
 int vfs_avgpool_fwd_launch(const bf16_t* x, bf16_t* y, int N, int HW, int C, hipStream_t s);
 int vfs_avgpool_bwd_launch(const bf16_t* g, bf16_t* gx, int N, int HW, int C, hipStream_t s);

@@ -5,22 +5,26 @@ import numpy as np
 import torch
 
 PACK_DTYPE = np.dtype([('w', '<u8'), ('wf', '<u8'), ('wd', '<u8'), ('start', '<i8'), ('Cout', '<i4'),
-                       ('Cin', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('kind', '<i4'), ('pad0', '<i4')])
+                       ('Cin', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('kind', '<i4'), ('tile_start', '<i4')])
 assert PACK_DTYPE.itemsize == 56
 
 
 def build_pack_table(entries, device):
     """entries: list of (w_fp32[Cout,Cin,KH,KW] tensor, wf bf16 tensor, wd bf16 tensor|None, kind).
-    Returns (table uint8 tensor on device, ntensors, total_elems)."""
+    Returns (table uint8 tensor on device, ntensors, total_tiles): one workgroup per 32x32
+    (cout x cin) tile of a tensor, per 256 elements for the stem (csrc/misc.hip)."""
     arr = np.zeros(len(entries), PACK_DTYPE)
     start = 0
+    tiles = 0
     for i, (w, wf, wd, kind) in enumerate(entries):
         shp = list(w.shape) + [1, 1]
+        assert kind == 1 or shp[2] * shp[3] <= 25
         arr[i] = (w.data_ptr(), wf.data_ptr(), 0 if wd is None else wd.data_ptr(), start,
-                  shp[0], shp[1], shp[2], shp[3], kind, 0)
+                  shp[0], shp[1], shp[2], shp[3], kind, tiles)
         start += w.numel()
+        tiles += (w.numel() + 255) // 256 if kind == 1 else ((shp[0] + 31) // 32) * ((shp[1] + 31) // 32)
     t = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
-    return t, len(entries), start
+    return t, len(entries), tiles
 
 
 def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
