@@ -28,7 +28,7 @@ typedef uint16_t vfs_bf16;
 const char* vfs_last_error(void);
 int vfs_abi_version(void);
 /* tuning knobs for A/B measurements: "halo" (1 = 3x3/stride-1 convs use the halo-tile kernels),
- * "stem_direct" */
+ * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default) */
 int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------

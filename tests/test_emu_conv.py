@@ -140,15 +140,24 @@ def test_stem_fwd_wgrad(backend):
     y = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
     ntile = N * ((Ho + 7) // 8) * ((Wo + 15) // 16)
     stats = torch.full((ntile, 2, 64), float('nan'), device=dev)
-    lib.stem_fwd(x4, wf, y, stats, N, H, W, Ho, Wo, None)
     ref = F.conv2d(x, w, None, 2, 3)
-    assert relerr(nchw(y.cpu()), ref) < 6e-3
-    yf = y.float().cpu().reshape(M, 64).double()
-    st = stats.cpu().double()
-    assert torch.allclose(st[:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=5e-3)
-    assert torch.allclose(st[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=5e-3)
-    half = ntile // 2     # first / second half of the images = first / second half of the rows
-    assert torch.allclose(st[:half, 0].sum(0), yf[:M // 2].sum(0), rtol=1e-4, atol=5e-3)
+    # default grid (one tile per workgroup at this size), then ONE workgroup walking every tile and
+    # three walking ragged ranges: the statistics run must break at every image boundary
+    for blocks in (0, 1, 3):
+        y.fill_(float('nan'))
+        stats.fill_(float('nan'))
+        lib.set_option(b'stem_blocks', blocks)
+        try:
+            lib.stem_fwd(x4, wf, y, stats, N, H, W, Ho, Wo, None)
+        finally:
+            lib.set_option(b'stem_blocks', 0)
+        assert relerr(nchw(y.cpu()), ref) < 6e-3
+        yf = y.float().cpu().reshape(M, 64).double()
+        st = stats.cpu().double()
+        assert torch.allclose(st[:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=5e-3)
+        assert torch.allclose(st[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=5e-3)
+        half = ntile // 2     # first / second half of the images = first / second half of the rows
+        assert torch.allclose(st[:half, 0].sum(0), yf[:M // 2].sum(0), rtol=1e-4, atol=5e-3)
     # the generic implicit-GEMM stem path must agree bit-for-bit on the output
     lib.set_option(b'stem_direct', 0)
     y2 = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)

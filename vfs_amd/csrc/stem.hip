@@ -29,15 +29,17 @@ __device__ __forceinline__ int stem_w_off(int r, int cout, int chunk) {   // swi
   return (r * 64 + cout) * 32 + ((chunk ^ ((cout >> 2) & 3)) << 3);
 }
 
+#define ST_STAGE_ROW 72   // staged output pixel row: 64 channels + 16 bytes of padding
 __global__ __launch_bounds__(256) void stem_fwd_direct_kernel(ConvArgs a, int tiles_per_block, int ntiles) {
   __shared__ __attribute__((aligned(16))) bf16_t sW[7 * 64 * 32];
   __shared__ __attribute__((aligned(16))) bf16_t sX[ST_PH * ST_PROW];
-  __shared__ float sRed[2][64][2];
+  __shared__ __attribute__((aligned(16))) bf16_t sOut[4 * 32 * ST_STAGE_ROW];
+  __shared__ __attribute__((aligned(16))) float sRed[4][2][64];
+  constexpr int PL = (ST_PH * 19 + 255) / 256;     // 16-byte patch loads per thread (2)
   const ConvGeom g = a.g;               // H, W = padded input dims (NHWC4), Ho, Wo = output dims
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wc = wave >> 1, wp = wave & 1;        // wave = 32 cout x 64 pixels (rows 4wp..4wp+3)
+  const int t = threadIdx.x, lane = t & 63, wp = t >> 6;   // wave = 64 cout x 32 pixels (tile rows 2wp, 2wp+1)
   const int lr = lane & 15, lq = lane >> 4;
-  const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 7) / 8;
+  const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 7) / 8, tiles_img = tiles_x * tiles_y;
 
   // weights [64][8][8][4] (row 7 and column 0 are zero padding) -> LDS rows r = 0..6
   for (int i = t; i < 7 * 64 * 4; i += 256) {
@@ -47,93 +49,132 @@ __global__ __launch_bounds__(256) void stem_fwd_direct_kernel(ConvArgs a, int ti
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * 4 * 2), 0x00020000);
 
-  const int t_begin = blockIdx.x * tiles_per_block, t_end = min(ntiles, t_begin + tiles_per_block);
-  const bool do_stats = a.stats != nullptr;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int y0 = ty * 8, x0 = tx * 16;
-    __syncthreads();                       // previous tile's readers are done (also covers sW fill)
-    // ---- stage the patch: rows 2y0-3.., 19 chunks (2 columns) per row starting at column 2x0-4
-    for (int i = t; i < ST_PH * 19; i += 256) {
-      const int pr = i / 19, pc = i - pr * 19;
-      const int y = 2 * y0 - 3 + pr, x = 2 * x0 - 4 + 2 * pc;
-      const bool ok = (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+  // patch of a tile: rows 2y0-3.., 19 chunks (2 columns) per row starting at column 2x0-4
+  u32x4 pr_[PL];
+  auto load_patch = [&](int tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / tiles_img;
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      const int i = t + 256 * k;
+      const int prow = i / 19, pc = i - prow * 19;
+      const int y = 2 * ty * 8 - 3 + prow, x = 2 * tx * 16 - 4 + 2 * pc;
+      const bool ok = i < ST_PH * 19 && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
       const unsigned off = ok ? (unsigned)((((size_t)(n * g.H + y) * g.W + x) * 4) * 2) : OOB_OFFSET;
-      st16(&sX[pr * ST_PROW + pc * 8], __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+      pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
     }
-    __syncthreads();
-    f32x4 acc[2][4];
+  };
+  auto store_patch = [&]() {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int k = 0; k < PL; ++k) {
+      const int i = t + 256 * k;
+      if (i < ST_PH * 19) {
+        const int prow = i / 19, pc = i - prow * 19;
+        st16(&sX[prow * ST_PROW + pc * 8], pr_[k]);
+      }
+    }
+  };
+
+  const int t_begin = blockIdx.x * tiles_per_block, t_end = min(ntiles, t_begin + tiles_per_block);
+  if (t_begin >= t_end) return;
+  const bool do_stats = a.stats != nullptr;
+  // BatchNorm statistics accumulate in registers over a RUN of tiles of the same image (the two views
+  // are different images) and are reduced once per run into the row of the run's first tile
+  float s1[4][4], s2[4][4];
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[tm][q] = 0.f; s2[tm][q] = 0.f; }
+  int run_first = t_begin;
+  load_patch(t_begin);
+  store_patch();
+  __syncthreads();                       // patch + weights are in LDS
+  bf16_t* slab = sOut + wp * (32 * ST_STAGE_ROW);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / tiles_img;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const bool has_next = tile + 1 < t_end;
+    if (has_next) load_patch(tile + 1);  // in flight during this tile's MFMAs and epilogue
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      bf16x8 af[2], bfr[4];
+      bf16x8 af[4], bfr[2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-        af[tm] = *reinterpret_cast<const bf16x8*>(&sW[stem_w_off(r, wc * 32 + tm * 16 + lr, lq)]);
+      for (int tm = 0; tm < 4; ++tm)
+        af[tm] = *reinterpret_cast<const bf16x8*>(&sW[stem_w_off(r, tm * 16 + lr, lq)]);
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int py = wp * 4 + tn;
+      for (int tn = 0; tn < 2; ++tn) {
+        const int py = wp * 2 + tn;
         bfr[tn] = *reinterpret_cast<const bf16x8*>(&sX[(2 * py + r) * ST_PROW + (2 * lr + 2 * lq) * 4]);
       }
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 2; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
     }
-    // ---- epilogue: 4 consecutive channels of one pixel per lane, BatchNorm partial statistics
-    float s1[2][4], s2[2][4];
+    // ---- epilogue: transpose the wave's 64 x 32 outputs through its LDS slab, whole 128-byte pixel rows out
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tn = 0; tn < 2; ++tn) {
+      const bool mok = y0 + wp * 2 + tn < g.Ho && x0 + lr < g.Wo;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { s1[tm][q] = 0.f; s2[tm][q] = 0.f; }
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int y = y0 + wp * 4 + tn, x = x0 + lr;
-      const bool mok = y < g.Ho && x < g.Wo;
-      const size_t mdst = ((size_t)n * g.Ho + y) * g.Wo + x;
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const int c = wc * 32 + tm * 16 + lq * 4;
-        if (mok) {
-          u32x2 pk;
-          pk.x = pack2bf(acc[tm][tn][0], acc[tm][tn][1]);
-          pk.y = pack2bf(acc[tm][tn][2], acc[tm][tn][3]);
-          st8(a.out + mdst * 64 + c, pk);
-          if (do_stats) {
-            const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
-            s1[tm][0] += q0; s2[tm][0] += q0 * q0;
-            s1[tm][1] += q1; s2[tm][1] += q1 * q1;
-            s1[tm][2] += q2; s2[tm][2] += q2 * q2;
-            s1[tm][3] += q3; s2[tm][3] += q3 * q3;
-          }
+      for (int tm = 0; tm < 4; ++tm) {
+        u32x2 pk;
+        pk.x = pack2bf(acc[tm][tn][0], acc[tm][tn][1]);
+        pk.y = pack2bf(acc[tm][tn][2], acc[tm][tn][3]);
+        st8(&slab[(tn * 16 + lr) * ST_STAGE_ROW + tm * 16 + lq * 4], pk);
+        if (do_stats && mok) {   // statistics of the STORED (bf16) values
+          const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
+          s1[tm][0] += q0; s2[tm][0] += q0 * q0;
+          s1[tm][1] += q1; s2[tm][1] += q1 * q1;
+          s1[tm][2] += q2; s2[tm][2] += q2 * q2;
+          s1[tm][3] += q3; s2[tm][3] += q3 * q3;
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();     // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = i * 8 + (lane >> 3), ch = lane & 7;
+      const int y = y0 + wp * 2 + (p >> 4), x = x0 + (p & 15);
+      if (y < g.Ho && x < g.Wo)
+        st16(a.out + (((size_t)n * g.Ho + y) * g.Wo + x) * 64 + ch * 8, ld16(&slab[p * ST_STAGE_ROW + ch * 8]));
+    }
+    const bool run_ends = !has_next || (tile + 1) / tiles_img != n;      // uniform
     if (do_stats) {
+      if (run_ends) {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < 4; ++tm) {
+          f32x4 r1, r2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float x1 = s1[tm][q], x2 = s2[tm][q];
-          x1 = row16_sum(x1);   // VALU (DPP) reduction over the 16 pixel lanes
-          x2 = row16_sum(x2);
+          for (int q = 0; q < 4; ++q) {
+            r1[q] = row16_sum(s1[tm][q]);
+            r2[q] = row16_sum(s2[tm][q]);
+            s1[tm][q] = 0.f; s2[tm][q] = 0.f;
+          }
           if (lr == 0) {
-            const int cl = wc * 32 + tm * 16 + lq * 4 + q;
-            sRed[wp][cl][0] = x1;
-            sRed[wp][cl][1] = x2;
+            *reinterpret_cast<f32x4*>(&sRed[wp][0][tm * 16 + lq * 4]) = r1;
+            *reinterpret_cast<f32x4*>(&sRed[wp][1][tm * 16 + lq * 4]) = r2;
           }
         }
-      __syncthreads();
-      if (t < 64) {
-        float* dst = a.stats + (size_t)tile * 2 * 64;
-        dst[t] = sRed[0][t][0] + sRed[1][t][0];
-        dst[64 + t] = sRed[0][t][1] + sRed[1][t][1];
+        __syncthreads();
+        if (t < 128) {
+          const int st = t >> 6, cl = t & 63;
+          a.stats[(size_t)run_first * 128 + t] = (sRed[0][st][cl] + sRed[1][st][cl]) + (sRed[2][st][cl] + sRed[3][st][cl]);
+        }
+        if (tile != run_first && t >= 128) a.stats[(size_t)tile * 128 + (t - 128)] = 0.f;
+        run_first = tile + 1;
+      } else if (tile != run_first && t < 128) {
+        a.stats[(size_t)tile * 128 + t] = 0.f;
       }
     }
+    __syncthreads();                     // every wave is done with this tile's patch (and with sRed)
+    if (has_next) store_patch();
+    __syncthreads();
   }
 }
 
@@ -141,7 +182,8 @@ int vfs_stem_tiles(int N, int Ho, int Wo) { return N * ((Ho + 7) / 8) * ((Wo + 1
 
 int vfs_stem_fwd_direct_launch(const ConvArgs& a, hipStream_t stream) {
   const int ntiles = vfs_stem_tiles(a.g.N, a.g.Ho, a.g.Wo);
-  int blocks = ntiles < 2048 ? ntiles : 2048;
+  const int maxb = vfs_option_stem_blocks > 0 ? vfs_option_stem_blocks : 2048;
+  int blocks = ntiles < maxb ? ntiles : maxb;
   const int tpb = (ntiles + blocks - 1) / blocks;
   blocks = (ntiles + tpb - 1) / tpb;
   hipLaunchKernelGGL(stem_fwd_direct_kernel, dim3(blocks), dim3(256), 0, stream, a, tpb, ntiles);

@@ -54,6 +54,7 @@ int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsp
 int vfs_stem_tiles(int N, int Ho, int Wo);
 int vfs_stem_fwd_direct_launch(const ConvArgs& a, hipStream_t stream);
 extern int vfs_option_stem_direct;
+extern int vfs_option_stem_blocks;   // grid cap of the direct stem kernel (0 = default 2048); tests walk many tiles per block
 extern int vfs_option_halo;   // 1: 3x3/s1 convs use the halo-tile kernel (capi: vfs_set_option)
 int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream);
 
