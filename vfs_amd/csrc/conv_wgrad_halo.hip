@@ -35,7 +35,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int lo_off, int hi
 }
 
 template <bool SMALLW>
-__global__ __launch_bounds__(256, SMALLW ? 1 : 2) void conv3x3_wgrad_halo_kernel(WgradArgs a, int tiles_per_split, int ntiles) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a, int tiles_per_split, int ntiles) {
   constexpr int TW = SMALLW ? 8 : 16, TH = 8, TI = SMALLW ? 2 : 1;
   constexpr int PW = TW + 2, PH = TH + 2;
   constexpr int PROWS = TI * PH * PW;
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256, SMALLW ? 1 : 2) void conv3x3_wgrad_halo_kernel
     for (int tile = t_begin; tile < t_end; ++tile) {
       const bool more = tile + 1 < t_end;
       if (more) load_tile(tile + 1);
-#pragma unroll
+      // the two-image tile needs ~20 more address / staging registers: fully unrolled it only fits one
+      // wave per SIMD (472 registers) and ran at 640 TFLOP/s; rolled k-steps keep it at two waves
+#pragma unroll(SMALLW ? 1 : 4)
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 bfr[2];
 #pragma unroll

@@ -44,7 +44,7 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
         colblocks = (Cin // 64) * (Cout // 64)
         # every workgroup writes a 9x64x64 fp32 partial (147 KB): keep ~2 workgroups per CU so
         # the split-K traffic (blocks x 147 KB, written then re-read) stays well below the MFMA time
-        tb = 256 if (Cin * Cout <= 4096 or W == 8) else 512   # measured: multiples of the 256 CUs
+        tb = int(os.environ.get('VFS_WGRAD_TB', 512))   # measured on all four layer shapes: 512 > 256 > 768 > 1024
         nsplit = max(1, min(ntiles, (tb + colblocks - 1) // colblocks))
         tps = (ntiles + nsplit - 1) // nsplit
         nsplit = (ntiles + tps - 1) // tps
