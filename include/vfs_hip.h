@@ -78,7 +78,10 @@ int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stre
  * `sums` across ranks for SyncBN (count = global element count per channel per group).
  * bnp: float[G][4][C] = {scale, shift, mean, invstd}. */
 int vfs_bn_reduce_partials(const float* partial, double* sums, double* scratch, int G, int bpg, int C,
-                           vfs_stream_t stream); /* scratch: double[G][128][2][C] or NULL */
+                           vfs_stream_t stream);
+/* scratch (or NULL): 64 uint32 ticket counters, zero before the first use and left at zero by every
+ * call, followed by double[G][128][2][C].  With it, large row counts are reduced by many workgroups
+ * in ONE launch (the workgroup that draws the last ticket of a 32-channel block finishes it). */
 int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp,
                     float* running_mean, float* running_var, int G, int C, double count, float eps,
                     float momentum, vfs_stream_t stream);

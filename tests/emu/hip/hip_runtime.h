@@ -293,6 +293,7 @@ inline v16f mfma_32x32x16_bf16(v8s a, v8s b, v16f c) {
 inline void __syncthreads() { emu::block_barrier(); }
 #define __builtin_amdgcn_s_barrier() emu::block_barrier()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 // lanes are fibers here, not lockstep: the (code-free on hardware) wave barrier is a real rendezvous
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
@@ -407,6 +408,11 @@ inline void vfs_dma16_async(vfs_rsrc_words rsrc, void* lds_wave_base, unsigned v
   memcpy((char*)lds_wave_base + 16 * emu::lane_id(), &v, 16);
 }
 inline void vfs_dma_wait_all() {}
+// agent-scope relaxed accesses (csrc/vfs_common.h): blocks may run on different host threads
+inline void vfs_store_agent(double* p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
+inline double vfs_load_agent(const double* p) { double v; __atomic_load(const_cast<double*>(p), &v, __ATOMIC_SEQ_CST); return v; }
+inline unsigned vfs_ticket_agent(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
+inline void vfs_release_workgroup() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 template <typename T>
 inline T atomicAdd(T* p, T v) {

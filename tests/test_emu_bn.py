@@ -1,5 +1,6 @@
 """BatchNorm / pooling / loss / SGD kernels vs torch (CPU fp32) on the same bf16-rounded operands.
 backend=emu: fiber emulator on the CPU; backend=gpu: libvfs_hip.so on the MI355X."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -77,7 +78,7 @@ def test_bn_backward_matches_autograd(backend):
     ppb = 32
     nblk = M // ppb
     partial = torch.zeros(nblk, 2, C)
-    scratch = torch.zeros(G * 128 * 2 * C, dtype=torch.float64)
+    scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)   # ticket counters + chunk sums
     for ymask, relu in ((y, 0), (None, 1)):       # mask from the stored output / recomputed from x
         lib.bn_bwd_reduce(nhwc(gout), ymask, nhwc(x), bnp, partial, M, C, mpg, ppb, relu, None)
         sums = torch.zeros(G, 2, C, dtype=torch.float64)
@@ -90,6 +91,39 @@ def test_bn_backward_matches_autograd(backend):
     dgamma, dbeta = torch.zeros(C), torch.zeros(C)
     lib.bn_param_grad(sums, dgamma, dbeta, G, C, None)
     assert relerr(dgamma, gm_.grad) < 1e-4 and relerr(dbeta, bt_.grad) < 1e-4
+
+
+@pytest.mark.parametrize('G,bpg,C', [(2, 300, 96), (1, 5000, 64), (2, 65, 2048)])
+def test_bn_chunked_single_launch_reduction(backend, G, bpg, C):
+    """large row counts: many workgroups reduce row chunks and the one that draws the last ticket of a
+    channel block finishes it - sums, fused finalize and fused parameter gradients against fp64 torch,
+    twice in a row on the same scratch (the tickets must return to zero)"""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(G * 1000 + bpg)
+    partial = torch.randn(G * bpg, 2, C, generator=g)
+    partial[:, 1].abs_().add_(partial[:, 0] ** 2)       # sum of squares >= (sum)^2 / n
+    ref = partial.double().reshape(G, bpg, 2, C).sum(1)
+    scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    count = float(bpg * 128)
+    for _ in range(2):
+        sums = torch.zeros(G, 2, C, dtype=torch.float64)
+        lib.bn_reduce_partials(partial, sums, scratch, G, bpg, C, None)
+        assert torch.allclose(sums, ref, rtol=1e-12, atol=1e-9)
+        assert (scratch[:32].view(torch.int32) == 0).all()
+        sums2 = torch.zeros(G, 2, C, dtype=torch.float64)
+        bnp, rm, rv = torch.zeros(G, 4, C), torch.zeros(C), torch.ones(C)
+        lib.bn_stats_finalize(partial, sums2, scratch, gamma, beta, bnp, rm, rv, G, bpg, C, count, 1e-5, 0.1, None)
+        assert torch.equal(sums2, sums)
+        bnp1, rm1, rv1 = torch.zeros(G, 4, C), torch.zeros(C), torch.ones(C)
+        lib.bn_finalize(sums, gamma, beta, bnp1, rm1, rv1, G, C, count, 1e-5, 0.1, None)
+        assert torch.equal(bnp, bnp1) and torch.equal(rm, rm1) and torch.equal(rv, rv1)
+        dg, db = torch.ones(C), torch.ones(C)
+        sums3 = torch.zeros(G, 2, C, dtype=torch.float64)
+        lib.bn_bwd_sums_paramgrad(partial, sums3, scratch, dg, db, G, bpg, C, None)
+        assert torch.equal(sums3, sums)
+        assert torch.allclose(db.double() - 1, ref[:, 0].sum(0), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(dg.double() - 1, ref[:, 1].sum(0), rtol=1e-5, atol=1e-3)
 
 
 def test_stem_bn_relu_maxpool_fwd_bwd(backend):
@@ -199,7 +233,7 @@ def test_stem_pool_bn_bwd_fused_equals_unfused(backend):
     idx = torch.empty(N, Hp, Wp, C, dtype=torch.uint8)
     lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, N, H, W, C, Hp, Wp, N // G, None)
     gp = nhwc(rb(torch.randn(N, C, Hp, Wp, generator=g)))
-    scratch = torch.zeros(G * 128 * 2 * C, dtype=torch.float64)
+    scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)   # ticket counters + chunk sums
     M = N * H * W
     # unfused reference chain
     ga = torch.empty(N, H, W, C, dtype=torch.bfloat16)

@@ -138,6 +138,105 @@ __global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restr
   }
 }
 
+// The same two stages in ONE launch for large row counts: grid (channel blocks, groups, row chunks);
+// every workgroup writes the fp64 sums of its chunk to `chunks`, publishes them (agent-scope fence)
+// and draws a ticket for its channel block; the workgroup that draws the LAST ticket of a channel
+// block finishes that block: fixed-order sum over the chunks, then the fused finalize (MODE 0),
+// parameter-gradient (MODE 1) or plain sums (MODE 2) step.  Deterministic (the summation order does
+// not depend on which workgroup is last); the ticket counters return to zero.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __restrict__ in, double* __restrict__ sums,
+                                                               double* __restrict__ chunks, unsigned* __restrict__ tickets,
+                                                               int G, int bpg, int C, int rpc, int nchunks,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ bnp, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, double count, float eps,
+                                                               float momentum, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[8][2][32];
+  __shared__ unsigned s_ticket;
+  const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  {
+    const int gi = blockIdx.y, ch = blockIdx.z;
+    const int r0 = ch * rpc, r1 = min(bpg, r0 + rpc);
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+      const float* p = in + (size_t)gi * bpg * 2 * C;
+      for (int b = r0 + sl; b < r1; b += 8) {
+        a0 += (double)p[(size_t)b * 2 * C + c];
+        a1 += (double)p[(size_t)b * 2 * C + C + c];
+      }
+    }
+    sh[sl][0][cl] = a0;
+    sh[sl][1][cl] = a1;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double r0s = 0.0, r1s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0s += sh[k][0][cl]; r1s += sh[k][1][cl]; }
+      double* o = chunks + ((size_t)gi * nchunks + ch) * 2 * C;
+      vfs_store_agent(&o[c], r0s);       // device-coherent stores (no L2 write-back fence, see vfs_common.h)
+      vfs_store_agent(&o[C + c], r1s);
+    }
+  }
+  vfs_release_workgroup();               // this wave's chunk sums have been performed
+  __syncthreads();
+  if (t == 0) s_ticket = vfs_ticket_agent(&tickets[blockIdx.x]);
+  __syncthreads();
+  if (s_ticket != (unsigned)(gridDim.y * gridDim.z) - 1u) return;
+  float rm = 0.f, rv = 0.f;
+  double g1 = 0.0, g2 = 0.0;
+  if (MODE == 0 && sl == 0 && c < C) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 0.f; }
+  for (int gi = 0; gi < G; ++gi) {
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+      const double* p = chunks + (size_t)gi * nchunks * 2 * C;
+      for (int b = sl; b < nchunks; b += 8) {
+        a0 += vfs_load_agent(&p[(size_t)b * 2 * C + c]);   // device-coherent loads of the other workgroups' sums
+        a1 += vfs_load_agent(&p[(size_t)b * 2 * C + C + c]);
+      }
+    }
+    __syncthreads();
+    sh[sl][0][cl] = a0;
+    sh[sl][1][cl] = a1;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0 += sh[k][0][cl]; r1 += sh[k][1][cl]; }
+      sums[((size_t)gi * 2 + 0) * C + c] = r0;
+      sums[((size_t)gi * 2 + 1) * C + c] = r1;
+      if (MODE == 0) {
+        const double mean = r0 / count;
+        double var = r1 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * invstd;
+        float* o = bnp + (size_t)gi * 4 * C;
+        o[c] = scale;
+        o[C + c] = beta[c] - (float)mean * scale;
+        o[2 * C + c] = (float)mean;
+        o[3 * C + c] = invstd;
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      } else if (MODE == 1) {
+        g1 += r0; g2 += r1;
+      }
+    }
+  }
+  if (sl == 0 && c < C) {
+    if (MODE == 0) {
+      if (running_mean) running_mean[c] = rm;
+      if (running_var) running_var[c] = rv;
+    } else if (MODE == 1) {
+      dbeta[c] += (float)g1;
+      dgamma[c] += (float)g2;
+    }
+  }
+  if (t == 0) tickets[blockIdx.x] = 0u;  // ready for the next launch on this stream
+}
+
 // eval-mode BN: bnp from running statistics (G = 1)
 __global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ running_mean,
@@ -576,45 +675,39 @@ static inline int grid_for(long long total_vec) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s) {
-  const int cb = (C + 31) / 32;
-  if (bpg <= 64 || scratch == nullptr) {
-    hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, 1), dim3(256), 0, s, partial, sums, bpg, C, bpg, 1);
-    return vfs_check_launch("bn_reduce_partials");
-  }
-  int nchunks = (bpg + 31) / 32;
-  if (nchunks > VFS_BN_MAX_CHUNKS) nchunks = VFS_BN_MAX_CHUNKS;
-  const int rpc = (bpg + nchunks - 1) / nchunks;
-  nchunks = (bpg + rpc - 1) / rpc;
-  hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, nchunks), dim3(256), 0, s, partial, scratch, bpg, C, rpc, nchunks);
-  hipLaunchKernelGGL((bn_reduce_rows_kernel<double>), dim3(cb, G, 1), dim3(256), 0, s, (const double*)scratch, sums, nchunks, C,
-                     nchunks, 1);
-  return vfs_check_launch("bn_reduce_partials");
+int vfs_option_bn_ticket = 1;   // capi: vfs_set_option("bn_ticket", 0) = single-workgroup-per-channel-block reduction
+// scratch = [VFS_BN_TICKETS ticket counters (zero before the first use, left zero by every launch)]
+//           [double[G][<=VFS_BN_MAX_CHUNKS][2][C] chunk sums]
+static inline void bn_chunk_plan(int bpg, int* nchunks, int* rpc) {
+  int n = (bpg + 31) / 32;
+  if (n > VFS_BN_MAX_CHUNKS) n = VFS_BN_MAX_CHUNKS;
+  *rpc = (bpg + n - 1) / n;
+  *nchunks = (bpg + *rpc - 1) / *rpc;
 }
-// mode 0: statistics -> bnp + running stats ; mode 1: backward sums -> bsums + dgamma/dbeta
 int vfs_bn_reduce_fused_launch(int mode, const float* partial, double* sums, double* scratch, int G, int bpg, int C,
                                const float* gamma, const float* beta, float* bnp, float* rm, float* rv, double count, float eps,
                                float momentum, float* dgamma, float* dbeta, hipStream_t s) {
   const int cb = (C + 31) / 32;
-  const void* in = partial;
-  int rows = bpg;
-  bool dbl = false;
-  if (bpg > 64 && scratch != nullptr) {   // stage 1: parallel row chunks -> fp64 chunk sums
-    int nchunks = (bpg + 31) / 32;
-    if (nchunks > VFS_BN_MAX_CHUNKS) nchunks = VFS_BN_MAX_CHUNKS;
-    const int rpc = (bpg + nchunks - 1) / nchunks;
-    nchunks = (bpg + rpc - 1) / rpc;
-    hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, nchunks), dim3(256), 0, s, partial, scratch, bpg, C, rpc, nchunks);
-    in = scratch; rows = nchunks; dbl = true;
+  if (vfs_option_bn_ticket && bpg > 64 && scratch != nullptr && cb <= VFS_BN_TICKETS) {   // chunked, single launch (last workgroup finishes)
+    int nchunks, rpc;
+    bn_chunk_plan(bpg, &nchunks, &rpc);
+    unsigned* tickets = reinterpret_cast<unsigned*>(scratch);
+    double* chunks = scratch + VFS_BN_TICKETS / 2;
+    const dim3 grid(cb, G, nchunks);
+    if (mode == 0) hipLaunchKernelGGL((bn_reduce_ticket_kernel<0>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+    else if (mode == 1) hipLaunchKernelGGL((bn_reduce_ticket_kernel<1>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+    else hipLaunchKernelGGL((bn_reduce_ticket_kernel<2>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+    return vfs_check_launch("bn_reduce_ticket");
   }
-  if (mode == 0) {
-    if (dbl) hipLaunchKernelGGL((bn_reduce_fused_kernel<double, 0>), dim3(cb), dim3(256), 0, s, (const double*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-    else hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 0>), dim3(cb), dim3(256), 0, s, (const float*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-  } else {
-    if (dbl) hipLaunchKernelGGL((bn_reduce_fused_kernel<double, 1>), dim3(cb), dim3(256), 0, s, (const double*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-    else hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 1>), dim3(cb), dim3(256), 0, s, (const float*)in, sums, G, rows, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-  }
+  if (mode == 0) hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 0>), dim3(cb), dim3(256), 0, s, partial, sums, G, bpg, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+  else if (mode == 1) hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 1>), dim3(cb), dim3(256), 0, s, partial, sums, G, bpg, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+  else hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, 1), dim3(256), 0, s, partial, sums, bpg, C, bpg, 1);
   return vfs_check_launch("bn_reduce_fused");
+}
+// mode 0: statistics -> bnp + running stats ; mode 1: backward sums -> bsums + dgamma/dbeta ; 2: sums only
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s) {
+  return vfs_bn_reduce_fused_launch(2, partial, sums, scratch, G, bpg, C, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.f, 0.f,
+                                    nullptr, nullptr, s);
 }
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s) {

@@ -26,6 +26,7 @@ int vfs_check_launch(const char* what) {
 
 int vfs_option_halo = 1;
 int vfs_option_stem_blocks = 0;
+extern int vfs_option_bn_ticket;
 int vfs_option_stem_direct = 1;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
@@ -43,6 +44,7 @@ int vfs_abi_version(void) { return 1; }
 int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo")) { vfs_option_halo = value; return VFS_OK; }
   if (!strcmp(name, "stem_blocks")) { vfs_option_stem_blocks = value; return VFS_OK; }
+  if (!strcmp(name, "bn_ticket")) { vfs_option_bn_ticket = value; return VFS_OK; }
   if (!strcmp(name, "stem_direct")) { vfs_option_stem_direct = value; return VFS_OK; }
   return vfs_set_error(VFS_ERR_ARG, "vfs_set_option: unknown option");
 }

@@ -53,6 +53,7 @@ struct BnBwdArgs {
 };
 
 #define VFS_BN_MAX_CHUNKS 128
+#define VFS_BN_TICKETS 64     // 32-bit ticket counters at the head of the BatchNorm reduction scratch (one per 32 channels)
 // stem: BN backward through max-pool + ReLU (bn.hip)
 struct StemBwdArgs {
   const bf16_t* gp;    // [N][Hp][Wp][C] gradient wrt the pooled output

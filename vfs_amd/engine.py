@@ -186,7 +186,14 @@ class Engine:
         return y, Ho, Wo
 
     def bn_scratch(self, G, C, dev):
-        return self.ws('ws.bnred', G * 128 * 2 * C, torch.float64, dev)
+        """scratch of the chunked BatchNorm reductions: 64 ticket counters (must start at zero; every
+        launch leaves them at zero) followed by double[G][128][2][C] chunk sums"""
+        need = 32 + G * 128 * 2 * C
+        t = self.bufs.get('ws.bnred')
+        if t is None or t.numel() < need or t.device != dev:
+            t = torch.zeros(need, dtype=torch.float64, device=dev)
+            self.bufs['ws.bnred'] = t
+        return t
 
     def bn_act(self, u, raw, M, G, train, relu, res=None, rres=None, rbnp=None, tag=''):
         dev = raw.device
