@@ -20,7 +20,8 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0   # dense MFMA peak, MI355X_MICROARCH.md
 
 
 def log(*a):
@@ -154,6 +155,10 @@ def main():
     # every conv launch (events pre-created; only hipEventRecord is added)
     prof, dt_prof = None, None
     if not args.no_roofline:
+        # one stream for this leg: with the weight-gradient kernels running concurrently on the side
+        # stream a per-kernel event pair would time two overlapping kernels, not one
+        side_prev = os.environ.get('VFS_SIDE_STREAM')
+        os.environ['VFS_SIDE_STREAM'] = '0'
         eng.prof = []
         step()
         torch.cuda.synchronize()
@@ -163,6 +168,10 @@ def main():
         dt_prof, _ = timed(args.steps)
         log(f'{args.steps} eager steps with per-kernel events: {dt_prof / args.steps * 1e3:.2f} ms/step')
         prof, eng.prof = eng.prof, None
+        if side_prev is None:
+            os.environ.pop('VFS_SIDE_STREAM')
+        else:
+            os.environ['VFS_SIDE_STREAM'] = side_prev
 
     pairs_per_step = B * T * world
     res = {
@@ -189,14 +198,24 @@ def main():
         tpath = os.path.join(REPO, 'profiles', f'r01_traffic_{args.model}.json')
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get('classes', {}).get(kind, {}).get('hbm_bytes_per_launch')
-        res['roofline'] = {'kernel': kind, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
-                           'algorithmic_flop_per_launch': fl / cnt, 'launches': cnt,
-                           'avg_launch_ms': tm / cnt * 1e3,
-                           'time_share_of_step': tm / dt_prof,
-                           'measured_over': f'{args.steps} eager steps right after the timed region, {dt_prof / args.steps * 1e3:.2f} ms/step',
-                           'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'time_share_of_step': v[1] / dt_prof}
-                                      for k, v in agg.items() if k != kind}}
+        # which roof binds the class: time at the dense bf16 MFMA peak vs time at the HBM peak for the
+        # bytes the PMC passes counted (MI355X_MICROARCH.md: 2.5 PFLOP/s, 8 TB/s)
+        t_launch = tm / cnt
+        t_mfma = fl / cnt / (PEAK_BF16_TFLOPS * 1e12)
+        t_hbm = (traffic or 0.0) / (PEAK_HBM_GBS * 1e9)
+        extra = {'algorithmic_flop_per_launch': fl / cnt, 'launches': cnt, 'avg_launch_ms': t_launch * 1e3,
+                 'time_share_of_step': tm / dt_prof,
+                 'mfma': {'achieved_TFLOP/s': ach, 'frac': ach / PEAK_BF16_TFLOPS},
+                 'hbm': {'achieved_GB/s': (traffic or 0.0) / t_launch / 1e9, 'frac': (traffic or 0.0) / t_launch / 1e9 / PEAK_HBM_GBS},
+                 'measured_over': f'{args.steps} eager single-stream steps right after the timed region, {dt_prof / args.steps * 1e3:.2f} ms/step',
+                 'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'time_share_of_step': v[1] / dt_prof}
+                            for k, v in agg.items() if k != kind}}
+        if t_hbm > t_mfma:
+            res['roofline'] = {'kernel': kind, 'bound': 'hbm', 'achieved': extra['hbm']['achieved_GB/s'], 'peak': PEAK_HBM_GBS,
+                               'unit': 'GB/s', 'frac': extra['hbm']['frac'], 'traffic': traffic, **extra}
+        else:
+            res['roofline'] = {'kernel': kind, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic, **extra}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample) ...')
         res['cpu_baseline'] = cpu_baseline_subprocess(depth, args.size, min(os.cpu_count() or 1, 64))
