@@ -20,8 +20,8 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_BF16_TFLOPS = 2500.0
-PEAK_HBM_GBS = 8000.0   # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E, same guide
 
 
 def log(*a):
