@@ -170,6 +170,15 @@ int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H,
 /* F.one_hot of the resized first-frame label map into the seg bank (vanilla_tracker.py:96-100) */
 int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t stream);
 
+/* ---- DAVIS-2017 semi-supervised J&F (datasets/davis_dataset.py:68-140 -> davis2017.evaluation) -----
+ * pred / gt: uint8 label maps [T][H][W]; frames 1..T-2 are evaluated (first = given, last excluded);
+ * objects 1..nobj (<= 32), gt label 255 = void when use_void; radius = ceil(0.008*||(H,W)||) of the
+ * boundary-match disk.  counts: int32 [T-2][nobj][6] = {|pred&gt|, |pred|gt|, #pred boundary,
+ * #gt boundary, matched pred boundary, matched gt boundary}; scratch: uint32 [2][T-2][H][W].
+ * J = c0/c1 (1 if c1 == 0); F from c2..c5 with the package's empty-boundary conventions. */
+int vfs_davis_counts(const uint8_t* pred, const uint8_t* gt, int* counts, void* scratch, int T, int H, int W,
+                     int nobj, int radius, int use_void, vfs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,3 +12,5 @@ from .sim_loss import CosineSimLoss  # noqa: F401
 from .sim_siam_head import SimSiamHead  # noqa: F401
 from .trackers import BaseTracker, SimSiamBaseTracker, VanillaTracker  # noqa: F401
 from .optim import SGD, build_optimizer  # noqa: F401
+from .davis_eval import DavisEvaluator, evaluate_sequences  # noqa: F401
+from .checkpoint import from_pretrained_keys, to_pretrained_keys  # noqa: F401

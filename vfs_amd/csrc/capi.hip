@@ -262,4 +262,15 @@ int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t st
   return vfs_onehot_launch(labels, out, P, CO, S(stream));
 }
 
+int vfs_davis_counts(const uint8_t* pred, const uint8_t* gt, int* counts, void* scratch, int T, int H, int W, int nobj, int radius,
+                     int use_void, vfs_stream_t stream) {
+  if (T >= 3 && nobj > 0 && (!pred || !gt || !counts || !scratch)) return vfs_set_error(VFS_ERR_ARG, "davis_counts: null buffer");
+  DavisArgs a;
+  a.pred = pred; a.gt = gt; a.counts = counts;
+  a.bp = (unsigned*)scratch;
+  a.bg = scratch ? (unsigned*)scratch + (size_t)(T > 2 ? T - 2 : 0) * H * W : nullptr;
+  a.T = T; a.H = H; a.W = W; a.nobj = nobj; a.radius = radius; a.use_void = use_void;
+  return vfs_davis_counts_launch(a, S(stream));
+}
+
 }  // extern "C"

@@ -151,3 +151,15 @@ int vfs_labelprop_launch(const LabelPropArgs& a, hipStream_t s);
 int vfs_seg_postprocess_launch(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
                                hipStream_t s);
 int vfs_onehot_launch(const uint8_t* lab, float* out, int P, int CO, hipStream_t s);
+
+// DAVIS J&F ingredients (davis.hip)
+struct DavisArgs {
+  const uint8_t* pred;   // [T][H][W] predicted labels
+  const uint8_t* gt;     // [T][H][W] ground-truth labels (255 = void when use_void)
+  unsigned* bp;          // scratch: boundary words of the prediction [T-2][H][W]
+  unsigned* bg;          // scratch: boundary words of the ground truth
+  int* counts;           // [T-2][nobj][6] = inters, union, n_fg, n_gt, fg_match, gt_match
+  int T, H, W, nobj, radius, use_void;
+};
+int vfs_davis_counts_launch(const DavisArgs& a, hipStream_t s);
+
