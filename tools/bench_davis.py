@@ -91,12 +91,33 @@ def main():
     lab = O.label_propagate(feats, seg, (H, W), precede_frames=20, topk=10, temperature=0.07,
                             neighbor_range=int(tc['neighbor_range']), with_first=True, normalize=False)
     mism = float((out[0][:P] != lab).mean())
+    # J&F of the propagated labels against a "ground truth" that keeps the first-frame masks (the clip is
+    # a static scene + noise): exercises the evaluator on the real pipeline; oracle counts on 3 frames
+    from vfs_amd import davis_eval as DE
+    from oracle import davis_jf as OJ
+    gt_clip = np.broadcast_to(seg, (T, H, W)).copy()
+    pred_dev = torch.from_numpy(np.ascontiguousarray(out[0])).to(dev)
+    gt_dev = torch.from_numpy(gt_clip).to(dev)
+    DE.sequence_counts(pred_dev, gt_dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    jf = DE.evaluate_sequences({'synthetic': (pred_dev, gt_dev)})
+    torch.cuda.synchronize()
+    t_eval = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = OJ.sequence_counts(out[0][:5], gt_clip[:5])
+    t_oracle = (time.perf_counter() - t0) / 3
+    counts_equal = bool(np.array_equal(DE.sequence_counts(pred_dev[:5], gt_dev[:5]), want))
     res = {'metric': 'DAVIS label propagation', 'model': f'R{depth}', 'frames': T, 'feature_hw': [h, w], 'C': C,
            'ms_per_frame_end_to_end': dt / (T - 1) * 1e3, 'ms_backbone_per_frame': t_feat / T * 1e3,
            'ms_labelprop_kernel_21_key_frames': t_lp * 1e3, 'key_frames': len(slots),
            'labelprop_algorithmic_TFLOPs': alg_flop / t_lp / 1e12, 'labelprop_frac_of_mfma_peak': alg_flop / t_lp / 2.5e15,
            'label_mismatch_vs_oracle_same_features': mism, 'parity_frames': P - 1,
-           'labels_present': sorted(int(v) for v in np.unique(out[0]))}
+           'labels_present': sorted(int(v) for v in np.unique(out[0])),
+           'jf_eval': {'J&F-Mean': jf['J&F-Mean'], 'J-Mean': jf['J-Mean'], 'F-Mean': jf['F-Mean'],
+                       'ms_per_evaluated_frame_gpu': t_eval / (T - 2) * 1e3,
+                       'ms_per_evaluated_frame_cpu_oracle': t_oracle * 1e3,
+                       'counts_equal_oracle_on_3_frames': counts_equal, 'objects': 2}}
     print(json.dumps(res))
 
 
