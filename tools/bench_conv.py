@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vfs_amd._lib import get_lib  # noqa: E402
+from vfs_amd._lib import VfsLib, get_lib, set_lib  # noqa: E402
 from vfs_amd.packing import wgrad_halo_eligible, wgrad_splits  # noqa: E402
 
 R18 = [  # N, H, W, Cin, Cout, k, stride, pad   (N = 256 frames: 2 views x 32 videos x 4 frames)
@@ -36,6 +36,8 @@ def timeit(fn, iters=20):
 
 
 def main():
+    if os.environ.get('VFS_HIP_LIB'):      # A/B a variant build of the library
+        set_lib(VfsLib(os.environ['VFS_HIP_LIB']))
     lib = get_lib()
     dev = torch.device('cuda:0')
     s = torch.cuda.current_stream().cuda_stream

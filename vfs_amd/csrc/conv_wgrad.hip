@@ -3,22 +3,36 @@
 //   dW[cout][k] = sum_pixels dY[pixel][cout] * G[pixel][k]        (G = implicit im2col of the
 //                                                                   forward input, vfs_conv.h)
 // GEMM view: rows(i) = k-columns (A operand), cols(j) = cout (B operand), reduction = pixels.
-// Both operands live in memory pixel-major (NHWC), i.e. with the REDUCTION index slowest, so the
-// stage transposes while filling LDS: each thread loads 4 pixels x 8 channels (4 x 16 B, rows
-// of 128 B coalesced), regroups them with 16 bit-permutes into 8 channels x 4 pixels and writes
-// 8-byte runs into a [channel][64 pixels] swizzled tile; fragments are then plain ds_read_b128
-// exactly as in the forward kernel.  Split-K over pixel ranges; fp32 partials are summed in a
-// fixed order by wgrad_reduce (deterministic), which also scatters into the reference's OIHW
-// parameter layout.
+// Both operands live in memory pixel-major (NHWC), i.e. with the REDUCTION index slowest.  The stage
+// copies them as they lie (16-byte stores into [pixel][64 channels + pad] LDS tiles) and the MFMA
+// fragments are built with ds_read_b64_tr_b16, the LDS transpose read of gfx950 (as in
+// conv_wgrad_halo.hip) - the first version transposed through VGPRs with 16 bit-permutes and
+// 8-byte LDS stores per lane and ran at a third of the halo kernel's rate.  Split-K over pixel
+// ranges; fp32 partials are summed in a fixed order by wgrad_reduce (deterministic), which also
+// scatters into the reference's OIHW parameter layout.
 #include "vfs_conv.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#define WG_RS 72   // LDS row pitch of a [pixel][64 channels] tile: 144 B (see conv_wgrad_halo.hip)
+// 8 pixels x 16 channels, transposed: returns the 8 pixel values (MFMA k run) of channel (lane&15)
+__device__ __forceinline__ bf16x8 wg_tr_frag(const bf16_t* tile, int lo_off, int hi_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + lo_off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + hi_off));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
 
 template <int BCW, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BKC = 128;        // k-columns per workgroup (two forward K-steps)
   constexpr int TM = 4;           // 64 k-columns per wave
   constexpr int TN = BCW / 32;    // (BCW/2) couts per wave
-  __shared__ __attribute__((aligned(16))) bf16_t sA[2][BKC * 64];
-  __shared__ __attribute__((aligned(16))) bf16_t sD[2][BCW * 64];
+  // pixel-major tiles: per buffer two k-column halves [64 px][64 + pad] and BCW/64 cout tiles
+  constexpr int TILE = 64 * WG_RS, DT = BCW / 64;
+  __shared__ __attribute__((aligned(16))) bf16_t sA[2][2 * TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t sD[2][DT * TILE];
 
   const ConvGeom g = a.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -99,25 +113,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   };
-  auto store_transposed = [&](bf16_t* tile, const u32x4 (&v)[4], int cj, int pg) {
-    const int ch = pg >> 1, half = (pg & 1) * 4;
+  auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned d0 = v[0][q], d1 = v[1][q], d2 = v[2][q], d3 = v[3][q];
-      u32x2 e, o;
-      e.x = (d0 & 0xffffu) | (d1 << 16);
-      e.y = (d2 & 0xffffu) | (d3 << 16);
-      o.x = (d0 >> 16) | (d1 & 0xffff0000u);
-      o.y = (d2 >> 16) | (d3 & 0xffff0000u);
-      const int r0 = cj * 8 + 2 * q;
-      st8(tile + lds_off_t(r0, ch) + half, e);
-      st8(tile + lds_off_t(r0 + 1, ch) + half, o);
+    for (int i = 0; i < 4; ++i) st16(&sA[buf][(a_cj >> 3) * TILE + (a_pg * 4 + i) * WG_RS + a_j * 8], av[i]);
+    if (d_active) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st16(&sD[buf][(d_cj >> 3) * TILE + (d_pg * 4 + i) * WG_RS + (d_cj & 7) * 8], dv[i]);
     }
   };
-  auto store_tiles = [&](int buf) {
-    store_transposed(sA[buf], av, a_cj, a_pg);
-    if (d_active) store_transposed(sD[buf], dv, d_cj, d_pg);
-  };
+  // fragment geometry (conv_wgrad_halo.hip): MFMA k index 8*lq + 4*h + e of k-step ks <-> tile pixel
+  // 32*ks + 16*h + 4*lq + e; a lane points at pixel row pl and its 4-channel run chq
+  const int lr = lane & 15, lq = lane >> 4;
+  const int pl = 4 * lq + (lr >> 2), chq = (lr & 3) * 4;
+  const int a_base = wm * TILE + pl * WG_RS + chq;                                   // wave = k-column half wm
+  const int d_base = (BCW == 128 ? wn * TILE : wn * 32) + pl * WG_RS + chq;          // 64 (or 32) couts of the wave
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -132,12 +141,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int cur = it & 1;
     const bool more = it + 1 < iters;
     if (more) load_tiles(it + 1);
-    mma_kstep<TM, TN, true>(sA[cur], sD[cur], wm * 64, wn * (BCW / 2), lane, acc);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        af[tm] = wg_tr_frag(sA[cur] + a_base, (32 * ks) * WG_RS + tm * 16, (32 * ks + 16) * WG_RS + tm * 16);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        bfr[tn] = wg_tr_frag(sD[cur] + d_base, (32 * ks) * WG_RS + tn * 16, (32 * ks + 16) * WG_RS + tn * 16);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-  const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int cout = cb * BCW + wn * (BCW / 2) + tn * 16 + lr;
