@@ -61,6 +61,16 @@ int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* sta
 int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, int N,
                    int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                    int pad, vfs_stream_t stream);
+/* the same input gradient, plus the BatchNorm-backward statistics of the unit whose OUTPUT this gradient
+ * belongs to, from the epilogue (saves bn_bwd_reduce's pass over dx): bn_partial float[ceil(M/128)][2][Cin]
+ * rows {sum g*mask, sum g*mask*xhat} per 128 output pixels, M = N*H*W; bn_x = that unit's raw conv output
+ * [M][Cin], bn_y its activation for the ReLU mask (residual units) or NULL (bn_relu: mask recomputed
+ * from bn_x), bnp float[G][4][Cin], bn_mpg pixels per group (multiple of 128).  stride 1 only.
+ * Feed bn_partial to vfs_bn_bwd_sums_paramgrad / vfs_bn_reduce_partials with bpg = bn_mpg/128. */
+int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add,
+                      const vfs_bf16* bn_x, const vfs_bf16* bn_y, const float* bnp, float* bn_partial,
+                      int bn_mpg, int bn_relu, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                      int KW, int stride, int pad, vfs_stream_t stream);
 /* wgrad: grad[Cout][Cin][KH][KW] (fp32, reference OIHW layout) += sum_pixels dy * im2col(x).
  * partial: workspace float[nsplit][Cout][KH*KW*Cin]; pix_per_split % 64 == 0 and
  * nsplit*pix_per_split >= N*Ho*Wo.  Deterministic (fixed-order split-K reduction). */

@@ -107,6 +107,59 @@ def test_pack_weights_ragged(backend, shape):
         assert torch.equal(wd.float().cpu(), rb(w0).permute(1, 2, 3, 0))
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,G', [
+    (2, 16, 32, 128, 64, 3, 2),     # halo dgrad, 128 output channels, two statistics groups
+    (4, 32, 32, 64, 64, 3, 2),      # halo dgrad, 64 output channels: 16x16 tiles, two rows per tile
+    (4, 8, 8, 128, 128, 3, 2),      # halo dgrad on whole 8x8 images (two per tile)
+    (3, 7, 7, 128, 64, 1, 1),       # generic kernel, ragged M = 147
+    (2, 8, 8, 64, 128, 1, 1),       # generic kernel, 64 output channels (32-channel waves)
+])
+@pytest.mark.parametrize('mask', ['y', 'relu', 'none'])
+def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, mask):
+    """vfs_conv_dgrad_bn: the input gradient is bit-identical to vfs_conv_dgrad, and the partial rows
+    {sum g*mask, sum g*mask*xhat} summed per group equal what bn_bwd_reduce computes from the stored
+    gradient (fp32 sums: 1e-4 relative)."""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N * 7 + Cin + k)
+    pad = k // 2
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    _, wd = pack(backend, w)
+    dy = d(nhwc(rb(torch.randn(N, Cout, H, W, generator=g))))
+    add = d(nhwc(rb(torch.randn(N, Cin, H, W, generator=g))))
+    x = rb(torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.3)           # raw conv output of the producer unit
+    M = N * H * W
+    mpg = M // G
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    xf = x.float().reshape(G, mpg, Cin)
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * inv
+    bnp = torch.stack([scale, beta - mean * scale, mean, inv], 1).contiguous()    # [G][4][C]
+    y = rb(torch.relu(x.float() * scale.repeat_interleave(mpg, 0).reshape(N, H, W, Cin)
+                      + (beta - mean * scale).repeat_interleave(mpg, 0).reshape(N, H, W, Cin)
+                      + 0.5 * torch.randn(N, H, W, Cin, generator=g)))
+    dx0 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+    lib.conv_dgrad(dy, wd, dx0, add, N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+    nblk = (M + 127) // 128
+    partial = torch.full((nblk, 2, Cin), float('nan'), device=dev)
+    dx1 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+    lib.conv_dgrad_bn(dy, wd, dx1, add, d(x.to(torch.bfloat16)), d(y.to(torch.bfloat16)) if mask == 'y' else None, d(bnp), partial, mpg, 1 if mask == 'relu' else 0,
+                      N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+    assert torch.equal(dx1.cpu(), dx0.cpu())
+    gq = dx0.float().cpu().reshape(G, mpg, Cin).double()
+    xq = x.float().reshape(G, mpg, Cin).double()
+    if mask == 'y':
+        gq = gq * (y.float().reshape(G, mpg, Cin) > 0)
+    elif mask == 'relu':
+        act = x.float().reshape(G, mpg, Cin) * scale[:, None] + (beta - mean * scale)[:, None]
+        gq = gq * (act > 0)
+    xh = ((x.float().reshape(G, mpg, Cin) - mean[:, None]) * inv[:, None]).double()
+    want1, want2 = gq.sum(1), (gq * xh).sum(1)
+    st = partial.cpu().double().reshape(G, nblk // G if G > 1 else nblk, 2, Cin).sum(1)
+    assert torch.allclose(st[:, 0], want1, rtol=1e-4, atol=2e-2), (st[:, 0] - want1).abs().max()
+    assert torch.allclose(st[:, 1], want2, rtol=1e-4, atol=2e-2), (st[:, 1] - want2).abs().max()
+
+
 BIG_CASES = [  # the layer shapes of the bench configs (per-GPU batch reduced), ragged M included
     (8, 64, 64, 64, 64, 3, 1, 1),      # R18 layer1 @256
     (8, 64, 64, 64, 128, 3, 2, 1),     # R18 layer2.0.conv1

@@ -62,7 +62,7 @@ int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float
                  int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
   ConvArgs a;
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
-  a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout;
+  a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
   return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
 }
 
@@ -71,7 +71,7 @@ int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* sta
   if (Wp & 1) return vfs_set_error(VFS_ERR_SHAPE, "stem_fwd: padded width must be even");
   ConvArgs a;
   a.g = make_geom(N, H, Wp, 4, Ho, Wo, 7, 7, 2, 3, 256);
-  a.src = x4; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = nullptr; a.stats = stats; a.Cout = 64;
+  a.src = x4; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = nullptr; a.stats = stats; a.Cout = 64; a.bn = BnBwdFuse{};
   if (vfs_option_stem_direct && (size_t)N * H * Wp * 8 < 0xFFFFFFF0ull) return vfs_stem_fwd_direct_launch(a, S(stream));
   return vfs_conv_igemm_dispatch(a, GATHER_STEM, S(stream));
 }
@@ -81,7 +81,20 @@ int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const v
   // gather source = dy [N,Ho,Wo,Cout]; destination grid = dx [N,H,W,Cin]
   ConvArgs a;
   a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
+  a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin; a.bn = BnBwdFuse{};
+  return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
+}
+int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const vfs_bf16* bn_x,
+                      const vfs_bf16* bn_y, const float* bnp, float* bn_partial, int bn_mpg, int bn_relu, int N, int H, int W,
+                      int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+  if (stride != 1) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: stride 1 only (strided dgrads run per parity class)");
+  if (!bn_x || !bnp || !bn_partial || bn_mpg <= 0) return vfs_set_error(VFS_ERR_ARG, "conv_dgrad_bn: null statistics operand");
+  const long long M = (long long)N * H * W;
+  if (bn_mpg < M && bn_mpg % 128) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: groups must be multiples of 128 pixels");
+  ConvArgs a;
+  a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
   a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin;
+  a.bn.x = bn_x; a.bn.y = bn_y; a.bn.bnp = bnp; a.bn.partial = bn_partial; a.bn.mpg = bn_mpg; a.bn.relu = bn_relu;
   return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
 }
 

@@ -44,8 +44,9 @@ __device__ __forceinline__ void halo_pixel(int wp, int tn, int lr, int& ti, int&
 
 // ---------------- epilogue shared by the halo kernels ----------------
 // acc[tm][tn]: wave tile of 64 channels (wc) x 64 pixels (wp).  F = compile-time superset of
-// {1: BatchNorm partial statistics, 2: residual add, 4: bias}: the three combinations the training step
-// uses get branch-free bodies, anything else the runtime-checked one.  sRed: [WAVES_P][2][BC] floats.
+// {1: BatchNorm partial statistics, 2: residual add, 4: bias, 8: fused BatchNorm-BACKWARD statistics of
+// the output (BnBwdFuse, dgrad)}: the combinations the training step uses get branch-free bodies,
+// anything else the runtime-checked one.  sRed: [WAVES_P][2][BC] floats.
 //
 // The MFMA accumulator layout gives a lane 4 channels (8 bytes) of one pixel per tile; storing that
 // directly is 16 dwordx2 stores per lane in 32-byte fragments - store-ISSUE bound (measured: the
@@ -64,6 +65,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
   const bool do_stats = (F & 1) && a.stats != nullptr;
   const bool do_add = (F & 2) && a.add != nullptr;
   const bool do_bias = (F & 4) && a.bias != nullptr;
+  const bool do_bn = (F & 8) && a.bn.partial != nullptr;
   const int lane = t & 63;
   bf16_t* slab = stage + (t >> 6) * HALO_STAGE_WAVE;
   float s1[TM][4], s2[TM][4];
@@ -71,6 +73,21 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
+  // fused BatchNorm-backward statistics: this lane's eight (pixel, 8-channel chunk) operands are
+  // requested NOW, before the accumulators are converted and staged, and consumed in the row-store loop
+  u32x4 bxv[8], byv[8];
+  if (do_bn) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = i * 8 + (lane >> 3);
+      int ti, py, px;
+      halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
+      const size_t o = (((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px)) * a.Cout + c0 + wc * 64 + (lane & 7) * 8;
+      bxv[i] = ld16(a.bn.x + o);
+      if (a.bn.y) byv[i] = ld16(a.bn.y + o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     u32x2 ad[TM];
@@ -108,13 +125,38 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
   }
   __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
   // whole pixel rows out: lane = (pixel p = 8 i + lane/8, 16-byte chunk lane%8)
+  BnFuseLane bl;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int p = i * 8 + (lane >> 3), ch = lane & 7;
     int ti, py, px;
     halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
     const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
-    st16(a.out + mdst * a.Cout + c0 + wc * 64 + ch * 8, ld16(&slab[p * HALO_STAGE_ROW + ch * 8]));
+    const size_t o = mdst * a.Cout + c0 + wc * 64 + ch * 8;
+    const u32x4 gv = ld16(&slab[p * HALO_STAGE_ROW + ch * 8]);
+    st16(a.out + o, gv);
+    if (do_bn) {
+      if (i == 0) bnfuse_init(bl, a.bn, a.Cout, (int)(mdst / a.bn.mpg), c0 + wc * 64 + ch * 8);
+      bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);
+    }
+  }
+  if (do_bn) {
+    // lanes lane%8 == ch hold partial sums of the same 8 channels for 8 different pixel groups: meet in
+    // LDS behind the output slabs, then one row of {S1, S2} per 128 pixels (= per pair of pixel waves)
+    float* sB = reinterpret_cast<float*>(stage + 4 * HALO_STAGE_WAVE);
+    bnfuse_spill(bl, sB, t >> 6, lane >> 3, 8, 64, lane & 7);
+    __syncthreads();
+    for (int e = t; e < WAVES_P * BC; e += 256) {
+      const int h = e / (2 * BC), rem = e - h * 2 * BC, st = rem / BC, cl = rem - st * BC;
+      float sum = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        const int wave = (cl >> 6) * WAVES_P + 2 * h + w2;
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) sum += sB[((size_t)(wave * 8 + grp) * 2 + st) * 64 + (cl & 63)];
+      }
+      a.bn.partial[((size_t)tile * (WAVES_P / 2) + h) * 2 * a.Cout + st * a.Cout + c0 + cl] = sum;
+    }
   }
   if (do_stats) {
     // lanes of one DPP row hold the same channels for 16 different pixels: VALU row reduction, then
@@ -145,11 +187,13 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
 template <int BC, bool SMALLW>
 __device__ __forceinline__ void halo_epilogue_dispatch(const ConvArgs& a, const f32x4 (&acc)[4][4], float* sRed, bf16_t* stage,
                                                        int tile, int tn0, int y0, int x0, int c0, int wc, int wp, int lr, int lq, int t) {
-  const int flags = (a.stats ? 1 : 0) | (a.add ? 2 : 0) | (a.bias ? 4 : 0);
+  const int flags = (a.stats ? 1 : 0) | (a.add ? 2 : 0) | (a.bias ? 4 : 0) | (a.bn.partial ? 8 : 0);
   if (flags == 1) halo_epilogue<1, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
   else if (flags == 2) halo_epilogue<2, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
   else if (flags == 0) halo_epilogue<0, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
-  else halo_epilogue<7, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 8) halo_epilogue<8, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 10) halo_epilogue<10, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else halo_epilogue<15, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
 
 template <int BC, bool DGRAD, bool SMALLW>
@@ -164,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   // one arena: [patch | 2 weight tiles]; after the last tap the epilogue re-uses it as output stage
   __shared__ __attribute__((aligned(16))) bf16_t smem[PROWS * RS + 2 * BC * RS];
   __shared__ __attribute__((aligned(16))) float sRed[WAVES_P][2][BC];
-  static_assert(PROWS * RS + 2 * BC * RS >= 4 * HALO_STAGE_WAVE, "output stage does not fit");
+  static_assert((PROWS * RS + 2 * BC * RS) * 2 >= 4 * HALO_STAGE_WAVE * 2 + 4 * 8 * 2 * 64 * 4, "output stage + statistics do not fit");
   bf16_t* const sP = smem;
   bf16_t* const sW = smem + PROWS * RS;
 

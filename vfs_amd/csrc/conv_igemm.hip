@@ -205,6 +205,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
+  // fused BatchNorm-backward statistics of the output (vfs_conv.h): the lane's operand rows are requested
+  // NOW (one HBM round trip overlapped with the staging below), consumed in the row-store loop
+  constexpr int CPR = WC / 8, PPI = 64 / CPR;     // 16-byte chunks per staged row, pixels per store instruction
+  const bool do_bn = a.bn.partial != nullptr;
+  BnFuseLane bl;
+  u32x4 bxv[CPR], byv[CPR];
+  if (do_bn && c0 + wc * WC + (lane % CPR) * 8 < a.Cout) {
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) {
+      const int m = m0 + wp * 64 + i * PPI + lane / CPR;
+      const size_t o = (size_t)(m < Mc ? m : m0) * a.Cout + c0 + wc * WC + (lane % CPR) * 8;
+      bxv[i] = ld16(a.bn.x + o);
+      if (a.bn.y) byv[i] = ld16(a.bn.y + o);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -239,12 +255,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
   __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
   {
-    constexpr int CPR = WC / 8, PPI = 64 / CPR;   // 16-byte chunks per staged row, pixels per store instruction
+    const int ch = lane % CPR, c = c0 + wc * WC + ch * 8;
+    if (do_bn && c < a.Cout) bnfuse_init(bl, a.bn, a.Cout, (m0 + wp * 64) / a.bn.mpg, c);
 #pragma unroll
     for (int i = 0; i < CPR; ++i) {
-      const int p = i * PPI + lane / CPR, ch = lane % CPR;
-      const int m = m0 + wp * 64 + p, c = c0 + wc * WC + ch * 8;
-      if (m < Mc && c < a.Cout) st16(a.out + pixel_dst(m) * a.Cout + c, ld16(&slab[p * SROW + ch * 8]));
+      const int p = i * PPI + lane / CPR;
+      const int m = m0 + wp * 64 + p;
+      if (m < Mc && c < a.Cout) {
+        const size_t o = pixel_dst(m) * a.Cout + c;
+        const u32x4 gv = ld16(&slab[p * SROW + ch * 8]);
+        st16(a.out + o, gv);
+        if (do_bn) bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);
+      }
+    }
+    if (do_bn) {   // uniform: one {S1, S2} row per 128-pixel workgroup, summed over pixel groups and the two pixel waves
+      float* sB = reinterpret_cast<float*>(smem + 4 * 64 * SROW);
+      static_assert((2 * BC * 64 + 2 * BP * 64) * 2 >= 4 * 64 * SROW * 2 + 4 * PPI * 2 * WC * 4, "statistics do not fit");
+      if (c >= a.Cout) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { bl.s1[k] = 0.f; bl.s2[k] = 0.f; }
+      }
+      bnfuse_spill(bl, sB, wave, lane / CPR, PPI, WC, ch);
+      __syncthreads();
+      for (int e = t; e < 2 * BC; e += 256) {
+        const int st = e / BC, cl = e - st * BC;
+        if (c0 + cl >= a.Cout) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const int wv = (cl / WC) * 2 + w2;
+          for (int grp = 0; grp < PPI; ++grp) sum += sB[((size_t)(wv * PPI + grp) * 2 + st) * WC + (cl % WC)];
+        }
+        a.bn.partial[(size_t)pb * 2 * a.Cout + st * a.Cout + c0 + cl] = sum;
+      }
     }
   }
   if (do_stats) {
@@ -293,6 +336,8 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
   if (mode != GATHER_STEM && a.g.KH * a.g.KW > 32) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: more than 32 taps");
   if ((size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 >= 0xFFFFFFF0ull || (size_t)a.Cout * a.g.Ktot * 2 >= 0xFFFFFFF0ull)
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: tensor >= 4 GiB (split the batch)");
+  if (a.bn.partial && (mode != GATHER_DGRAD || a.g.stride != 1))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: fused BatchNorm-backward statistics need a stride-1 dgrad");
   const bool wide = (a.Cout % 128 == 0);
   switch (mode) {
     case GATHER_FWD:

@@ -25,6 +25,20 @@ struct ConvGeom {
   int M;            // N*Ho*Wo
 };
 
+// BatchNorm-backward statistics fused into the epilogue of the dgrad that PRODUCES the gradient g (the
+// conv's output): per 128-pixel block  S1[c] = sum g*mask,  S2[c] = sum g*mask*xhat  with
+// xhat = (x - mean)*invstd of the BatchNorm unit whose output this gradient belongs to - what
+// bn_bwd_reduce_kernel computes in a separate pass over g and x.  mask: y > 0 (residual units, y given),
+// x*scale+shift > 0 (plain conv-BN-ReLU units, relu = 1), or none.  partial == nullptr: disabled.
+struct BnBwdFuse {
+  const bf16_t* x;     // [M][Cout] raw conv output of that unit
+  const bf16_t* y;     // [M][Cout] its activation (mask) or null
+  const float* bnp;    // [G][4][Cout] scale, shift, mean, invstd
+  float* partial;      // [ceil(M/128)][2][Cout]
+  int mpg;             // pixels per statistics group (selects the bnp row; blocks never straddle groups)
+  int relu;
+};
+
 struct ConvArgs {
   ConvGeom g;
   const bf16_t* src;   // gather source
@@ -34,6 +48,7 @@ struct ConvArgs {
   const float* bias;   // optional [Cout]
   float* stats;        // optional [num_pixel_blocks][2][Cout]
   int Cout;
+  BnBwdFuse bn;        // optional fused BatchNorm-backward statistics of the OUTPUT (dgrad only)
 };
 
 struct WgradArgs {
@@ -148,6 +163,54 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // variant for tiles filled by the transposing wgrad stage (rows written with stride 8)
 __device__ __forceinline__ int lds_off_t(int row, int chunk) {
   return row * 64 + ((chunk ^ (((row >> 1) ^ (row >> 4)) & 7)) << 3);
+}
+
+// ---- fused BatchNorm-backward statistics (BnBwdFuse): per-lane pieces used by the epilogues.
+// A lane owns one 8-channel chunk for all the pixel rows it stores; coefficients stay in registers.
+struct BnFuseLane {
+  float sc[8], sh[8], mean[8], inv[8], s1[8], s2[8];
+};
+__device__ __forceinline__ void bnfuse_init(BnFuseLane& L, const BnBwdFuse& bn, int Cout, int gi, int c) {
+  const float* bp = bn.bnp + (size_t)gi * 4 * Cout + c;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(bp + 4 * h), b = *reinterpret_cast<const f32x4*>(bp + Cout + 4 * h);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(bp + 2 * Cout + 4 * h), v = *reinterpret_cast<const f32x4*>(bp + 3 * Cout + 4 * h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { L.sc[4 * h + i] = a[i]; L.sh[4 * h + i] = b[i]; L.mean[4 * h + i] = m[i]; L.inv[4 * h + i] = v[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { L.s1[i] = 0.f; L.s2[i] = 0.f; }
+}
+// gv: the 8 gradient values just stored for one pixel; xv / yv: the unit's raw output / activation at the
+// same place (loaded by the caller EARLY: issued next to the use, each load costs a full HBM round trip
+// per tile and the fusion is no faster than the separate reduction pass)
+__device__ __forceinline__ void bnfuse_accum(BnFuseLane& L, const BnBwdFuse& bn, u32x4 gv, u32x4 xv, u32x4 yv) {
+  float g[8], x[8];
+  unpack8(gv, g);
+  unpack8(xv, x);
+  if (bn.y) {
+    float y[8];
+    unpack8(yv, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+  } else if (bn.relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = (x[i] * L.sc[i] + L.sh[i] > 0.f) ? g[i] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    L.s1[i] += g[i];
+    L.s2[i] += g[i] * ((x[i] - L.mean[i]) * L.inv[i]);
+  }
+}
+// lane -> LDS [wave][pixel group][stat][WCH channels]; the caller syncs and sums groups / pixel waves
+__device__ __forceinline__ void bnfuse_spill(const BnFuseLane& L, float* sB, int wave, int grp, int ngrp, int wch, int ch) {
+  float* d = sB + ((size_t)(wave * ngrp + grp) * 2) * wch + ch * 8;
+  *reinterpret_cast<f32x4*>(d) = (f32x4){L.s1[0], L.s1[1], L.s1[2], L.s1[3]};
+  *reinterpret_cast<f32x4*>(d + 4) = (f32x4){L.s1[4], L.s1[5], L.s1[6], L.s1[7]};
+  *reinterpret_cast<f32x4*>(d + wch) = (f32x4){L.s2[0], L.s2[1], L.s2[2], L.s2[3]};
+  *reinterpret_cast<f32x4*>(d + wch + 4) = (f32x4){L.s2[4], L.s2[5], L.s2[6], L.s2[7]};
 }
 
 // one 64-deep K-step of MFMAs for a wave: acc[tm][tn] += A(rowsA + tm*16) x B(rowsB + tn*16)

@@ -219,7 +219,12 @@ class Engine:
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
         rl = 1 if relu else 0
-        lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, rl, s)
+        fused = getattr(self, '_fused_bn', None)
+        self._fused_bn = None
+        if fused is not None and fused[0] is u:     # the producing dgrad already emitted the statistics rows
+            partial, nblk = fused[1], fused[2]
+        else:
+            lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, rl, s)
         self._bwd_sums(u, partial, G, nblk // G, C, dev)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
@@ -297,8 +302,11 @@ class Engine:
                        x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
                        N // G, count, nblocks, self.stream(dev))
 
-    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None):
-        """weight (and bias) gradients accumulate into .grad; returns the input gradient or None."""
+    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None, bn_next=None):
+        """weight (and bias) gradients accumulate into .grad; returns the input gradient or None.
+        bn_next = (unit, raw, ymask, relu, G): the BatchNorm unit whose backward consumes the input
+        gradient; for stride-1 convs the dgrad epilogue also emits that unit's backward statistics
+        (vfs_conv_dgrad_bn) and the following bn_bwd skips its reduce pass."""
         dev = dx.device
         s = self.stream(dev)
         lib = self.lib
@@ -326,6 +334,19 @@ class Engine:
         if not need_dgrad:
             return None
         gin = g_out if g_out is not None else self.buf(f'{u.name}.gin', (N, H, W, u.cin), BF16, dev)
+        self._fused_bn = None
+        if bn_next is not None and u.stride == 1 and os.environ.get('VFS_BN_FUSE', '1') == '1':
+            pu, praw, pymask, prelu, G = bn_next
+            Min = N * H * W
+            mpg = Min // G
+            if G == 1 or mpg % 128 == 0:
+                nblk = (Min + 127) // 128
+                partial = self.ws('ws.bnbwd_fused', nblk * 2 * u.cin, torch.float32, dev)
+                self.timed('conv_igemm', flops, dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,
+                           mpg, 1 if (prelu and pymask is None) else 0, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k,
+                           u.stride, u.pad, s)
+                self._fused_bn = (pu, partial, nblk)
+                return gin
         self.timed('conv_igemm', flops, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
                    u.k, u.k, u.stride, u.pad, s)
         return gin

@@ -311,7 +311,10 @@ class ResNet(nn.Module):
                     raise NotImplementedError('gradients at several stages')  # not on the VFS path
             if g is None:
                 continue
-            g = self._block_bwd(eng, blocks[i], g, N, G)
+            # the BatchNorm unit that consumes this block's INPUT gradient: the join unit of the block before
+            prev = blocks[i - 1] if i > 0 else None
+            next_bn = None if prev is None else (prev['blk'].convs[-1].unit, prev['raws'][-1], prev['out'])
+            g = self._block_bwd(eng, blocks[i], g, N, G, next_bn)
             if on_stage_done is not None and i in stage_start:
                 on_stage_done(getattr(self, self.res_layers[stage_start[i]]))
         # stem: maxpool+relu backward -> BN backward -> wgrad
@@ -330,7 +333,9 @@ class ResNet(nn.Module):
         if on_stage_done is not None:
             on_stage_done(self.conv1)
 
-    def _block_bwd(self, eng, bctx, g, N, G):
+    def _block_bwd(self, eng, bctx, g, N, G, next_bn=None):
+        """next_bn = (unit, raw, out) of the preceding block's join: the dgrad that completes this block's
+        input gradient also emits that unit's BatchNorm-backward statistics (Engine.conv_bwd)."""
         blk = bctx['blk']
         convs = blk.convs
         last = len(convs) - 1
@@ -346,7 +351,13 @@ class ResNet(nn.Module):
             ih, iw, oh, ow = bctx['dims'][ci]
             x_in = bctx['x'] if ci == 0 else bctx['acts'][ci - 1]
             add = gm if (ci == 0 and blk.downsample is None) else None
-            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add)
+            if ci > 0:       # plain conv-BN-ReLU unit in front: its statistics come out of this dgrad
+                bn_next = (convs[ci - 1].unit, bctx['raws'][ci - 1], None, True, G)
+            elif blk.downsample is None and next_bn is not None:
+                bn_next = (next_bn[0], next_bn[1], next_bn[2], True, G)
+            else:
+                bn_next = None
+            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add, bn_next=bn_next)
             if ci > 0:
                 p = convs[ci - 1]
                 _, _, ph, pw = bctx['dims'][ci - 1]
@@ -354,7 +365,8 @@ class ResNet(nn.Module):
         if blk.downsample is not None:
             d = blk.downsample
             boh, bow = bctx['dims'][last][2:]
-            gin = eng.conv_bwd(d.unit, ddx, bctx['x'], N, h, w, boh, bow, need_dgrad=True, add=gin, g_out=gin)
+            bn_next = None if next_bn is None else (next_bn[0], next_bn[1], next_bn[2], True, G)
+            gin = eng.conv_bwd(d.unit, ddx, bctx['x'], N, h, w, boh, bow, need_dgrad=True, add=gin, g_out=gin, bn_next=bn_next)
         return gin
 
     # ------------------------------------------------------------------ module-level forward
