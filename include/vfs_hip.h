@@ -108,9 +108,10 @@ int vfs_bn_eval_params(const float* gamma, const float* beta, const float* runni
 int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres,
                const float* rbnp, vfs_bf16* y, long long M, int C, int mpg, int relu,
                vfs_stream_t stream);
-/* stem: y = maxpool3x3/2/1(relu(bn(x)))  (resnet.py:435), idx = argmax code per element */
-int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, int N, int H,
-                        int W, int C, int Hp, int Wp, int npg, vfs_stream_t stream);
+/* stem: y = maxpool3x3/2/1(relu(bn(x)))  (resnet.py:435), idx = argmax code per element; xpool
+ * (optional) = the RAW x at each argmax: the BatchNorm backward of the stem then never re-reads x */
+int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, vfs_bf16* xpool,
+                        int N, int H, int W, int C, int Hp, int Wp, int npg, vfs_stream_t stream);
 int vfs_maxpool_relu_bwd(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, vfs_bf16* ga,
                          int N, int H, int W, int C, int Hp, int Wp, vfs_stream_t stream);
 /* BN backward: pass 1 -> partial[nblk][2][C] (S1 = sum gm, S2 = sum gm*xhat, gm = g*mask);
@@ -128,8 +129,9 @@ int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, in
  * (same results as vfs_maxpool_relu_bwd followed by vfs_bn_bwd_reduce / vfs_bn_bwd_apply);
  * pass 1 -> partial[ceil(N*Hp*Wp/ppb)][2][C], pass 2 -> dx[N][H][W][C] */
 int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx,
-                                const vfs_bf16* x, const float* bnp, float* partial, int N, int H, int W,
-                                int C, int Hp, int Wp, int npg, int ppb, vfs_stream_t stream);
+                                const vfs_bf16* x, const vfs_bf16* xpool, const float* bnp, float* partial,
+                                int N, int H, int W, int C, int Hp, int Wp, int npg, int ppb,
+                                vfs_stream_t stream); /* xpool (from vfs_bn_relu_maxpool) replaces the gather from x */
 /* stem weight gradient with the BN-backward apply pass folded into its operand load (the
  * full-resolution dx is never materialised): grad[64][3][7][7] += ...; partial: float[nblocks][64][224],
  * nblocks = ceil(ntiles / ceil(ntiles / nblocks)) with ntiles = N*ceil(Ho/8)*ceil(Wo/16) */

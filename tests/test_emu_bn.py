@@ -136,7 +136,7 @@ def test_stem_bn_relu_maxpool_fwd_bwd(backend):
     Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty(N, Hp, Wp, C, dtype=torch.bfloat16)
     idx = torch.empty(N, Hp, Wp, C, dtype=torch.uint8)
-    lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, N, H, W, C, Hp, Wp, N, None)
+    lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, None, N, H, W, C, Hp, Wp, N, None)
     a = rb(F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5)))
     a.requires_grad_(True)
     ref = F.max_pool2d(a, 3, 2, 1)
@@ -231,7 +231,8 @@ def test_stem_pool_bn_bwd_fused_equals_unfused(backend):
     Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty(N, Hp, Wp, C, dtype=torch.bfloat16)
     idx = torch.empty(N, Hp, Wp, C, dtype=torch.uint8)
-    lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, N, H, W, C, Hp, Wp, N // G, None)
+    xpool = torch.empty(N, Hp, Wp, C, dtype=torch.bfloat16)
+    lib.bn_relu_maxpool(nhwc(x), bnp, y, idx, xpool, N, H, W, C, Hp, Wp, N // G, None)
     gp = nhwc(rb(torch.randn(N, C, Hp, Wp, generator=g)))
     scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)   # ticket counters + chunk sums
     M = N * H * W
@@ -249,7 +250,10 @@ def test_stem_pool_bn_bwd_fused_equals_unfused(backend):
     P = N * Hp * Wp
     ppb2 = 24
     partial2 = torch.zeros(P // ppb2, 2, C)
-    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(x), bnp, partial2, N, H, W, C, Hp, Wp, N // G, ppb2, None)
+    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(x), None, bnp, partial2, N, H, W, C, Hp, Wp, N // G, ppb2, None)
+    partial3 = torch.zeros_like(partial2)
+    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(x), xpool, bnp, partial3, N, H, W, C, Hp, Wp, N // G, ppb2, None)
+    assert torch.allclose(partial3, partial2, rtol=1e-5, atol=1e-4)    # pooled-raw stream == gather from raw
     sums2 = torch.zeros(G, 2, C, dtype=torch.float64)
     lib.bn_reduce_partials(partial2, sums2, scratch, G, (P // ppb2) // G, C, None)
     # the fused pass sums the per-window contributions before any bf16 rounding of the accumulated
@@ -277,12 +281,12 @@ def test_stem_wgrad_fused_equals_unfused_chain(backend):
     bnp, mpg = bn_forward_chain(lib, nhwc(raw), gamma, beta, G, torch.zeros(64), torch.ones(64))
     y = torch.empty(N, Hp, Wp, 64, dtype=torch.bfloat16)
     idx = torch.empty(N, Hp, Wp, 64, dtype=torch.uint8)
-    lib.bn_relu_maxpool(nhwc(raw), bnp, y, idx, N, Ho, Wo, 64, Hp, Wp, N // G, None)
+    lib.bn_relu_maxpool(nhwc(raw), bnp, y, idx, None, N, Ho, Wo, 64, Hp, Wp, N // G, None)
     gp = nhwc(rb(torch.randn(N, 64, Hp, Wp, generator=g)))
     P = N * Hp * Wp
     ppb = P // G
     partial = torch.zeros(P // ppb, 2, 64)
-    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(raw), bnp, partial, N, Ho, Wo, 64, Hp, Wp, N // G, ppb, None)
+    lib.stem_pool_bn_bwd_reduce(gp, y, idx, nhwc(raw), None, bnp, partial, N, Ho, Wo, 64, Hp, Wp, N // G, ppb, None)
     sums = torch.zeros(G, 2, 64, dtype=torch.float64)
     lib.bn_reduce_partials(partial, sums, None, G, (P // ppb) // G, 64, None)
     count = float(mpg)

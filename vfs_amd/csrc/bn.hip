@@ -364,12 +364,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
     const int hp = (int)(p % (unsigned)a.Hp);
     const int n = (int)(p / (unsigned)a.Hp);
     const int gi = n / a.npg;
-    float sc[8], sh[8], best[8];
+    float sc[8], sh[8], best[8], xb[8];
     int bi[8];
     ld8f(a.bnp + (size_t)gi * 4 * a.C + c, sc);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+    for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; xb[i] = 0.f; }
     for (int dy = 0; dy < 3; ++dy) {
       const int h = 2 * hp - 1 + dy;
       if ((unsigned)h >= (unsigned)a.H) continue;
@@ -381,12 +381,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float val = round_bf(fmaxf(x[i] * sc[i] + sh[i], 0.f));  // pool the STORED (bf16) activation
-          if (val > best[i]) { best[i] = val; bi[i] = dy * 3 + dx; }
+          if (val > best[i]) { best[i] = val; bi[i] = dy * 3 + dx; xb[i] = x[i]; }
         }
       }
     }
     const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
     st16(a.y + o, pack8(best));
+    if (a.xpool) st16(a.xpool + o, pack8(xb));   // exact: x is bf16 already
     if (a.idx) {
       u32x2 pk;
       pk.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
@@ -581,6 +582,37 @@ __global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(StemBwdArg
   if (rt < rows) {
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 2 * a.C + c, mean);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
+    if (a.xp) {
+      // raw x at the argmax was saved by the forward pooling kernel: a pure stream over three pooled
+      // tensors (pooled pixels are linear in memory), four rows in flight per lane
+      for (int r = rt; r < a.ppb; r += 4 * rows) {
+        u32x4 gv[4], yv[4], xv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long p = p0 + r + u * rows;
+          ok[u] = (r + u * rows < a.ppb) && p < P;
+          const size_t o = (size_t)(ok[u] ? p : p0) * a.C + c;
+          gv[u] = ld16(a.gp + o);
+          yv[u] = ld16(a.yp + o);
+          xv[u] = ld16(a.xp + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          float g[8], yp[8], x[8];
+          unpack8(gv[u], g);
+          unpack8(yv[u], yp);
+          unpack8(xv[u], x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            g[i] = yp[i] > 0.f ? g[i] : 0.f;
+            s1[i] += g[i];
+            s2[i] += g[i] * ((x[i] - mean[i]) * inv[i]);
+          }
+        }
+      }
+    } else
     for (int r = rt; r < a.ppb; r += rows) {
       long long p = p0 + r;
       if (p >= P) break;

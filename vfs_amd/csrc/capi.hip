@@ -155,10 +155,10 @@ int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const v
   a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
   return vfs_bn_act_launch(a, S(stream));
 }
-int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, int N, int H, int W, int C, int Hp,
-                        int Wp, int npg, vfs_stream_t stream) {
+int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, vfs_bf16* xpool, int N, int H, int W, int C,
+                        int Hp, int Wp, int npg, vfs_stream_t stream) {
   BnPoolArgs a;
-  a.x = x; a.bnp = bnp; a.y = y; a.idx = idx; a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg;
+  a.x = x; a.bnp = bnp; a.y = y; a.idx = idx; a.xpool = xpool; a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg;
   return vfs_bn_relu_maxpool_launch(a, S(stream));
 }
 int vfs_maxpool_relu_bwd(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, vfs_bf16* ga, int N, int H, int W, int C,
@@ -183,14 +183,14 @@ int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, co
   a.relu = relu;
   return vfs_bn_bwd_apply_launch(a, S(stream));
 }
-int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, const vfs_bf16* x, const float* bnp,
-                                float* partial, int N, int H, int W, int C, int Hp, int Wp, int npg, int ppb,
+int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, const vfs_bf16* x, const vfs_bf16* xpool,
+                                const float* bnp, float* partial, int N, int H, int W, int C, int Hp, int Wp, int npg, int ppb,
                                 vfs_stream_t stream) {
   const long long mpg = (long long)npg * Hp * Wp;
   if (ppb <= 0 || mpg % ppb) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd_reduce: pooled pixels per group % ppb");
   StemBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.gp = gp; a.yp = yp; a.idx = idx; a.x = x; a.bnp = bnp; a.partial = partial;
+  a.gp = gp; a.yp = yp; a.idx = idx; a.x = x; a.xp = xpool; a.bnp = bnp; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.C = C; a.Hp = Hp; a.Wp = Wp; a.npg = npg; a.ppb = ppb;
   const long long P = (long long)N * Hp * Wp;
   return vfs_stem_pool_bn_bwd_reduce_launch(a, (int)((P + ppb - 1) / ppb), S(stream));

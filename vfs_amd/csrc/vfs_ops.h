@@ -21,6 +21,7 @@ struct BnPoolArgs {
   const float* bnp;  // [G][4][C]
   bf16_t* y;         // [N][Hp][Wp][C]
   uint8_t* idx;      // [N][Hp][Wp][C] or null
+  bf16_t* xpool;     // [N][Hp][Wp][C] or null: raw x at the argmax
   int N, H, W, C, Hp, Wp, npg;  // npg = images per group
 };
 
@@ -60,6 +61,7 @@ struct StemBwdArgs {
   const bf16_t* yp;    // pooled output (ReLU mask)
   const uint8_t* idx;  // argmax codes
   const bf16_t* x;     // [N][H][W][C] raw stem conv output
+  const bf16_t* xp;    // pass 1, optional: [N][Hp][Wp][C] raw x at the argmax (replaces the gather from x)
   const float* bnp;    // [G][4][C]
   const double* sums;  // pass 2
   float* partial;      // pass 1: [nblk][2][C]

@@ -250,7 +250,7 @@ class Engine:
                 u.bn.num_batches_tracked += n
                 u.nbt_pending = 0
 
-    def stem_pool_bn_bwd(self, u, gp, yp, idx, raw, N, H, W, Hp, Wp, G):
+    def stem_pool_bn_bwd(self, u, gp, yp, idx, raw, N, H, W, Hp, Wp, G, xpool=None):
         """BN backward of the stem through max-pool + ReLU (no full-resolution gradient tensor)."""
         dev = raw.device
         s = self.stream(dev)
@@ -264,7 +264,7 @@ class Engine:
         nblk = (N * Hp * Wp) // ppb
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
-        lib.stem_pool_bn_bwd_reduce(gp, yp, idx, raw, u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
+        lib.stem_pool_bn_bwd_reduce(gp, yp, idx, raw, xpool, u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
         self._bwd_sums(u, partial, G, nblk // G, C, dev)
         return float(npg * H * W * self.world)
 

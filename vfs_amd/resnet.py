@@ -245,9 +245,11 @@ class ResNet(nn.Module):
         dev = x4.device
         pooled = eng.buf('backbone.pool', (N, Hp, Wp, 64), BF16, dev)
         idx = eng.buf('backbone.pool_idx', (N, Hp, Wp, 64), torch.uint8, dev) if train else None
+        # raw conv output at each argmax: the stem's BatchNorm backward reads it instead of gathering from raw
+        xpool = eng.buf('backbone.pool_x', (N, Hp, Wp, 64), BF16, dev) if train else None
         npg = N // G if stem_train else N
-        eng.lib.bn_relu_maxpool(raw, stem.bnp, pooled, idx, N, Hs, Ws, 64, Hp, Wp, npg, eng.stream(dev))
-        ctx.update(stem_raw=raw, Hs=Hs, Ws=Ws, pooled=pooled, idx=idx, Hp=Hp, Wp2=Wp)
+        eng.lib.bn_relu_maxpool(raw, stem.bnp, pooled, idx, xpool, N, Hs, Ws, 64, Hp, Wp, npg, eng.stream(dev))
+        ctx.update(stem_raw=raw, Hs=Hs, Ws=Ws, pooled=pooled, idx=idx, xpool=xpool, Hp=Hp, Wp2=Wp)
         x, h, w = pooled, Hp, Wp
         outs = {}
         for si, lname in enumerate(self.res_layers):
@@ -321,7 +323,8 @@ class ResNet(nn.Module):
         dev = g.device
         Hs, Ws = ctx['Hs'], ctx['Ws']
         stem = self.conv1.unit
-        count = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G)
+        count = eng.stem_pool_bn_bwd(stem, g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G,
+                                     xpool=ctx.get('xpool'))
         if os.environ.get('VFS_STEM_FUSED', '1') == '1':
             eng.stem_wgrad_fused(stem, ctx['x4'], ctx['H'], ctx['Wp'], g, ctx['pooled'], ctx['idx'], ctx['stem_raw'],
                                  N, Hs, Ws, ctx['Hp'], ctx['Wp2'], G, count)
