@@ -460,18 +460,43 @@ class VanillaTracker(nn.Module):
         self.backbone = ResNet(depth, strides=test_cfg.get('strides', (1, 2, 1, 1)),
                                out_indices=test_cfg.get('out_indices', (2,)), stop_after_out=True)
 
+    def extract_feat_test(self, frames):
+        """vanilla_tracker.py:30-46: with test_cfg.all_blocks the output of EVERY residual block of the
+        stages in test_cfg.out_indices (a tuple), otherwise the backbone's stage output."""
+        if not self.test_cfg.get('all_blocks', False):
+            return self.backbone(frames)
+        bb = self.backbone
+        x = bb.maxpool(bb.conv1(frames))
+        outs = []
+        stages = tuple(self.test_cfg.get('out_indices', (2,)))
+        for i, name in enumerate(bb.res_layers):
+            layer = getattr(bb, name)
+            if i in stages:
+                for block in layer:
+                    x = block(x)
+                    outs.append(x)
+            else:
+                x = layer(x)
+        return tuple(outs)
+
     @torch.no_grad()
     def forward_test(self, imgs, ref_seg_map, original_shape):
         imgs = imgs.reshape((-1,) + imgs.shape[2:])           # [1,3,T,H,W]
         frames = video2images(imgs)
         step = self.test_cfg.get('batch_step', 10)
-        feats = torch.cat([self.backbone(frames[i:i + step]) for i in range(0, frames.size(0), step)])
-        feats = images2video(feats, frames.size(0))
+        chunks = [self.extract_feat_test(frames[i:i + step]) for i in range(0, frames.size(0), step)]
         tc = self.test_cfg
-        return label_propagate(feats, ref_seg_map, tuple(original_shape[:2]),
-                               precede_frames=tc['precede_frames'], topk=tc['topk'],
-                               temperature=tc['temperature'], neighbor_range=tc.get('neighbor_range'),
-                               with_first=tc.get('with_first', True))
+        many = isinstance(chunks[0], tuple)
+        res = []
+        for fi in range(len(chunks[0]) if many else 1):
+            feats = torch.cat([c[fi] if many else c for c in chunks])
+            feats = images2video(feats, frames.size(0))
+            res.append(label_propagate(feats, ref_seg_map, tuple(original_shape[:2]),
+                                       precede_frames=tc['precede_frames'], topk=tc['topk'],
+                                       temperature=tc['temperature'], neighbor_range=tc.get('neighbor_range'),
+                                       with_first=tc.get('with_first', True)))
+        # vanilla_tracker.py:199-205: several feature levels are stacked along axis 1 of [1, ...]
+        return np.stack(res, axis=0) if many else res[0]
 
 
 # --------------------------------------------------------------------------

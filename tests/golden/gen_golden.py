@@ -210,7 +210,8 @@ def main():
     from mmaction.models.common.affinity_utils import spatial_neighbor
     from mmaction.models.common.local_attention import masked_attention_efficient
     from mmaction.models.common.utils import pil_nearest_interpolate
-    save = lambda name, **kw: (np.savez_compressed(os.path.join(HERE, name + '.npz'), **kw),
+    OUT = os.environ.get('VFS_GOLDEN_OUT', HERE)      # regenerate into a scratch directory to add single fixtures
+    save = lambda name, **kw: (np.savez_compressed(os.path.join(OUT, name + '.npz'), **kw),
                                print('wrote', name, {k: getattr(v, 'shape', None) for k, v in kw.items()}))
 
     # ---- backbone forwards (train mode, batch statistics) ----
@@ -305,6 +306,13 @@ def main():
     save('forward_test_r18', seg_preds=res[0].astype(np.uint8), ref_seg=seg,
          feat_checksum=np.array([feat.double().sum().item(), feat.double().abs().sum().item()]),
          feat_shape=np.array(feat.shape), feat_sample=feat.flatten()[::997].numpy().copy())
+
+    # ---- the same clip with test_cfg.all_blocks=True (README.md:76): one label map per res4 block ----
+    model.test_cfg['all_blocks'] = True
+    with torch.no_grad():
+        res = model(imgs, return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                    img_meta=[dict(original_shape=(H, W, 3))])
+    save('forward_test_r18_all_blocks', seg_preds=res[0].astype(np.uint8), ref_seg=seg)
 
 
 if __name__ == '__main__':

@@ -130,3 +130,34 @@ def test_forward_test_matches_reference_golden_labels(backend):
                             neighbor_range=8, with_first=True, normalize=False)
     mism = (out[0] != lab).mean()
     assert mism < 2e-3, mism
+
+
+def test_forward_test_all_blocks(backend):
+    """test_cfg.all_blocks=True: the list holds ONE array [num_blocks, T, H, W] (vanilla_tracker.py:199-205);
+    statistical agreement with the reference's fp32 labels per block, last block = the single-feature path"""
+    import os
+    import vfs_amd
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'forward_test_r18_all_blocks.npz'))
+    cfg = vfs_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(__file__)), 'configs', 'vfs_r18.py'))
+    tc = vfs_amd.ConfigDict(cfg.test_cfg)
+    tc['neighbor_range'], tc['precede_frames'], tc['all_blocks'] = 8, 3, True
+    bb = dict(cfg.model['backbone'])
+    bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']
+    model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
+    ref = O.VanillaTracker(18, dict(tc))
+    O.fill_state_dict_(ref, seed=5)
+    model.load_state_dict(ref.state_dict(), strict=False)
+    model.to(backend.dev).eval()
+    T, H, W = 6, 96, 128
+    imgs = O.fill_tensor([1, 1, 3, T, H, W], 41, scale=2.0).to(backend.dev)
+    seg = torch.from_numpy(g['ref_seg'])[None]
+    meta = [dict(original_shape=(H, W, 3))]
+    out = model(imgs, return_loss=False, ref_seg_map=seg, img_meta=meta)
+    assert isinstance(out, list) and len(out) == 1 and out[0].shape == (2, T, H, W) and out[0].dtype == np.uint8
+    for b in range(2):
+        assert (out[0][b][0] == g['seg_preds'][b][0]).all()
+        assert (out[0][b] == g['seg_preds'][b]).mean() > 0.97
+    model.test_cfg['all_blocks'] = False
+    single = model(imgs, return_loss=False, ref_seg_map=seg, img_meta=meta)
+    assert np.array_equal(single[0], out[0][1])
+

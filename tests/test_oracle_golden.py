@@ -124,3 +124,19 @@ def test_forward_test_matches_reference():
     assert out.shape == g['seg_preds'].shape and out.dtype == np.uint8
     mism = (out != g['seg_preds']).mean()
     assert mism == 0.0, mism
+
+
+def test_forward_test_all_blocks_matches_reference():
+    """test_cfg.all_blocks=True (vanilla_tracker.py:30-46, README.md:76): one label map per res4 block"""
+    g = load('forward_test_r18_all_blocks')
+    tc = dict(precede_frames=3, topk=10, temperature=0.07, strides=(1, 2, 1, 1), out_indices=(2,),
+              neighbor_range=8, with_first=True, with_first_neighbor=True, all_blocks=True)
+    model = O.VanillaTracker(18, tc)
+    O.fill_state_dict_(model, seed=5)
+    model.eval()
+    T, H, W = 6, 96, 128
+    imgs = O.fill_tensor([1, 1, 3, T, H, W], 41, scale=2.0)
+    out = model.forward_test(imgs, g['ref_seg'], (H, W, 3))
+    assert out.shape == g['seg_preds'].shape == (2, T, H, W) and out.dtype == np.uint8
+    assert (out != g['seg_preds']).mean() == 0.0
+
