@@ -71,6 +71,17 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
                       const vfs_bf16* bn_x, const vfs_bf16* bn_y, const float* bnp, float* bn_partial,
                       int bn_mpg, int bn_relu, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
                       int KW, int stride, int pad, vfs_stream_t stream);
+/* conv-BN-ReLU -> conv without materialising the activation: x_raw is the RAW output of the producer unit,
+ * in_bnp its float[G][4][Cin] {scale, shift, mean, invstd}, in_npg images per group; relu(x*scale+shift)
+ * (rounded to bf16 exactly as vfs_bn_act) is applied while the halo patch is staged, padding stays zero.
+ * 3x3 / stride 1 / pad 1 on halo-tile-eligible shapes only (VFS_ERR_SHAPE otherwise); the matching weight
+ * gradient reads the same raw tensor.  Replaces vfs_bn_act + vfs_conv_fwd / vfs_conv_wgrad. */
+int vfs_conv_fwd_bnin(const vfs_bf16* x_raw, const float* in_bnp, int in_npg, const vfs_bf16* wf, vfs_bf16* y,
+                      const float* bias, float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                      int KH, int KW, int stride, int pad, vfs_stream_t stream);
+int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* in_bnp, int in_npg, float* partial,
+                        float* grad, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                        int stride, int pad, int nsplit, int pix_per_split, vfs_stream_t stream);
 /* wgrad: grad[Cout][Cin][KH][KW] (fp32, reference OIHW layout) += sum_pixels dy * im2col(x).
  * partial: workspace float[nsplit][Cout][KH*KW*Cin]; pix_per_split % 64 == 0 and
  * nsplit*pix_per_split >= N*Ho*Wo.  Deterministic (fixed-order split-K reduction). */

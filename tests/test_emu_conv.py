@@ -160,6 +160,45 @@ def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, m
     assert torch.allclose(st[:, 1], want2, rtol=1e-4, atol=2e-2), (st[:, 1] - want2).abs().max()
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,G', [
+    (2, 16, 32, 128, 128, 2),     # 8x16 tiles, two channel chunks, two groups
+    (2, 32, 32, 64, 64, 2),       # 16x16 tiles (64 output channels)
+    (4, 8, 8, 64, 128, 2),        # whole 8x8 images, two per tile
+])
+def test_conv_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):
+    """vfs_conv_fwd_bnin / vfs_conv_wgrad_bnin (the activation of the producer unit is never materialised)
+    against vfs_bn_act followed by vfs_conv_fwd / vfs_conv_wgrad on the same raw tensor: bit-identical."""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N + H + Cin)
+    raw = rb(torch.randn(N, H, W, Cin, generator=g) * 1.3).to(torch.bfloat16)
+    w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5)
+    wf, _ = pack(backend, w)
+    npg = N // G
+    bnp = torch.stack([torch.rand(G, Cin, generator=g) + 0.5, torch.randn(G, Cin, generator=g) * 0.4,
+                       torch.zeros(G, Cin), torch.ones(G, Cin)], 1).contiguous()
+    M = N * H * W
+    rawd, bnpd = d(raw), d(bnp)
+    act = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+    lib.bn_act(rawd, bnpd, None, None, None, act, M, Cin, M // G, 1, None)
+    nblk = (M + 127) // 128
+    y0 = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+    y1 = torch.full_like(y0, float('nan'))
+    st0 = torch.full((nblk, 2, Cout), float('nan'), device=dev)
+    st1 = torch.full_like(st0, float('nan'))
+    lib.conv_fwd(act, wf, y0, None, st0, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, None)
+    lib.conv_fwd_bnin(rawd, bnpd, npg, wf, y1, None, st1, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, None)
+    assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(st1.cpu(), st0.cpu())
+    dy = d(rb(torch.randn(N, H, W, Cout, generator=g)).to(torch.bfloat16))
+    nsplit, pps = wgrad_splits(M, Cout, 9 * Cin, target_blocks=12, halo_geom=(N, H, W, Cin))
+    partial = torch.zeros(nsplit, Cout, 9 * Cin, device=dev)
+    g0, g1 = torch.zeros(Cout, Cin, 3, 3, device=dev), torch.zeros(Cout, Cin, 3, 3, device=dev)
+    lib.conv_wgrad(dy, act, partial, g0, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nsplit, pps, None)
+    lib.conv_wgrad_bnin(dy, rawd, bnpd, npg, partial, g1, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nsplit, pps, None)
+    assert torch.equal(g1.cpu(), g0.cpu())
+    with pytest.raises(Exception):       # only the halo-tile shapes fold the input BatchNorm
+        lib.conv_fwd_bnin(rawd, bnpd, npg, wf, y1, None, st1, N, H, W, Cin, H // 2, W // 2, Cout, 3, 3, 2, 1, None)
+
+
 BIG_CASES = [  # the layer shapes of the bench configs (per-GPU batch reduced), ragged M included
     (8, 64, 64, 64, 64, 3, 1, 1),      # R18 layer1 @256
     (8, 64, 64, 64, 128, 3, 2, 1),     # R18 layer2.0.conv1

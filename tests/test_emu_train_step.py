@@ -109,13 +109,16 @@ def _maxrel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize('depth,shape', [(18, [4, 2, 3, 2, 32, 32]), (50, [8, 2, 3, 1, 32, 32])])
-def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape):
+@pytest.mark.parametrize('depth,shape', [(18, [4, 2, 3, 2, 32, 32]), (50, [8, 2, 3, 1, 32, 32]),
+                                         # 16x16 feature maps in layer1: halo-tile kernels, folded input BatchNorm, fused dgrad statistics
+                                         (18, [4, 2, 3, 2, 64, 64])])
+def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monkeypatch):
     """Tight orchestration check without the chaos: run the fused step, then for the stem, every
     residual block, the head and the loss feed the ENGINE'S OWN input / incoming-gradient buffers
     to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
     and require outputs, input gradients and parameter gradients to agree to bf16 rounding."""
     import vfs_amd
+    monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)
     eng = backend.eng
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
     model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
@@ -218,6 +221,8 @@ def test_graph_replay_equals_eager(gpu_backend, monkeypatch):
     dev = gpu_backend.dev
     shape = [8, 2, 3, 2, 64, 64]
     batches = [O.fill_tensor(shape, seed=100 + i, scale=2.0).to(dev) for i in range(6)]
+
+    monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # exercise the folded-input-BatchNorm kernels at this small size too
 
     def run(graphs):
         monkeypatch.setenv('VFS_GRAPHS', '1' if graphs else '0')

@@ -63,6 +63,21 @@ int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float
   ConvArgs a;
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
   a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
+  return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
+}
+int vfs_conv_fwd_bnin(const vfs_bf16* x_raw, const float* in_bnp, int in_npg, const vfs_bf16* wf, vfs_bf16* y, const float* bias,
+                      float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                      vfs_stream_t stream) {
+  if (!in_bnp || in_npg <= 0) return vfs_set_error(VFS_ERR_ARG, "conv_fwd_bnin: BatchNorm parameters of the input");
+  ConvArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.src = x_raw; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
+  a.in_bnp = in_bnp; a.in_npg = in_npg;
+  const bool smallw = (W == 8 && H == 8);
+  if (!vfs_option_halo || Cin % 64 || (size_t)N * H * W * Cin * 2 >= 0xFFFFFFF0ull || !vfs_conv_halo_eligible(a, GATHER_FWD) ||
+      (smallw && in_npg % 2))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_fwd_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
   return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
 }
 
@@ -72,6 +87,7 @@ int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* sta
   ConvArgs a;
   a.g = make_geom(N, H, Wp, 4, Ho, Wo, 7, 7, 2, 3, 256);
   a.src = x4; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = nullptr; a.stats = stats; a.Cout = 64; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
   if (vfs_option_stem_direct && (size_t)N * H * Wp * 8 < 0xFFFFFFF0ull) return vfs_stem_fwd_direct_launch(a, S(stream));
   return vfs_conv_igemm_dispatch(a, GATHER_STEM, S(stream));
 }
@@ -82,6 +98,7 @@ int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const v
   ConvArgs a;
   a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
   a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
   return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
 }
 int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const vfs_bf16* bn_x,
@@ -94,6 +111,7 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
   ConvArgs a;
   a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
   a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin;
+  a.in_bnp = nullptr; a.in_npg = 0;
   a.bn.x = bn_x; a.bn.y = bn_y; a.bn.bnp = bnp; a.bn.partial = bn_partial; a.bn.mpg = bn_mpg; a.bn.relu = bn_relu;
   return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
 }
@@ -103,12 +121,27 @@ int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float*
   WgradArgs a;
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
   a.dy = dy; a.x = x; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
+  a.in_bnp = nullptr; a.in_npg = 0;
   int rc;
   if (vfs_option_halo && vfs_wgrad_halo_eligible(a, GATHER_FWD)) {
     rc = vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);   // may use fewer splits than offered
   } else {
     rc = vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
   }
+  if (rc) return rc;
+  return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
+}
+int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* in_bnp, int in_npg, float* partial, float* grad, int N,
+                        int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int nsplit,
+                        int pix_per_split, vfs_stream_t stream) {
+  if (!in_bnp || in_npg <= 0) return vfs_set_error(VFS_ERR_ARG, "conv_wgrad_bnin: BatchNorm parameters of the input");
+  WgradArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.dy = dy; a.x = x_raw; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
+  a.in_bnp = in_bnp; a.in_npg = in_npg;
+  if (!vfs_option_halo || !vfs_wgrad_halo_eligible(a, GATHER_FWD) || (W == 8 && H == 8 && in_npg % 2))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
+  int rc = vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);
   if (rc) return rc;
   return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
 }

@@ -257,15 +257,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
       (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2), 0x00020000);
 
   u32x4 pr_[PLD];
+  // folded BatchNorm-apply + ReLU of the input (ConvArgs::in_bnp): this thread's 8 channels of the chunk
+  const bool bn_in = !DGRAD && a.in_bnp != nullptr;
+  const float* bn_in_p = bn_in ? a.in_bnp + (size_t)(tn0 / a.in_npg) * 4 * g.C + j * 8 : nullptr;
+  f32x4 isc0, isc1, ish0, ish1;
   auto load_patch = [&](int cc) {
 #pragma unroll
     for (int k = 0; k < PLD; ++k) pr_[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, poff[k], cc * 128, 0);
+    if (bn_in) {
+      const float* p = bn_in_p + cc * 64;
+      isc0 = *reinterpret_cast<const f32x4*>(p); isc1 = *reinterpret_cast<const f32x4*>(p + 4);
+      ish0 = *reinterpret_cast<const f32x4*>(p + g.C); ish1 = *reinterpret_cast<const f32x4*>(p + g.C + 4);
+    }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int k = 0; k < PLD; ++k) {
       const int pr = row0 + 32 * k;
-      if (pr < PROWS) st16(&sP[pr * RS + j * 8], pr_[k]);
+      if (pr < PROWS) {
+        u32x4 v = pr_[k];
+        if (bn_in && poff[k] != OOB_OFFSET) v = bn_relu_vec(v, isc0, isc1, ish0, ish1);   // padding stays zero
+        st16(&sP[pr * RS + j * 8], v);
+      }
     }
   };
   auto dma_w = [&](int cc, int tap, int buf) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int lo_off, int hi
   return f;
 }
 
-template <bool SMALLW>
+template <bool SMALLW, bool BNIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a, int tiles_per_split, int ntiles) {
   constexpr int TW = SMALLW ? 8 : 16, TH = 8, TI = SMALLW ? 2 : 1;
   constexpr int PW = TW + 2, PH = TH + 2;
@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
   constexpr int PLD = (PROWS * 8 + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf16_t sP[PROWS * RS];   // X halo patch  [patch row][64 cin + pad]
   __shared__ __attribute__((aligned(16))) bf16_t sD[128 * RS];     // dY tile       [pixel][64 cout + pad]
+  // BNIN: x is the RAW output of a plain conv-BN-ReLU unit; relu(x*scale+shift) is applied while the patch
+  // is staged.  The coefficients of this workgroup's 64-channel chunk live in LDS ([group][scale|shift][64]):
+  // held in registers across the MFMA loop they pushed the kernel (144 accumulators) into spills.
+  __shared__ __attribute__((aligned(16))) float sBn[BNIN ? 8 * 2 * 64 : 4];
 
   const ConvGeom g = a.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -78,14 +82,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
       (void*)a.dy, 0, (unsigned)((size_t)g.N * g.H * g.W * a.Cout * 2), 0x00020000);
 
   u32x4 pv[PLD], dv[4];
+  unsigned pvalid = 0;                 // BNIN: bit k = slot k of the staged patch is inside the image
+  int bn_gi = 0;                       // BNIN: statistics group of the tile in registers
   auto load_tile = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n0 = (tile / (tiles_x * tiles_y)) * TI;
     const int y0 = ty * TH, x0 = tx * TW;
+    if (BNIN) bn_gi = n0 / a.in_npg;
+    pvalid = 0;
 #pragma unroll
     for (int k = 0; k < PLD; ++k) {
       const int y = y0 + p_y[k], x = x0 + p_x[k], n = n0 + p_ti[k];
       const bool ok = p_ti[k] >= 0 && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W && n < g.N;
       const unsigned off = ok ? (unsigned)((((size_t)(n * g.H + y) * g.W + x) * g.C + cc * 64 + j * 8) * 2) : OOB_OFFSET;
+      if (BNIN) pvalid |= ok ? (1u << k) : 0u;
       pv[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
     }
 #pragma unroll
@@ -100,7 +109,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
 #pragma unroll
     for (int k = 0; k < PLD; ++k) {
       const int pr = row0 + 32 * k;
-      if (pr < PROWS) st16(&sP[pr * RS + j * 8], pv[k]);
+      if (pr < PROWS) {
+        u32x4 v = pv[k];
+        if (BNIN && ((pvalid >> k) & 1u)) {   // padding stays zero
+          const float* p = sBn + bn_gi * 128 + j * 8;
+          v = bn_relu_vec(v, *reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4),
+                          *reinterpret_cast<const f32x4*>(p + 64), *reinterpret_cast<const f32x4*>(p + 68));
+        }
+        st16(&sP[pr * RS + j * 8], v);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) st16(&sD[(row0 + 32 * i) * RS + j * 8], dv[i]);
@@ -119,6 +136,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     return SMALLW ? (p >> 6) * (PH * PW) + ((p >> 3) & 7) * PW : (p >> 4) * PW;
   };
 
+  if (BNIN) {   // up to 8 groups x {scale, shift} x this chunk's 64 channels
+    const int ngroups = min(8, (g.N + a.in_npg - 1) / a.in_npg);
+    for (int i = t; i < ngroups * 128; i += 256) {
+      const int gi = i >> 7, r = (i >> 6) & 1, c = i & 63;
+      sBn[i] = a.in_bnp[(size_t)gi * 4 * g.C + r * g.C + cc * 64 + c];
+    }
+    __syncthreads();
+  }
   f32x4 acc[9][2][2];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
@@ -197,9 +222,13 @@ int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsp
   b.nsplit = (ntiles + tps - 1) / tps;
   *eff_nsplit = b.nsplit;
   const int blocks = (a.g.C >> 6) * (a.Cout >> 6) * b.nsplit;
-  if (smallw)
-    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<true>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
-  else
-    hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<false>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
+  if (a.in_bnp && (a.g.N + a.in_npg - 1) / a.in_npg > 8) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: more than 8 BatchNorm groups");
+  if (smallw) {
+    if (a.in_bnp) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
+    else hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
+  } else {
+    if (a.in_bnp) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
+    else hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
+  }
   return vfs_check_launch("conv3x3_wgrad_halo");
 }

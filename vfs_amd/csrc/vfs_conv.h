@@ -49,6 +49,11 @@ struct ConvArgs {
   float* stats;        // optional [num_pixel_blocks][2][Cout]
   int Cout;
   BnBwdFuse bn;        // optional fused BatchNorm-backward statistics of the OUTPUT (dgrad only)
+  // optional BatchNorm-apply + ReLU of the INPUT, folded into the operand load (forward, halo kernel): src
+  // is the RAW output of a plain conv-BN-ReLU unit, in_bnp = its float[G][4][C] {scale, shift, ..},
+  // in_npg = images per statistics group.  The activation tensor is never written or read.
+  const float* in_bnp;
+  int in_npg;
 };
 
 struct WgradArgs {
@@ -59,7 +64,21 @@ struct WgradArgs {
   int Cout;
   int pix_per_split;   // multiple of 64
   int nsplit;
+  const float* in_bnp; // optional: x is a RAW conv output, relu(x*scale+shift) is applied while staging (halo kernel)
+  int in_npg;
 };
+
+// relu(x*scale + shift) on one 16-byte vector (8 channels), rounded to bf16 exactly as bn_act_kernel does
+__device__ __forceinline__ u32x4 bn_relu_vec(u32x4 v, const f32x4& sc0, const f32x4& sc1, const f32x4& sh0, const f32x4& sh1) {
+  float x[8];
+  unpack8(v, x);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[i] = fmaxf(x[i] * sc0[i] + sh0[i], 0.f);
+    x[4 + i] = fmaxf(x[4 + i] * sc1[i] + sh1[i], 0.f);
+  }
+  return pack8(x);
+}
 
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode);

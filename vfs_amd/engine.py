@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import get_lib
-from .packing import build_pack_table, wgrad_halo_eligible, wgrad_splits
+from .packing import bn_fold_eligible, build_pack_table, wgrad_halo_eligible, wgrad_splits
 
 BF16 = torch.bfloat16
 
@@ -133,7 +133,7 @@ class Engine:
         self.lib.pack_weights(tab, n, total, self.stream(dev))
 
     # ------------------------------------------------------------------ forward primitives
-    def conv_fwd(self, u, x, N, H, W, G, train, tag=''):
+    def conv_fwd(self, u, x, N, H, W, G, train, tag='', in_bn=None):
         """raw = conv(x); BN statistics/params when the unit has a BN.  Returns (raw, Ho, Wo)."""
         dev = x.device
         s = self.stream(dev)
@@ -160,6 +160,11 @@ class Engine:
             if u.kind == 'stem':
                 self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * 64 * 147, dev, lib.stem_fwd,
                            x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
+            elif in_bn is not None:     # x is the producer's RAW output: BatchNorm + ReLU folded into the operand load
+                assert (n0, nn_) == (0, N), 'folded input BatchNorm needs the single-launch (fused statistics) path'
+                self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin, dev, lib.conv_fwd_bnin,
+                           x, in_bn[0], in_bn[1], u.wf, y, bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
+                           u.k, u.k, u.stride, u.pad, s)
             else:
                 self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin, dev, lib.conv_fwd,
                            x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
@@ -184,6 +189,21 @@ class Engine:
                 lib.bn_eval_params(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, u.bnp, u.cout,
                                    float(bn.eps), s)
         return y, Ho, Wo
+
+    def can_fold_input_bn(self, u, N, G, H, W, train):
+        """may conv unit u read the raw output of its producer (BatchNorm + ReLU folded into the load)?"""
+        if os.environ.get('VFS_BNACT_FUSE', '1') != '1' or u.kind == 'stem':
+            return False
+        # pays only where the saved activation pass is large: the fold costs VALU work in the staging of
+        # the consumer's forward and weight-gradient kernels (measured: + on ResNet-18's wide early layers,
+        # - on ResNet-50's 33 MB-and-smaller bottleneck tensors)
+        if N * H * W * u.cin * 2 < float(os.environ.get('VFS_BNACT_FUSE_MB', '48')) * (1 << 20):
+            return False
+        Ng = N // G
+        mpg = Ng * H * W
+        if not (G == 1 or mpg % 128 == 0):      # the consumer must take the single-launch statistics path
+            return False
+        return bn_fold_eligible(N, G if train else 1, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
 
     def bn_scratch(self, G, C, dev):
         """scratch of the chunked BatchNorm reductions: 64 ticket counters (must start at zero; every
@@ -302,7 +322,7 @@ class Engine:
                        x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
                        N // G, count, nblocks, self.stream(dev))
 
-    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None, bn_next=None):
+    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None, bn_next=None, x_in_bn=None):
         """weight (and bias) gradients accumulate into .grad; returns the input gradient or None.
         bn_next = (unit, raw, ymask, relu, G): the BatchNorm unit whose backward consumes the input
         gradient; for stride-1 convs the dgrad epilogue also emits that unit's backward statistics
@@ -327,8 +347,12 @@ class Engine:
         # with the dgrad / BatchNorm-backward kernels of the critical path (joined by wgrad_join)
         with self.on_side_stream(dev):
             ss = self.stream(dev)
-            self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
-                       Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+            if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
+                self.timed('conv_wgrad', flops, dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
+                           u.weight.grad, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+            else:
+                self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
+                           Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             if u.bias is not None:
                 lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)
         if not need_dgrad:

@@ -34,6 +34,26 @@ def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
     return W % 16 == 0 or (W == 8 and H == 8)
 
 
+def conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
+    """mirror of vfs_conv_halo_eligible (csrc/conv_halo.hip), forward"""
+    if k != 3 or stride != 1 or pad != 1 or Cin % 64 or Cout % 64:
+        return False
+    if Cout % 128 == 0:
+        return (H % 8 == 0 and W % 16 == 0) or (W == 8 and H == 8 and N % 2 == 0)
+    return H % 16 == 0 and W % 16 == 0
+
+
+def bn_fold_eligible(N, G, H, W, Cin, Cout, k, stride, pad):
+    """can conv(k, stride, pad) read the RAW output of its producer unit and apply BatchNorm + ReLU while
+    staging (vfs_conv_fwd_bnin / vfs_conv_wgrad_bnin)?  Both halo kernels must take the shape and a tile
+    must not straddle two statistics groups (8x8 images are tiled in pairs)."""
+    if not (conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad) and wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad)):
+        return False
+    if W == 8 and H == 8 and (N // G) % 2:
+        return False
+    return N % G == 0 and G <= 8
+
+
 def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
     """Split-K plan for the wgrad kernels: (nsplit, pix_per_split).  halo_geom = (N, H, W, Cin)
     selects the plan of the 3x3 halo kernel (workgroup = 64 cin x 64 cout x 9 taps, split over

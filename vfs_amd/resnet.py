@@ -266,15 +266,27 @@ class ResNet(nn.Module):
         convs = blk.convs
         bctx = dict(blk=blk, x=x, h=h, w=w, acts=[], raws=[], dims=[])
         a, ah, aw = x, h, w
+        in_bn = None
+        bctx['act_bn'] = []
         for ci, c in enumerate(convs):
             tr = train and c.bn.training
-            raw, oh, ow = eng.conv_fwd(c.unit, a, N, ah, aw, G, tr)
+            raw, oh, ow = eng.conv_fwd(c.unit, a, N, ah, aw, G, tr, in_bn=in_bn)
             bctx['raws'].append(raw)
             bctx['dims'].append((ah, aw, oh, ow))
             M = N * oh * ow
+            in_bn = None
             if ci < len(convs) - 1:
-                a = eng.bn_act(c.unit, raw, M, G, tr, True)
-                bctx['acts'].append(a)
+                nxt = convs[ci + 1]
+                if eng.can_fold_input_bn(nxt.unit, N, G, oh, ow, train and nxt.bn.training):
+                    # plain conv-BN-ReLU unit feeding a halo-tile conv: the activation is never written; the
+                    # consumer (and its weight gradient) reads raw and applies scale/shift/ReLU while staging
+                    in_bn = (c.unit.bnp, (N // G) if tr else N)
+                    a = raw
+                    bctx['acts'].append(raw)
+                else:
+                    a = eng.bn_act(c.unit, raw, M, G, tr, True)
+                    bctx['acts'].append(a)
+                bctx['act_bn'].append(in_bn)
                 ah, aw = oh, ow
             else:
                 if blk.downsample is not None:
@@ -360,7 +372,8 @@ class ResNet(nn.Module):
                 bn_next = (next_bn[0], next_bn[1], next_bn[2], True, G)
             else:
                 bn_next = None
-            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add, bn_next=bn_next)
+            x_in_bn = bctx['act_bn'][ci - 1] if ci > 0 else None
+            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add, bn_next=bn_next, x_in_bn=x_in_bn)
             if ci > 0:
                 p = convs[ci - 1]
                 _, _, ph, pw = bctx['dims'][ci - 1]
