@@ -186,29 +186,32 @@ def main():
     }
     if rank == 0 and prof:
         agg = {}
-        for kind, flops, e0, e1 in prof:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
+        for kind, flops, e0, e1, nbytes in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            a[3] += nbytes
         kind = max(agg, key=lambda k: agg[k][1])
-        fl, tm, cnt = agg[kind]
+        fl, tm, cnt, nb = agg[kind]
         ach = fl / tm / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh), if present
         tpath = os.path.join(REPO, 'profiles', f'r01_traffic_{args.model}.json')
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get('classes', {}).get(kind, {}).get('hbm_bytes_per_launch')
-        # which roof binds the class: time at the dense bf16 MFMA peak vs time at the HBM peak for the
-        # bytes the PMC passes counted (MI355X_MICROARCH.md: 2.5 PFLOP/s, 8 TB/s)
+        # which roof binds the class: time at the dense bf16 MFMA peak for the algorithmic FLOP vs time at the
+        # HBM peak for the algorithmic bytes (every operand of a launch once; Engine.timed) - peaks from
+        # MI355X_MICROARCH.md: 2.5 PFLOP/s, 8 TB/s.  `traffic` is what the PMC passes actually counted.
         t_launch = tm / cnt
         t_mfma = fl / cnt / (PEAK_BF16_TFLOPS * 1e12)
-        t_hbm = (traffic or 0.0) / (PEAK_HBM_GBS * 1e9)
-        extra = {'algorithmic_flop_per_launch': fl / cnt, 'launches': cnt, 'avg_launch_ms': t_launch * 1e3,
-                 'time_share_of_step': tm / dt_prof,
+        t_hbm = nb / cnt / (PEAK_HBM_GBS * 1e9)
+        extra = {'algorithmic_flop_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt, 'launches': cnt,
+                 'avg_launch_ms': t_launch * 1e3, 'time_share_of_step': tm / dt_prof,
                  'mfma': {'achieved_TFLOP/s': ach, 'frac': ach / PEAK_BF16_TFLOPS},
-                 'hbm': {'achieved_GB/s': (traffic or 0.0) / t_launch / 1e9, 'frac': (traffic or 0.0) / t_launch / 1e9 / PEAK_HBM_GBS},
+                 'hbm': {'achieved_GB/s': nb / tm / 1e9, 'frac': nb / tm / 1e9 / PEAK_HBM_GBS,
+                         'measured_traffic_GB/s': (traffic or 0.0) / t_launch / 1e9},
                  'measured_over': f'{args.steps} eager single-stream steps right after the timed region, {dt_prof / args.steps * 1e3:.2f} ms/step',
-                 'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'time_share_of_step': v[1] / dt_prof}
+                 'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'GB/s': v[3] / v[1] / 1e9, 'time_share_of_step': v[1] / dt_prof}
                             for k, v in agg.items() if k != kind}}
         if t_hbm > t_mfma:
             res['roofline'] = {'kernel': kind, 'bound': 'hbm', 'achieved': extra['hbm']['achieved_GB/s'], 'peak': PEAK_HBM_GBS,

@@ -78,8 +78,10 @@ class Engine:
             self.bufs[key] = t
         return t
 
-    def timed(self, kind, flops, dev, fn, *args):
-        """launch through `fn`; with profiling on, bracket it with events on the launch stream"""
+    def timed(self, kind, work, dev, fn, *args):
+        """launch through `fn`; with profiling on, bracket it with events on the launch stream.
+        work = algorithmic FLOP of the launch, or (FLOP, algorithmic HBM bytes: every operand once)"""
+        flops, nbytes = work if isinstance(work, tuple) else (work, 0.0)
         if self.prof is None or dev.type != 'cuda':
             return fn(*args)
         pool = getattr(self, 'prof_pool', None)
@@ -90,7 +92,7 @@ class Engine:
         e0.record()
         rc = fn(*args)
         e1.record()
-        self.prof.append((kind, flops, e0, e1))
+        self.prof.append((kind, flops, e0, e1, nbytes))
         return rc
 
     @property
@@ -158,15 +160,17 @@ class Engine:
             (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_stats else None) for g in range(G)]
         for n0, nn_, part in groups:
             if u.kind == 'stem':
-                self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * 64 * 147, dev, lib.stem_fwd,
+                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * 64 * 147, 2.0 * nn_ * (H * W * 4 + Ho * Wo * 64)), dev, lib.stem_fwd,
                            x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
             elif in_bn is not None:     # x is the producer's RAW output: BatchNorm + ReLU folded into the operand load
                 assert (n0, nn_) == (0, N), 'folded input BatchNorm needs the single-launch (fused statistics) path'
-                self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin, dev, lib.conv_fwd_bnin,
+                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
+                                          2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd_bnin,
                            x, in_bn[0], in_bn[1], u.wf, y, bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
                            u.k, u.k, u.stride, u.pad, s)
             else:
-                self.timed('conv_igemm', 2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin, dev, lib.conv_fwd,
+                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
+                                          2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd,
                            x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
                            u.k, u.k, u.stride, u.pad, s)
         if u.bn is not None:
@@ -318,7 +322,9 @@ class Engine:
         nblocks = (ntiles + tpb - 1) // tpb
         partial = self.ws('ws.wgrad', nblocks * 64 * 224, torch.float32, dev)
         with self.on_side_stream(dev):      # ws.wgrad belongs to the side stream
-            self.timed('conv_wgrad', 2.0 * N * H * W * 64 * 147, dev, self.lib.stem_wgrad_fused,
+            self.timed('conv_wgrad', (2.0 * N * H * W * 64 * 147,
+                                      2.0 * N * (Hin * Win * 4 + H * W * 64) + 5.0 * N * Hp * Wp * 64 + 8.0 * nblocks * 64 * 224),
+                       dev, self.lib.stem_wgrad_fused,
                        x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
                        N // G, count, nblocks, self.stream(dev))
 
@@ -335,7 +341,7 @@ class Engine:
             nsplit, pps = wgrad_splits(M, 64, 256)
             partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)
             with self.on_side_stream(dev):
-                self.timed('conv_wgrad', 2.0 * M * 64 * 147, dev, lib.stem_wgrad,
+                self.timed('conv_wgrad', (2.0 * M * 64 * 147, 2.0 * (M * 64 + N * H * W * 4) + 8.0 * nsplit * 64 * 256), dev, lib.stem_wgrad,
                            dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, self.stream(dev))
             return None
         ktot = u.k * u.k * u.cin
@@ -343,15 +349,19 @@ class Engine:
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
         partial = self.ws('ws.wgrad', nsplit * u.cout * ktot, torch.float32, dev)
         flops = 2.0 * M * u.cout * ktot
+        # dY + x once, fp32 split-K partials written and re-read by the reduction, fp32 gradient read-modify-write
+        wbytes = 2.0 * (M * u.cout + N * H * W * u.cin) + 8.0 * nsplit * u.cout * ktot + 8.0 * u.cout * ktot
+        # dgrad: dY + weights in, dx out (+ residual gradient / fused BatchNorm operands when present)
+        dbytes = 2.0 * (M * u.cout + N * H * W * u.cin + u.cout * ktot)
         # the weight gradient only feeds the optimizer: it runs on the side stream, concurrently
         # with the dgrad / BatchNorm-backward kernels of the critical path (joined by wgrad_join)
         with self.on_side_stream(dev):
             ss = self.stream(dev)
             if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
-                self.timed('conv_wgrad', flops, dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
+                self.timed('conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
                            u.weight.grad, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             else:
-                self.timed('conv_wgrad', flops, dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
+                self.timed('conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
                            Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             if u.bias is not None:
                 lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)
@@ -366,12 +376,13 @@ class Engine:
             if G == 1 or mpg % 128 == 0:
                 nblk = (Min + 127) // 128
                 partial = self.ws('ws.bnbwd_fused', nblk * 2 * u.cin, torch.float32, dev)
-                self.timed('conv_igemm', flops, dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,
+                self.timed('conv_igemm', (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + (1 if pymask is not None else 0))),
+                           dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,
                            mpg, 1 if (prelu and pymask is None) else 0, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k,
                            u.stride, u.pad, s)
                 self._fused_bn = (pu, partial, nblk)
                 return gin
-        self.timed('conv_igemm', flops, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
+        self.timed('conv_igemm', (flops, dbytes + (2.0 * N * H * W * u.cin if add is not None else 0.0)), dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
                    u.k, u.k, u.stride, u.pad, s)
         return gin
 
