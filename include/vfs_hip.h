@@ -202,6 +202,17 @@ int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t st
 int vfs_davis_counts(const uint8_t* pred, const uint8_t* gt, int* counts, void* scratch, int T, int H, int W,
                      int nobj, int radius, int use_void, vfs_stream_t stream);
 
+/* ---- training input pipeline (configs/r*_*.py:48-91: RandomResizedCrop -> Resize -> Flip -> Normalize ->
+ * FormatShape NCTHW; pipelines/augmentations.py:171-334,487-596,600-707,711-794) in one pass over the decoded
+ * frames.  src uint8 [B*V*T][Hs][Ws][3] RGB in pipeline order (b, v, t); boxes int32 [F][4] = left, top,
+ * right, bottom; flips uint8 [F]; outputs (either may be NULL): imgs fp32 [B][V][3][T][Ho][Wo] (what
+ * train_step takes), x4 bf16 NHWC4 [V*B*T][Ho][Wp][4] (what vfs_stem_fwd reads).  Bilinear = cv2.resize
+ * INTER_LINEAR on 8-bit data (fixed point), normalisation = mmcv.imnormalize_ (double arithmetic). */
+int vfs_crop_resize_flip_norm(const uint8_t* src, const int* boxes, const uint8_t* flips, float* imgs, vfs_bf16* x4,
+                              int B, int V, int T, int Hs, int Ws, int Ho, int Wo, int Wp, double mean_r,
+                              double mean_g, double mean_b, double std_r, double std_g, double std_b,
+                              vfs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,4 +319,17 @@ int vfs_davis_counts(const uint8_t* pred, const uint8_t* gt, int* counts, void* 
   return vfs_davis_counts_launch(a, S(stream));
 }
 
+int vfs_crop_resize_flip_norm(const uint8_t* src, const int* boxes, const uint8_t* flips, float* imgs, vfs_bf16* x4, int B, int V, int T,
+                              int Hs, int Ws, int Ho, int Wo, int Wp, double mean_r, double mean_g, double mean_b, double std_r,
+                              double std_g, double std_b, vfs_stream_t stream) {
+  if (!src || !boxes || !flips || (!imgs && !x4)) return vfs_set_error(VFS_ERR_ARG, "crop_resize_flip_norm: null buffer");
+  if (x4 && Wp < Wo) return vfs_set_error(VFS_ERR_SHAPE, "crop_resize_flip_norm: Wp < Wo");
+  PipelineArgs a;
+  a.src = src; a.boxes = boxes; a.flips = flips; a.imgs = imgs; a.x4 = x4;
+  a.B = B; a.V = V; a.T = T; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.Wp = Wp;
+  a.mean[0] = mean_r; a.mean[1] = mean_g; a.mean[2] = mean_b;
+  a.stdinv[0] = 1.0 / std_r; a.stdinv[1] = 1.0 / std_g; a.stdinv[2] = 1.0 / std_b;
+  return vfs_crop_resize_flip_norm_launch(a, S(stream));
+}
+
 }  // extern "C"

@@ -165,3 +165,15 @@ struct DavisArgs {
 };
 int vfs_davis_counts_launch(const DavisArgs& a, hipStream_t s);
 
+// training input pipeline (pipeline.hip)
+struct PipelineArgs {
+  const uint8_t* src;    // [F][Hs][Ws][3] decoded RGB frames, F = B*V*T in pipeline order (b, v, t)
+  const int* boxes;      // [F][4] crop box left, top, right, bottom (img[top:bottom, left:right])
+  const uint8_t* flips;  // [F] horizontal flip after the resize
+  float* imgs;           // optional out: fp32 [B][V][3][T][Ho][Wo]
+  bf16_t* x4;            // optional out: bf16 NHWC4 [V*B*T][Ho][Wp][4]
+  int B, V, T, Hs, Ws, Ho, Wo, Wp;
+  double mean[3], stdinv[3];
+};
+int vfs_crop_resize_flip_norm_launch(const PipelineArgs& a, hipStream_t s);
+
