@@ -28,7 +28,10 @@ typedef uint16_t vfs_bf16;
 const char* vfs_last_error(void);
 int vfs_abi_version(void);
 /* tuning knobs for A/B measurements: "halo" (1 = 3x3/stride-1 convs use the halo-tile kernels),
- * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default) */
+ * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default), "bn_ticket",
+ * "igemm_onek" (single-buffer implicit-GEMM variant: 0 never, 1 one-K-step problems, 2 every 1x1 (default), 3 all),
+ * "igemm_ring_tiles" (1x1 problems with at most this many tiles use the LDS-DMA ring, default 512, 0 = off),
+ * "igemm_bc" (64 forces the 64-channel tile) */
 int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------
@@ -71,6 +74,19 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
                       const vfs_bf16* bn_x, const vfs_bf16* bn_y, const float* bnp, float* bn_partial,
                       int bn_mpg, int bn_relu, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
                       int KW, int stride, int pad, vfs_stream_t stream);
+/* Split-K variants for problems with few output pixels and a long reduction - the SimSiam head's Linear
+ * layers (sim_siam_head.py:78-111: 2048x2048 on 64 rows fill 16 workgroups otherwise): the K loop is cut into
+ * ksplit slices that run as separate workgroups; the last slice to finish adds the fp32 partial tiles in
+ * slice order (deterministic) and runs the usual epilogue (bias, statistics rows).  ks_ws: float workspace,
+ * 1024 + tiles * ksplit * 128 * BC floats with tiles = ceil(M/128) * ceil(Cout/BC) <= 1024, BC = 128 when
+ * Cout % 128 == 0 else 64; its first 1024 words (tickets) must be zero before the first launch and are left
+ * zero.  Stride-1 problems only for the dgrad; ksplit == 1 is the plain kernel. */
+int vfs_conv_fwd_splitk(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats,
+                        float* ks_ws, int ksplit, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                        int KW, int stride, int pad, vfs_stream_t stream);
+int vfs_conv_dgrad_splitk(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, float* ks_ws,
+                          int ksplit, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                          int stride, int pad, vfs_stream_t stream);
 /* conv-BN-ReLU -> conv without materialising the activation: x_raw is the RAW output of the producer unit,
  * in_bnp its float[G][4][Cin] {scale, shift, mean, invstd}, in_npg images per group; relu(x*scale+shift)
  * (rounded to bf16 exactly as vfs_bn_act) is applied while the halo patch is staged, padding stays zero.

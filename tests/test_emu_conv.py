@@ -77,6 +77,11 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (1, 12, 10, 64, 128, 3, 2, 1),
     (3, 7, 7, 128, 64, 1, 1, 0),
     (2, 8, 8, 64, 128, 1, 2, 0),
+    (2, 8, 8, 64, 64, 1, 1, 0),       # one K-step (Ktot == 64): single-buffer variant, 64-channel tile
+    (1, 12, 12, 64, 256, 1, 1, 0),    # one K-step, two 128-channel tiles, ragged M = 144
+    (3, 7, 7, 512, 64, 1, 1, 0),      # DMA-ring variant (1x1, K >= 256): 8 K-steps, 64-channel tile, ragged M = 147
+    (2, 8, 8, 256, 256, 1, 1, 0),     # DMA-ring variant: 4 K-steps forward and dgrad, two 128-channel tiles
+    (1, 5, 5, 320, 128, 1, 1, 0),     # DMA-ring variant: odd number of K-steps (5), one ragged tile
     (2, 9, 11, 64, 64, 3, 2, 1),      # odd sizes: unequal parity classes in the stride-2 dgrad
     (1, 16, 32, 128, 64, 3, 1, 1),    # halo-tile kernel: 8x16 spatial tiles, two channel chunks
     (4, 8, 8, 64, 128, 3, 1, 1),      # halo-tile kernel: two whole 8x8 images per workgroup
@@ -87,6 +92,19 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', CASES)
 def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', [(3, 7, 7, 128, 64, 1, 1, 0), (2, 9, 11, 64, 64, 3, 2, 1), (1, 12, 12, 256, 128, 1, 1, 0)])
+def test_conv_single_buffer_variant(backend, N, H, W, Cin, Cout, k, stride, pad):
+    """the single-buffer implicit-GEMM kernel on multi-K-step problems of every kind (option igemm_onek = 3),
+    without the DMA ring taking the 1x1 cases"""
+    backend.lib.set_option(b'igemm_onek', 3)
+    backend.lib.set_option(b'igemm_ring_tiles', 0)
+    try:
+        run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
+    finally:
+        backend.lib.set_option(b'igemm_onek', 2)
+        backend.lib.set_option(b'igemm_ring_tiles', 512)
 
 
 @pytest.mark.parametrize('shape', [(48, 40, 3, 3), (70, 33, 1, 1), (5, 3, 5, 5), (64, 64, 3, 3), (130, 257, 1, 1)])
@@ -113,6 +131,7 @@ def test_pack_weights_ragged(backend, shape):
     (4, 8, 8, 128, 128, 3, 2),      # halo dgrad on whole 8x8 images (two per tile)
     (3, 7, 7, 128, 64, 1, 1),       # generic kernel, ragged M = 147
     (2, 8, 8, 64, 128, 1, 1),       # generic kernel, 64 output channels (32-channel waves)
+    (2, 8, 8, 64, 64, 1, 1),        # generic kernel, one K-step
 ])
 @pytest.mark.parametrize('mask', ['y', 'relu', 'none'])
 def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, mask):
@@ -264,3 +283,47 @@ def test_stem_fwd_wgrad(backend):
     grad = torch.zeros(64, 3, 7, 7, device=dev)
     lib.stem_wgrad(d(nhwc(dy)), x4, partial, grad, N, H, W, Ho, Wo, nsplit, pps, None)
     assert relerr(grad.cpu(), wr.grad) < 3e-4
+
+
+@pytest.mark.parametrize('M,Cin,Cout', [(64, 512, 256), (200, 256, 192), (8, 1024, 128)])
+def test_splitk_linear_matches_plain_kernel(backend, M, Cin, Cout):
+    """the head's Linear layers (1x1 conv on 1x1 'images'): split-K forward / dgrad = the plain kernel up to the
+    fp32 summation order, statistics rows included; the tickets come back to zero (second launch works)"""
+    from vfs_amd.packing import igemm_ksplit
+    lib, d = backend.lib, backend.d
+    g = torch.Generator().manual_seed(M + Cin)
+    x = rb(torch.randn(M, Cin, 1, 1, generator=g))
+    w = rb(torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    wf, wd = pack(backend, w)
+    xh = d(nhwc(x))
+    ks, need = igemm_ksplit(M, Cout, Cin)
+    assert ks > 1 and need > 1024
+    ws = torch.zeros(need, device=backend.dev)
+    nblk = (M + 127) // 128
+    outs = []
+    for which in ('plain', 'split', 'split'):
+        y = torch.full((M, 1, 1, Cout), float('nan'), dtype=torch.bfloat16, device=backend.dev)
+        st = torch.full((nblk, 2, Cout), float('nan'), device=backend.dev)
+        if which == 'plain':
+            lib.conv_fwd(xh, wf, y, d(bias), st, M, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 0, None)
+        else:
+            lib.conv_fwd_splitk(xh, wf, y, d(bias), st, ws, ks, M, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 0, None)
+        outs.append((y.float().cpu(), st.cpu()))
+    assert torch.equal(ws[:1024].cpu(), torch.zeros(1024))
+    ref = F.conv2d(x, w, bias)
+    for y, st in outs:
+        assert relerr(nchw(y), ref) < 6e-3
+    assert relerr(outs[1][0], outs[0][0]) < 4e-3 and torch.equal(outs[1][0], outs[2][0])     # deterministic
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=2e-2, atol=0.5) and torch.equal(outs[1][1], outs[2][1])
+    # dgrad with the residual-gradient add
+    dy = rb(torch.randn(M, Cout, 1, 1, generator=g))
+    add = rb(torch.randn(M, Cin, 1, 1, generator=g))
+    ks2, need2 = igemm_ksplit(M, Cin, Cout)
+    if ks2 > 1:
+        ws2 = torch.zeros(need2, device=backend.dev)
+        dx = torch.full((M, 1, 1, Cin), float('nan'), dtype=torch.bfloat16, device=backend.dev)
+        lib.conv_dgrad_splitk(d(nhwc(dy)), wd, dx, d(nhwc(add)), ws2, ks2, M, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 0, None)
+        want = torch.einsum('mo,oi->mi', dy[:, :, 0, 0], w[:, :, 0, 0]) + add[:, :, 0, 0]
+        assert relerr(dx.float().cpu()[:, 0, 0], want) < 6e-3
+        assert torch.equal(ws2[:1024].cpu(), torch.zeros(1024))

@@ -28,6 +28,7 @@ int vfs_option_halo = 1;
 int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket;
 int vfs_option_stem_direct = 1;
+extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -46,6 +47,9 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "stem_blocks")) { vfs_option_stem_blocks = value; return VFS_OK; }
   if (!strcmp(name, "bn_ticket")) { vfs_option_bn_ticket = value; return VFS_OK; }
   if (!strcmp(name, "stem_direct")) { vfs_option_stem_direct = value; return VFS_OK; }
+  if (!strcmp(name, "igemm_bc")) { vfs_option_igemm_bc = value; return VFS_OK; }
+  if (!strcmp(name, "igemm_onek")) { vfs_option_igemm_onek = value; return VFS_OK; }
+  if (!strcmp(name, "igemm_ring_tiles")) { vfs_option_igemm_ring_tiles = value; return VFS_OK; }
   return vfs_set_error(VFS_ERR_ARG, "vfs_set_option: unknown option");
 }
 
@@ -65,6 +69,29 @@ int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float
   a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
   a.in_bnp = nullptr; a.in_npg = 0;
   return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
+}
+int vfs_conv_fwd_splitk(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, float* ks_ws, int ksplit,
+                        int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                        vfs_stream_t stream) {
+  if (ksplit < 1 || (ksplit > 1 && !ks_ws)) return vfs_set_error(VFS_ERR_ARG, "conv_fwd_splitk: workspace");
+  ConvArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
+  a.ks_ws = ks_ws; a.ksplit = ksplit;
+  return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
+}
+int vfs_conv_dgrad_splitk(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, float* ks_ws, int ksplit, int N,
+                          int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                          vfs_stream_t stream) {
+  if (ksplit < 1 || (ksplit > 1 && !ks_ws)) return vfs_set_error(VFS_ERR_ARG, "conv_dgrad_splitk: workspace");
+  if (stride != 1) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_splitk: stride 1 only");
+  ConvArgs a;
+  a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
+  a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
+  a.ks_ws = ks_ws; a.ksplit = ksplit;
+  return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
 }
 int vfs_conv_fwd_bnin(const vfs_bf16* x_raw, const float* in_bnp, int in_npg, const vfs_bf16* wf, vfs_bf16* y, const float* bias,
                       float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,

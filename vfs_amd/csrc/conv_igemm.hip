@@ -28,20 +28,37 @@
 
 #define OOB_OFFSET 0xFFFFFFF0u   // >= any num_records: the load returns zeros
 
-template <int BC, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// ONEK ("single buffer"): ONE operand buffer instead of two - the arena shrinks from 64 to 37 KB and, with the
+// smaller register budget, three to four workgroups share a CU instead of two.  The 1x1 convolutions are HBM-bound
+// latency chains (load -> LDS -> a few MFMA -> stage -> store): more of them in flight hides the latency better
+// than the double buffer does (measured on the 64->256 layer of ResNet-50: 60 -> 42 us).  With more than one K-step
+// the price is a second barrier per step (the tile may only be overwritten once every wave has read it); the
+// register prefetch of the next tile still overlaps the MFMAs.
+// PIPE = 3: LDS ring of three stages (a fourth stage measured no faster) filled by LDS-DMA (buffer_load ... lds), for the pure-GEMM case (1x1, stride 1) with a
+// long reduction and few workgroups (ResNet-50's 16x16 / 8x8 stages, the head's Linear layers).  Those launches
+// are ONE dependent chain of K-steps per workgroup; with the register double buffer a step costs a full global
+// round trip (~0.9 us measured, 32 steps), with two steps of DMA in flight it costs the MFMAs plus a barrier.
+// Lane l of a DMA piece lands at piece_base + 16*l, so each lane FETCHES the (row, chunk) whose swizzled slot
+// that is.  Rows past the ragged end re-fetch a valid row (their outputs are masked by the epilogue).
+template <int BC, int MODE, int PIPE, bool FBN>
+__global__ __launch_bounds__(256, PIPE >= 3 ? 1 : ((PIPE == 1 && !FBN) ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
+  constexpr bool ONEK = (PIPE == 1);
   constexpr int BP = 128;
   constexpr int WC = BC / 2;   // channels per wave
   constexpr int TM = WC / 16;  // 16-channel tiles per wave
   constexpr int TN = 4;        // 16-pixel tiles per wave
   constexpr int WLD = BC / 32; // weight rows loaded per thread
-  // one arena [2 weight tiles | 2 pixel tiles]; after the K loop the epilogue re-uses it as output stage
+  constexpr bool CAN_BN = FBN;
+  // one arena [weight tiles | pixel tiles]; after the K loop the epilogue re-uses it as output stage
   constexpr int SROW = WC + 8;                    // staged pixel row: WC channels + 16 bytes of padding
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BC * 64 + 2 * BP * 64];
-  static_assert(2 * BC * 64 + 2 * BP * 64 >= 4 * 64 * SROW, "output stage does not fit");
+  constexpr int NBUF = PIPE >= 3 ? PIPE : (ONEK ? 1 : 2);
+  constexpr int OPER = NBUF * (BC * 64 + BP * 64);
+  constexpr int STAGE = 4 * 64 * SROW + (CAN_BN ? 4 * (64 / (WC / 8)) * 2 * WC * 2 : 0);   // + statistics rows (floats)
+  constexpr int SMEM = OPER > STAGE ? OPER : STAGE;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
   __shared__ float sRed[2][BC][2];
   bf16_t (*sW)[BC * 64] = reinterpret_cast<bf16_t (*)[BC * 64]>(smem);
-  bf16_t (*sX)[BP * 64] = reinterpret_cast<bf16_t (*)[BP * 64]>(smem + 2 * BC * 64);
+  bf16_t (*sX)[BP * 64] = reinterpret_cast<bf16_t (*)[BP * 64]>(smem + NBUF * BC * 64);
 
   const ConvGeom g = a.g;
   const int t = threadIdx.x;
@@ -123,8 +140,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.wgt, 0, (unsigned)((size_t)a.Cout * g.Ktot * 2), 0x00020000);
 
+  // split-K: this workgroup owns K-steps [kbeg, kend) of nk
+  const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  const int kslice = ksplit > 1 ? (int)blockIdx.z : 0;
+  const int kper = (nk + ksplit - 1) / ksplit;
+  const int kbeg = min(nk, kslice * kper), kend = min(nk, kbeg + kper);
+
   u32x4 xr[4], wr[WLD];
   int l_cc = 0, l_ri = 0, l_si = 0, l_ti = 0;   // K-step counters of the NEXT load (uniform, no divisions)
+  if (MODE != GATHER_STEM && kbeg > 0) {
+    l_ti = kbeg / cpt; l_cc = kbeg - l_ti * cpt;
+    l_ri = l_ti / ns; l_si = l_ti - l_ri * ns;
+  }
   auto load_tiles = [&](int kt) {                // called with kt = 0, 1, 2, ... in order
     // uniform decode of the K-step: tap index, source delta (bytes), weight column (bytes)
     int ti, delta, wcol;
@@ -169,19 +196,96 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) {
-    load_tiles(0);
+  if (PIPE >= 3) {
+    constexpr int XQ = 4, WQ = BC / 32, NPW = XQ + WQ;          // DMA pieces (1 KB) per wave and K-step
+    const vfs_rsrc_words xrw = vfs_make_rsrc_words(a.src, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2));
+    const vfs_rsrc_words wrw = vfs_make_rsrc_words(a.wgt, (unsigned)((size_t)a.Cout * g.Ktot * 2));
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned xvo[XQ], wvo[WQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int slot = (wave_u * XQ + q) * 64 + lane, row = slot >> 3, chunk = (slot & 7) ^ ((row >> 1) & 7);
+      const int m = m0 + row < Mc ? m0 + row : m0;
+      xvo[q] = (unsigned)(((size_t)m * g.C) * 2 + chunk * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int slot = (wave_u * WQ + q) * 64 + lane, row = slot >> 3, chunk = (slot & 7) ^ ((row >> 1) & 7);
+      const int c = c0 + row < a.Cout ? c0 + row : c0;
+      wvo[q] = (unsigned)(((size_t)c * g.Ktot) * 2 + chunk * 16);
+    }
+    auto issue = [&](int kt, int st) {
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) vfs_dma16_async(xrw, sX[st] + (wave_u * XQ + q) * 512, xvo[q], (unsigned)kt * 128u);
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) vfs_dma16_async(wrw, sW[st] + (wave_u * WQ + q) * 512, wvo[q], (unsigned)kt * 128u);
+    };
+#pragma unroll
+    for (int d = 0; d < PIPE - 1; ++d)
+      if (kbeg + d < kend) issue(kbeg + d, d);
+    int st = 0;
+    for (int kt = kbeg; kt < kend; ++kt) {
+      // this wave's pieces of step kt have landed: at most the pieces of the later steps already issued stay in flight
+      const int ahead = min(PIPE - 2, kend - 1 - kt);
+      if (ahead >= 2) vfs_dma_wait<2 * NPW>(); else if (ahead == 1) vfs_dma_wait<NPW>(); else vfs_dma_wait<0>();
+      __syncthreads();                       // ... everybody's have, and everybody is done with step kt - 1
+      const int nst = st == 0 ? PIPE - 1 : st - 1;   // the stage step kt - 1 used
+      if (kt + PIPE - 1 < kend) issue(kt + PIPE - 1, nst);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_kstep<TM, TN, false>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st == PIPE - 1 ? 0 : st + 1;
+    }
+    __syncthreads();                         // the epilogue re-uses the arena
+  } else if (kend > kbeg) {
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      const bool more = kt + 1 < nk;
+    for (int kt = kbeg; kt < kend; ++kt) {
+      const int cur = ONEK ? 0 : (kt - kbeg) & 1;
+      const bool more = kt + 1 < kend;
       if (more) load_tiles(kt + 1);
       __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the MFMAs (the scheduler sinks them)
       mma_kstep<TM, TN, false>(sW[cur], sX[cur], wc * WC, wp * 64, lane, acc);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) store_tiles(cur ^ 1);
+      if (more) {
+        if (ONEK) __syncthreads();                // single buffer: every wave is done reading the tile
+        store_tiles(ONEK ? 0 : cur ^ 1);
+      }
       __syncthreads();
+    }
+  }
+
+  // ---------------- split-K hand-off ----------------
+  // every slice parks its accumulators (accumulator layout: 16 coalesced bytes per lane) with device-coherent
+  // stores and takes a ticket; the last one to arrive adds the slices up in slice order - the result does not
+  // depend on the arrival order - and goes on to the epilogue.  Tickets return to zero for the next launch.
+  if (ksplit > 1) {
+    __shared__ unsigned s_ticket;
+    const int tile = blockIdx.x;
+    unsigned* tickets = reinterpret_cast<unsigned*>(a.ks_ws);
+    float* parts = a.ks_ws + KS_TICKETS + (size_t)tile * ksplit * (TM * TN * 1024);
+    float* mine = parts + (size_t)kslice * (TM * TN * 1024);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) vfs_store_agent(mine + ((tm * TN + tn) * 256 + t) * 4, acc[tm][tn]);
+    vfs_release_workgroup();
+    __syncthreads();
+    if (t == 0) s_ticket = vfs_ticket_agent(&tickets[tile % KS_TICKETS]);
+    __syncthreads();
+    if (s_ticket != (unsigned)ksplit - 1u) return;
+    if (t == 0) vfs_store_agent(&tickets[tile % KS_TICKETS], 0u);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < ksplit; ++sl) {
+      const float* p = parts + (size_t)sl * (TM * TN * 1024);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] += vfs_load_agent4(p + ((tm * TN + tn) * 256 + t) * 4);
     }
   }
 
@@ -208,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // fused BatchNorm-backward statistics of the output (vfs_conv.h): the lane's operand rows are requested
   // NOW (one HBM round trip overlapped with the staging below), consumed in the row-store loop
   constexpr int CPR = WC / 8, PPI = 64 / CPR;     // 16-byte chunks per staged row, pixels per store instruction
-  const bool do_bn = a.bn.partial != nullptr;
+  const bool do_bn = CAN_BN && a.bn.partial != nullptr;
   BnFuseLane bl;
   u32x4 bxv[CPR], byv[CPR];
   if (do_bn && c0 + wc * WC + (lane % CPR) * 8 < a.Cout) {
@@ -270,7 +374,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     if (do_bn) {   // uniform: one {S1, S2} row per 128-pixel workgroup, summed over pixel groups and the two pixel waves
       float* sB = reinterpret_cast<float*>(smem + 4 * 64 * SROW);
-      static_assert((2 * BC * 64 + 2 * BP * 64) * 2 >= 4 * 64 * SROW * 2 + 4 * PPI * 2 * WC * 4, "statistics do not fit");
+      static_assert(!CAN_BN || SMEM * 2 >= 4 * 64 * SROW * 2 + 4 * PPI * 2 * WC * 4, "statistics do not fit");
       if (c >= a.Cout) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { bl.s1[k] = 0.f; bl.s2[k] = 0.f; }
@@ -314,7 +418,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------ host launcher
-template <int BC, int MODE>
+int vfs_option_igemm_bc = 0;     // 64: force the 64-channel tile (A/B knob)
+int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
+int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
+
+template <int BC, int MODE, int PIPE = 0, bool FBN = false>
 static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
   int M = a.g.M, classes = 1;
   if (MODE == GATHER_DGRAD2) {   // largest parity class: ceil(Ho/2) x ceil(Wo/2)
@@ -323,7 +431,13 @@ static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
   }
   int npb = (M + 127) / 128;
   int ncb = (a.Cout + BC - 1) / BC;
-  hipLaunchKernelGGL((conv_igemm_kernel<BC, MODE>), dim3(npb * ncb, classes), dim3(256), 0, stream, a);
+  int ks = 1;
+  if (a.ksplit > 1) {
+    if (MODE == GATHER_DGRAD2 || MODE == GATHER_STEM || !a.ks_ws || npb * ncb > KS_TICKETS)
+      return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: split-K needs a stride-1 problem with at most 1024 tiles and a workspace");
+    ks = a.ksplit;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BC, MODE, PIPE, FBN>), dim3(npb * ncb, classes, ks), dim3(256), 0, stream, a);
   return vfs_check_launch("conv_igemm");
 }
 
@@ -338,13 +452,32 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: tensor >= 4 GiB (split the batch)");
   if (a.bn.partial && (mode != GATHER_DGRAD || a.g.stride != 1))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: fused BatchNorm-backward statistics need a stride-1 dgrad");
-  const bool wide = (a.Cout % 128 == 0);
+  const bool wide = (a.Cout % 128 == 0) && vfs_option_igemm_bc != 64;
+  const bool onek = vfs_option_igemm_onek >= 3 || (vfs_option_igemm_onek == 2 && a.g.KH * a.g.KW == 1) ||
+                    (vfs_option_igemm_onek == 1 && a.g.Ktot == 64);
+  // DMA ring: pure GEMM (1x1, stride 1, no padding), at least 4 K-steps, at most vfs_option_igemm_ring_tiles tiles
+  const int bc = wide ? 128 : 64;
+  const long long tiles = (long long)((a.g.M + 127) / 128) * ((a.Cout + bc - 1) / bc);
+  const bool ring = vfs_option_igemm_ring_tiles > 0 && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
+                    a.g.Ktot >= 256 && tiles <= vfs_option_igemm_ring_tiles && !a.bn.partial &&
+                    (mode == GATHER_FWD || mode == GATHER_DGRAD);
+  if (ring) {
+    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(a, stream) : launch_igemm<64, GATHER_FWD, 3>(a, stream);
+    return wide ? launch_igemm<128, GATHER_DGRAD, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3>(a, stream);
+  }
   switch (mode) {
     case GATHER_FWD:
+      if (onek) return wide ? launch_igemm<128, GATHER_FWD, 1>(a, stream) : launch_igemm<64, GATHER_FWD, 1>(a, stream);
       return wide ? launch_igemm<128, GATHER_FWD>(a, stream) : launch_igemm<64, GATHER_FWD>(a, stream);
     case GATHER_DGRAD:
-      if (a.g.stride == 1)
+      if (a.g.stride == 1) {
+        if (a.bn.partial) {
+          if (onek) return wide ? launch_igemm<128, GATHER_DGRAD, 1, true>(a, stream) : launch_igemm<64, GATHER_DGRAD, 1, true>(a, stream);
+          return wide ? launch_igemm<128, GATHER_DGRAD, 0, true>(a, stream) : launch_igemm<64, GATHER_DGRAD, 0, true>(a, stream);
+        }
+        if (onek) return wide ? launch_igemm<128, GATHER_DGRAD, 1>(a, stream) : launch_igemm<64, GATHER_DGRAD, 1>(a, stream);
         return wide ? launch_igemm<128, GATHER_DGRAD>(a, stream) : launch_igemm<64, GATHER_DGRAD>(a, stream);
+      }
       if (a.g.stride == 2)
         return wide ? launch_igemm<128, GATHER_DGRAD2>(a, stream) : launch_igemm<64, GATHER_DGRAD2>(a, stream);
       return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad: stride must be 1 or 2");

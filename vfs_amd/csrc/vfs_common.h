@@ -83,6 +83,12 @@ __device__ __forceinline__ void vfs_dma16_async(vfs_rsrc_words rsrc, void* lds_w
       : "memory");
 }
 __device__ __forceinline__ void vfs_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's vector-memory operations (DMA pieces) are still in flight
+template <int N>
+__device__ __forceinline__ void vfs_dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#else
+template <int N>
+inline void vfs_dma_wait() {}
 #endif
 
 // Device-coherent (agent scope) relaxed accesses for small inter-workgroup hand-offs: sc1 stores / loads
@@ -97,10 +103,37 @@ __device__ __forceinline__ void vfs_store_agent(double* p, double v) {
 __device__ __forceinline__ double vfs_load_agent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void vfs_store_agent(float* p, f32x4 v) {
+  __hip_atomic_store(p, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 2, v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 3, v[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 vfs_load_agent4(const float* p) {
+  f32x4 v;
+  v[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v[1] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v[2] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v[3] = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+__device__ __forceinline__ void vfs_store_agent(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned vfs_ticket_agent(unsigned* p) {
   return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void vfs_release_workgroup() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+#else   // host emulation: blocks run on different threads
+inline void vfs_store_agent(float* p, f32x4 v) {
+  for (int i = 0; i < 4; ++i) { float x = v[i]; __atomic_store(p + i, &x, __ATOMIC_SEQ_CST); }
+}
+inline f32x4 vfs_load_agent4(const float* p) {
+  f32x4 v;
+  for (int i = 0; i < 4; ++i) { float x; __atomic_load(const_cast<float*>(p + i), &x, __ATOMIC_SEQ_CST); v[i] = x; }
+  return v;
+}
+inline void vfs_store_agent(unsigned* p, unsigned v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
 #endif
 
 __device__ __forceinline__ u32x4 zero16() {

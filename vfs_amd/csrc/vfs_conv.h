@@ -54,7 +54,14 @@ struct ConvArgs {
   // in_npg = images per statistics group.  The activation tensor is never written or read.
   const float* in_bnp;
   int in_npg;
+  // optional split-K (implicit-GEMM kernel, small pixel counts: the SimSiam head's Linear layers): the K loop
+  // is cut into ksplit slices (blockIdx.z); ks_ws = unsigned tickets[KS_TICKETS] (zero before the first launch,
+  // left at zero) followed by float partial tiles [tile][slice][...]; the LAST slice to arrive sums the
+  // partials in slice order (deterministic) and runs the epilogue.
+  float* ks_ws = nullptr;
+  int ksplit = 1;
 };
+#define KS_TICKETS 1024
 
 struct WgradArgs {
   ConvGeom g;          // geometry of the FORWARD conv (gather source = forward input)

@@ -15,9 +15,11 @@ import torch
 import torch.distributed as dist
 
 from ._lib import get_lib
-from .packing import bn_fold_eligible, build_pack_table, wgrad_halo_eligible, wgrad_splits
+from .packing import igemm_ksplit, bn_fold_eligible, build_pack_table, wgrad_halo_eligible, wgrad_splits
 
 BF16 = torch.bfloat16
+
+KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's Linear layers (slower as measured)
 
 
 class ConvUnit:
@@ -46,6 +48,9 @@ class Engine:
         self._side = {}
         self._side_dirty = False
         self.prof = None     # list collecting (kind, flops, start_event, end_event) when profiling
+        for kv in filter(None, os.environ.get('VFS_OPTS', '').split(',')):      # kernel A/B knobs: "name=value,..."
+            name, value = kv.split('=')
+            self.lib.set_option(name.strip().encode(), int(value))
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -169,10 +174,15 @@ class Engine:
                            x, in_bn[0], in_bn[1], u.wf, y, bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
                            u.k, u.k, u.stride, u.pad, s)
             else:
-                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
-                                          2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd,
-                           x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
-                           u.k, u.k, u.stride, u.pad, s)
+                ks, ksws = igemm_ksplit(nn_ * Ho * Wo, u.cout, u.k * u.k * u.cin) if (u.k == 1 and KSPLIT) else (1, 0)
+                work = (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
+                        2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin))
+                if ks > 1:      # few pixels, long reduction (the head's Linear layers): split-K fills the chip
+                    self.timed('conv_igemm', work, dev, lib.conv_fwd_splitk, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
+                               self.ksplit_ws(ksws, dev), ks, nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
+                else:
+                    self.timed('conv_igemm', work, dev, lib.conv_fwd, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
+                               nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
         if u.bn is not None:
             bn = u.bn
             if train:
@@ -208,6 +218,16 @@ class Engine:
         if not (G == 1 or mpg % 128 == 0):      # the consumer must take the single-launch statistics path
             return False
         return bn_fold_eligible(N, G if train else 1, H, W, u.cin, u.cout, u.k, u.stride, u.pad)
+
+    def ksplit_ws(self, need, dev):
+        """workspace of the split-K kernels: 1024 ticket words (zero between launches) + partial tiles"""
+        t = self.bufs.get('ws.ksplit')
+        if t is None or t.numel() < need or t.device != dev:
+            if t is not None and dev.type == 'cuda':
+                torch.cuda.synchronize(dev)
+            t = torch.zeros(int(need), dtype=torch.float32, device=dev)
+            self.bufs['ws.ksplit'] = t
+        return t
 
     def bn_scratch(self, G, C, dev):
         """scratch of the chunked BatchNorm reductions: 64 ticket counters (must start at zero; every
@@ -369,7 +389,8 @@ class Engine:
             return None
         gin = g_out if g_out is not None else self.buf(f'{u.name}.gin', (N, H, W, u.cin), BF16, dev)
         self._fused_bn = None
-        if bn_next is not None and u.stride == 1 and os.environ.get('VFS_BN_FUSE', '1') == '1':
+        ks, ksws = igemm_ksplit(N * H * W, u.cin, ktot // u.cin * u.cout) if (u.k == 1 and u.stride == 1 and KSPLIT) else (1, 0)
+        if ks == 1 and bn_next is not None and u.stride == 1 and os.environ.get('VFS_BN_FUSE', '1') == '1':
             pu, praw, pymask, prelu, G = bn_next
             Min = N * H * W
             mpg = Min // G
@@ -382,8 +403,13 @@ class Engine:
                            u.stride, u.pad, s)
                 self._fused_bn = (pu, partial, nblk)
                 return gin
-        self.timed('conv_igemm', (flops, dbytes + (2.0 * N * H * W * u.cin if add is not None else 0.0)), dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
-                   u.k, u.k, u.stride, u.pad, s)
+        work = (flops, dbytes + (2.0 * N * H * W * u.cin if add is not None else 0.0))
+        if ks > 1:
+            self.timed('conv_igemm', work, dev, lib.conv_dgrad_splitk, dx, u.wd, gin, add, self.ksplit_ws(ksws, dev), ks, N, H, W, u.cin,
+                       Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
+        else:
+            self.timed('conv_igemm', work, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
+                       u.k, u.k, u.stride, u.pad, s)
         return gin
 
 

@@ -54,6 +54,24 @@ def bn_fold_eligible(N, G, H, W, Cin, Cout, k, stride, pad):
     return N % G == 0 and G <= 8
 
 
+def igemm_ksplit(M, Cout, Ktot, target_blocks=256):
+    """Split-K plan of the implicit-GEMM kernel for problems that would not fill the chip (the head's Linear
+    layers): (ksplit, workspace floats).  ksplit == 1: plain kernel, no workspace.
+    The engine only uses it under VFS_KSPLIT=1: measured on MI355X the exchange of fp32 partial tiles through
+    device-coherent memory costs more than the 16-workgroup launches it replaces (R50 step 11.4 -> 11.85 ms)."""
+    bc = 128 if Cout % 128 == 0 else 64
+    tiles = ((M + 127) // 128) * ((Cout + bc - 1) // bc)
+    nk = Ktot // 64
+    if tiles >= 128 or tiles > 1024 or nk < 4:
+        return 1, 0
+    ks = max(1, min(nk // 2, (target_blocks + tiles - 1) // tiles))      # at least two K-steps per slice
+    per = (nk + ks - 1) // ks
+    ks = (nk + per - 1) // per
+    if ks <= 1:
+        return 1, 0
+    return ks, 1024 + tiles * ks * 128 * bc
+
+
 def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
     """Split-K plan for the wgrad kernels: (nsplit, pix_per_split).  halo_geom = (N, H, W, Cin)
     selects the plan of the 3x3 halo kernel (workgroup = 64 cin x 64 cout x 9 taps, split over
