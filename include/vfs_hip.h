@@ -180,6 +180,9 @@ int vfs_avgpool_bwd(const vfs_bf16* g, vfs_bf16* gx, int N, int HW, int C, vfs_s
 int vfs_cosine_loss_fwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2,
                         const vfs_bf16* z2, float* loss, int N, int C, int T, int K, int negative,
                         float weight, vfs_stream_t stream);
+/* BaseTracker._parse_losses (trackers/base.py:76-110) of the K loss rows: means[k] = mean(loss[k][:]) for k < K,
+ * means[K] = sum of the K means (the 'loss' entry); double accumulation, fixed order.  means: float[K+1] */
+int vfs_loss_means(const float* loss, float* means, int K, int N, vfs_stream_t stream);
 int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2,
                         const vfs_bf16* z2, const float* gloss, vfs_bf16* dp1, vfs_bf16* dp2, int N,
                         int C, int T, int K, int negative, float weight, vfs_stream_t stream);

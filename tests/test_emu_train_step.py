@@ -247,3 +247,42 @@ def test_graph_replay_equals_eager(gpu_backend, monkeypatch):
     assert l0 == l1, (l0, l1)
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+@pytest.mark.gpu
+def test_fast_train_step_equals_parse_losses_path(gpu_backend, monkeypatch):
+    """SimSiamBaseTracker.train_step (loss rows reduced by vfs_loss_means inside the forward chain, one host
+    read) against BaseTracker.train_step (forward_train dict -> _parse_losses with torch ops): same keys,
+    same values up to the summation order of the mean, bit-identical parameter update."""
+    import vfs_amd
+    from vfs_amd.trackers import BaseTracker
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', 'vfs_r18.py'))
+    dev = gpu_backend.dev
+    shape = [4, 2, 3, 2, 64, 64]
+    batches = [O.fill_tensor(shape, seed=60 + i, scale=2.0).to(dev) for i in range(3)]
+
+    def run(fast):
+        model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        model.load_state_dict(_filled(18).state_dict())
+        model.to(dev).train()
+        opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+        logs = []
+        for b in batches:
+            batch = dict(imgs=b, label=torch.zeros(shape[0], 1))
+            out = model.train_step(batch, opt) if fast else BaseTracker.train_step(model, batch, opt)
+            opt.zero_grad()
+            out['loss'].backward()
+            opt.step()
+            logs.append(out['log_vars'])
+            assert out['num_samples'] == shape[0] and out['loss'].dim() == 0
+        torch.cuda.synchronize()
+        return logs, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    la, sda = run(True)
+    lb, sdb = run(False)
+    for a, b in zip(la, lb):
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            assert isinstance(a[k], float) and abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    for k in sda:
+        assert torch.equal(sda[k], sdb[k]), k

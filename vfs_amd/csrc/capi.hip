@@ -296,6 +296,10 @@ int vfs_cosine_loss_fwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
   a.weight = weight;
   return vfs_cosine_loss_fwd_launch(a, S(stream));
 }
+int vfs_loss_means(const float* loss, float* means, int K, int N, vfs_stream_t stream) {
+  if (!loss || !means) return vfs_set_error(VFS_ERR_ARG, "loss_means: null buffer");
+  return vfs_loss_means_launch(loss, means, K, N, S(stream));
+}
 int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* p2, const vfs_bf16* z2, const float* gloss,
                         vfs_bf16* dp1, vfs_bf16* dp2, int N, int C, int T, int K, int negative, float weight,
                         vfs_stream_t stream) {

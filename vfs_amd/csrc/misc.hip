@@ -274,6 +274,27 @@ __global__ __launch_bounds__(64) void cosine_loss_bwd_kernel(LossArgs a) {
     if (c < a.C) out[(size_t)i * a.C + c] = f2bf(acc[q]);
   }
 }
+// _parse_losses (trackers/base.py:76-110) for the K unreduced loss rows of one step: means[k] = mean_i loss[k][i],
+// means[K] = their sum ('loss').  One wave, fixed summation order, double accumulation.
+__global__ __launch_bounds__(64) void loss_means_kernel(const float* __restrict__ loss, float* __restrict__ means, int K, int N) {
+  const int lane = threadIdx.x;
+  double total = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    for (int i = lane; i < N; i += 64) acc += (double)loss[(size_t)k * N + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    const float m = (float)(acc / (double)N);
+    if (lane == 0) means[k] = m;
+    total += (double)m;
+  }
+  if (lane == 0) means[K] = (float)total;
+}
+int vfs_loss_means_launch(const float* loss, float* means, int K, int N, hipStream_t s) {
+  if (K <= 0 || N <= 0) return vfs_set_error(VFS_ERR_SHAPE, "loss_means: empty");
+  hipLaunchKernelGGL(loss_means_kernel, dim3(1), dim3(64), 0, s, loss, means, K, N);
+  return vfs_check_launch("loss_means");
+}
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(cosine_loss_fwd_kernel, dim3(a.N, a.K), dim3(64), 0, s, a);
   return vfs_check_launch("cosine_loss_fwd");

@@ -123,6 +123,7 @@ struct LossArgs {
   float weight;
 };
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
+int vfs_loss_means_launch(const float* loss, float* means, int K, int N, hipStream_t s);
 int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);
 
 // fused SGD over the flat parameter arena (torch.optim.SGD, dampening 0, no nesterov)

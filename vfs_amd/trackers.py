@@ -39,6 +39,21 @@ class _TrainStepFn(torch.autograd.Function):
         return None, None, None
 
 
+class _ReduceLossFn(torch.autograd.Function):
+    """loss rows [K, N] -> the scalar 'loss' of _parse_losses, already reduced on the device by
+    vfs_loss_means inside the forward chain; backward hands every row element grad / N."""
+
+    @staticmethod
+    def forward(ctx, rows, means):
+        ctx.shape = rows.shape
+        return means[-1].detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        K, N = ctx.shape
+        return (g * (1.0 / N)).expand(K, N), None
+
+
 class _GraphState:
     """hipGraph replay of the fused step (single process): after one eager step with a given
     input signature the forward chain and the backward chain are each captured once
@@ -49,8 +64,9 @@ class _GraphState:
     def __init__(self, key):
         self.key, self.warm = key, 0
         self.fwd = self.bwd = None
-        self.imgs = self.loss = self.gl = self.ctx = None
+        self.imgs = self.loss = self.gl = self.ctx = self.means = None
         self.nbt = None
+        self.borrowed = True      # read the caller's input buffer in place until it changes
 
 
 class BaseTracker(nn.Module):
@@ -206,23 +222,34 @@ class SimSiamBaseTracker(BaseTracker):
             return self._hip_forward_train(imgs)
         eng = shared_engine()
         self._ensure_arena()
+        if gs.fwd is not None and gs.borrowed and imgs.data_ptr() != gs.imgs.data_ptr():
+            torch.cuda.synchronize(dev)       # the old graphs may still be executing: never destroy them in flight
+            gs.fwd = gs.bwd = None            # the caller moved on to another buffer: re-capture on a staging copy
+            gs.borrowed = False
         if gs.fwd is None:
-            gs.imgs = imgs.detach().clone().contiguous().float()
+            # a caller that keeps feeding the SAME resident fp32 buffer (bench.py, a device-side loader ring) is
+            # read in place; anything else is staged into a private copy the captured chain reads
+            inplace = gs.borrowed and imgs.dtype == torch.float32 and imgs.is_contiguous() and not imgs.requires_grad
+            gs.imgs = imgs.detach() if inplace else imgs.detach().clone().contiguous().float()
+            gs.borrowed = inplace
             before = {id(u): getattr(u, 'nbt_pending', 0) for u in eng.units}
             torch.cuda.synchronize(dev)
             gs.fwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gs.fwd):
                 gs.loss = self._hip_forward_train(gs.imgs)
             gs.ctx = self._ctx
+            gs.means = self._loss_means
             gs.nbt = [(u, getattr(u, 'nbt_pending', 0) - before[id(u)]) for u in eng.units]
             for u, n in gs.nbt:               # the capture pass itself launched nothing
                 u.nbt_pending = before[id(u)]
-        gs.imgs.copy_(imgs)
+        if not gs.borrowed:
+            gs.imgs.copy_(imgs)
         gs.fwd.replay()
         for u, n in gs.nbt:
             if n:
                 u.nbt_pending = getattr(u, 'nbt_pending', 0) + n
         self._ctx = gs.ctx
+        self._loss_means = gs.means
         return gs.loss
 
     def _step_backward(self, gl):
@@ -262,6 +289,8 @@ class SimSiamBaseTracker(BaseTracker):
         neg = int(self.img_head.loss_feat.negative)
         loss = torch.empty(K, Nv, dtype=torch.float32, device=dev)
         eng.lib.cosine_loss_fwd(p[:Nv], z[:Nv], p[Nv:], z[Nv:], loss, Nv, p.shape[1], T, K, neg, weight, s)
+        self._loss_means = eng.buf('img_head.loss_means', (K + 1,), torch.float32, dev)
+        eng.lib.loss_means(loss, self._loss_means, K, Nv, s)       # what _parse_losses needs, inside the forward chain
         self._ctx = dict(bctx=bctx, hctx=hctx, z=z, p=p, Nv=Nv, T=T, K=K, weight=weight, neg=neg, last=last)
         return loss
 
@@ -328,6 +357,31 @@ class SimSiamBaseTracker(BaseTracker):
         return [w for w in works if w is not None]
 
     # ------------------------------------------------------------------ reference API
+    def train_step(self, data_batch, optimizer, **kwargs):
+        """base.py:119-156.  Single process: forward_train + _parse_losses with the reduction done by
+        vfs_loss_means inside the forward chain and ONE host read for the log vars, instead of ~30 tiny
+        eager torch launches between the forward and the backward chain (they left the GPU idle for
+        0.33 ms of an 8.5 ms ResNet-18 step).  Same keys, same values (double accumulation), same autograd
+        contract: outputs['loss'].backward() runs the backward chain."""
+        if (dist.is_available() and dist.is_initialized()) or not self.with_img_head or \
+                not {'imgs'} <= set(k for k, v in data_batch.items() if v is not None) <= {'imgs', 'label'} or \
+                data_batch['imgs'].device.type != 'cuda':
+            return super().train_step(data_batch, optimizer, **kwargs)
+        self.iteration += 1
+        imgs = data_batch['imgs']
+        if self.transpose_temporal:
+            imgs = imgs.transpose(1, 3).contiguous()
+        assert imgs.size(1) == 2
+        assert imgs.ndim == 6
+        if self._anchor is None or self._anchor.device != imgs.device:
+            self._anchor = torch.zeros(1, device=imgs.device, requires_grad=True)
+        rows = _TrainStepFn.apply(self._anchor, self, imgs)
+        loss = _ReduceLossFn.apply(rows, self._loss_means)
+        vals = self._loss_means.tolist()
+        log_vars = OrderedDict((f'img_head.{i}.loss_feat', vals[i]) for i in range(rows.shape[0]))
+        log_vars['loss'] = vals[-1]
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['imgs']))
+
     def forward_train(self, imgs, grids=None, label=None):
         """imgs [B,2,3,T,H,W] -> {'img_head.{i}.loss_feat': [B*T]} (sim_siam_base_tracker.py:58-76)."""
         if self.transpose_temporal:
