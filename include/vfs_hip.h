@@ -122,6 +122,12 @@ int vfs_bn_reduce_partials(const float* partial, double* sums, double* scratch, 
 int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp,
                     float* running_mean, float* running_var, int G, int C, double count, float eps,
                     float momentum, vfs_stream_t stream);
+/* the same result as vfs_bn_stats_finalize, computed from the stored bf16 output raw [G*rows_per_group][C] instead of the conv
+ * kernels' 128-pixel statistics rows: for SMALL groups that are not multiples of 128 rows (the head's BN1d layers,
+ * sim_siam_head.py:78-111, 32 rows per view on the ResNet-50 config), so that ONE conv launch covers all groups */
+int vfs_bn_stats_raw_finalize(const vfs_bf16* raw, double* sums, const float* gamma, const float* beta, float* bnp,
+                              float* running_mean, float* running_var, int G, int rows_per_group, int C, double count,
+                              float eps, float momentum, vfs_stream_t stream);
 /* single-process fast paths (no SyncBN all-reduce in between): vfs_bn_reduce_partials fused with
  * vfs_bn_finalize, resp. with vfs_bn_param_grad (sums are still written for the apply pass) */
 int vfs_bn_stats_finalize(const float* partial, double* sums, double* scratch, const float* gamma,

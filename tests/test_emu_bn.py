@@ -307,3 +307,35 @@ def test_stem_wgrad_fused_equals_unfused_chain(backend):
     lib.stem_wgrad_fused(x4, nhwc(raw), gp, y, idx, bnp, sums, part2, grad2, N, H, W, Ho, Wo, Hp, Wp, N // G, count,
                          nblocks, None)
     assert relerr(grad2 - 1.0, grad1) < 2e-4
+
+
+@pytest.mark.parametrize('G,rows,C', [(2, 32, 2048), (2, 8, 96), (1, 200, 64)])
+def test_bn_stats_from_raw_small_groups(backend, G, rows, C):
+    """vfs_bn_stats_raw_finalize (the head's BN1d layers): sums, bnp = {scale, shift, mean, invstd} and the running
+    statistics updated group by group, against torch on the same bf16 values; and vfs_loss_means"""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(G * 100 + rows)
+    x = rb(torch.randn(G * rows, C, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    sums = torch.zeros(G, 2, C, dtype=torch.float64)
+    bnp = torch.zeros(G, 4, C)
+    lib.bn_stats_raw_finalize(x.to(torch.bfloat16), sums, gamma, beta, bnp, rm, rv, G, rows, C, float(rows), 1e-5, 0.1, None)
+    for gi in range(G):
+        xs = x[gi * rows:(gi + 1) * rows].double()
+        assert torch.allclose(sums[gi, 0], xs.sum(0), rtol=1e-12, atol=1e-9)
+        assert torch.allclose(sums[gi, 1], (xs * xs).sum(0), rtol=1e-12, atol=1e-9)
+        mean, var = xs.mean(0), xs.var(0, unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        assert torch.allclose(bnp[gi, 0].double(), gamma.double() * inv, rtol=2e-6)
+        assert torch.allclose(bnp[gi, 1].double(), beta.double() - mean * gamma.double() * inv, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(bnp[gi, 2].double(), mean, rtol=1e-6, atol=1e-6) and torch.allclose(bnp[gi, 3].double(), inv, rtol=2e-6)
+        rm0 = 0.9 * rm0 + 0.1 * mean.float()
+        rv0 = 0.9 * rv0 + 0.1 * (var * rows / max(rows - 1, 1)).float()
+    assert torch.allclose(rm, rm0, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv0, rtol=1e-5, atol=1e-6)
+    loss = torch.rand(G + 1, rows, generator=g)
+    means = torch.zeros(G + 2)
+    lib.loss_means(loss, means, G + 1, rows, None)
+    want = loss.double().mean(1)
+    assert torch.allclose(means[:-1].double(), want, rtol=1e-6) and abs(float(means[-1]) - float(want.float().double().sum())) < 1e-6

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_emu_bn.py tests/test_emu_train_step.py -q -m gpu -x 2>&1 | tail -3
+bash tools/gpu_ab_env.sh VFS_RAW_STATS 0 1 r50

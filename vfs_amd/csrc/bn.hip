@@ -138,6 +138,65 @@ __global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restr
   }
 }
 
+// Statistics straight from the stored bf16 conv output for SMALL groups (the head's Linear layers: 32 rows per view):
+// lets one conv launch cover all groups when a group is not a multiple of the 128-pixel statistics rows.
+__global__ __launch_bounds__(256) void bn_stats_raw_kernel(const bf16_t* __restrict__ x, double* __restrict__ sums, int G, int rows, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ bnp, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, double count, float eps, float momentum) {
+  __shared__ double sh[8][2][32];
+  const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float rm = 0.f, rv = 0.f;
+  if (sl == 0 && c < C) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 0.f; }
+  for (int gi = 0; gi < G; ++gi) {
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+      const bf16_t* p = x + (size_t)gi * rows * C;
+      for (int b = sl; b < rows; b += 8) {
+        const double v = (double)bf2f(p[(size_t)b * C + c]);
+        a0 += v;
+        a1 += v * v;
+      }
+    }
+    __syncthreads();
+    sh[sl][0][cl] = a0;
+    sh[sl][1][cl] = a1;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0 += sh[k][0][cl]; r1 += sh[k][1][cl]; }
+      sums[((size_t)gi * 2 + 0) * C + c] = r0;
+      sums[((size_t)gi * 2 + 1) * C + c] = r1;
+      const double mean = r0 / count;
+      double var = r1 / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float scale = gamma[c] * invstd;
+      float* o = bnp + (size_t)gi * 4 * C;
+      o[c] = scale;
+      o[C + c] = beta[c] - (float)mean * scale;
+      o[2 * C + c] = (float)mean;
+      o[3 * C + c] = invstd;
+      const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+  }
+  if (sl == 0 && c < C) {
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+  }
+}
+int vfs_bn_stats_raw_launch(const bf16_t* x, double* sums, int G, int rows, int C, const float* gamma, const float* beta, float* bnp,
+                            float* rm, float* rv, double count, float eps, float momentum, hipStream_t s) {
+  if (G <= 0 || rows <= 0 || C <= 0) return vfs_set_error(VFS_ERR_SHAPE, "bn_stats_raw: empty");
+  hipLaunchKernelGGL(bn_stats_raw_kernel, dim3((C + 31) / 32), dim3(256), 0, s, x, sums, G, rows, C, gamma, beta, bnp, rm, rv, count,
+                     eps, momentum);
+  return vfs_check_launch("bn_stats_raw");
+}
+
 // The same two stages in ONE launch for large row counts: grid (channel blocks, groups, row chunks);
 // every workgroup writes the fp64 sums of its chunk to `chunks`, publishes them (agent-scope fence)
 // and draws a ticket for its channel block; the workgroup that draws the LAST ticket of a channel

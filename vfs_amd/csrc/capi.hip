@@ -200,6 +200,13 @@ int vfs_bn_stats_finalize(const float* partial, double* sums, double* scratch, c
   return vfs_bn_reduce_fused_launch(0, partial, sums, scratch, G, bpg, C, gamma, beta, bnp, running_mean, running_var, count, eps,
                                     momentum, nullptr, nullptr, S(stream));
 }
+int vfs_bn_stats_raw_finalize(const vfs_bf16* raw, double* sums, const float* gamma, const float* beta, float* bnp, float* running_mean,
+                              float* running_var, int G, int rows_per_group, int C, double count, float eps, float momentum,
+                              vfs_stream_t stream) {
+  if (!raw || !sums || !gamma || !beta || !bnp) return vfs_set_error(VFS_ERR_ARG, "bn_stats_raw_finalize: null buffer");
+  return vfs_bn_stats_raw_launch(raw, sums, G, rows_per_group, C, gamma, beta, bnp, running_mean, running_var, count, eps, momentum,
+                                 S(stream));
+}
 int vfs_bn_bwd_sums_paramgrad(const float* partial, double* sums, double* scratch, float* dgamma, float* dbeta, int G, int bpg,
                               int C, vfs_stream_t stream) {
   return vfs_bn_reduce_fused_launch(1, partial, sums, scratch, G, bpg, C, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.f, 0.f,

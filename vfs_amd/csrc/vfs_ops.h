@@ -122,6 +122,8 @@ struct LossArgs {
   int N, C, T, K, negative;
   float weight;
 };
+int vfs_bn_stats_raw_launch(const bf16_t* x, double* sums, int G, int rows, int C, const float* gamma, const float* beta, float* bnp,
+                            float* rm, float* rv, double count, float eps, float momentum, hipStream_t s);
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
 int vfs_loss_means_launch(const float* loss, float* means, int K, int N, hipStream_t s);
 int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);

@@ -159,10 +159,18 @@ class Engine:
         if u.kind == 'stem':      # the stem kernel emits one statistics row per 8x16 spatial tile
             fused = True
             nblk_g = Ng * ((Ho + 7) // 8) * ((Wo + 15) // 16)
-        partial = self.ws('ws.stats', G * nblk_g * 2 * u.cout, torch.float32, dev) if want_stats else None
+        # small groups that are not multiples of the 128-pixel statistics rows (the head's Linear layers on the ResNet-50
+        # config: 32 rows per view): ONE launch without statistics rows, the sums come from the stored output
+        raw_stats = (want_stats and not fused and not self.collectives_on and mpg <= 2048
+                     and os.environ.get('VFS_RAW_STATS', '1') == '1')
+        if raw_stats:
+            fused, want_rows = True, False
+        else:
+            want_rows = want_stats
+        partial = self.ws('ws.stats', G * nblk_g * 2 * u.cout, torch.float32, dev) if want_rows else None
         bias = u.bias.data if u.bias is not None else None
         groups = [(0, N, partial)] if fused else [
-            (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_stats else None) for g in range(G)]
+            (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_rows else None) for g in range(G)]
         for n0, nn_, part in groups:
             if u.kind == 'stem':
                 self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * 64 * 147, 2.0 * nn_ * (H * W * 4 + Ho * Wo * 64)), dev, lib.stem_fwd,
@@ -188,7 +196,10 @@ class Engine:
             if train:
                 u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
                 u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
-                if self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
+                if raw_stats:
+                    lib.bn_stats_raw_finalize(y, u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var,
+                                              G, mpg, u.cout, float(mpg), float(bn.eps), float(bn.momentum), s)
+                elif self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
                     lib.bn_reduce_partials(partial, u.sums, self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
                     self.allreduce(u.sums)
                     lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,

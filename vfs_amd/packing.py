@@ -87,6 +87,7 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
         tps = (ntiles + nsplit - 1) // nsplit
         nsplit = (ntiles + tps - 1) // tps
         return nsplit, tps * 128
+    target_blocks = int(os.environ.get('VFS_WGRAD_TBG', target_blocks))
     nkb = (Ktot + 127) // 128
     ncb = Cout // (128 if Cout % 128 == 0 else 64)
     # every split writes (and wgrad_reduce re-reads) a full Cout x Ktot fp32 partial: aim for ~2-4
