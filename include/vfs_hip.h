@@ -122,6 +122,18 @@ int vfs_bn_reduce_partials(const float* partial, double* sums, double* scratch, 
 int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, float* bnp,
                     float* running_mean, float* running_var, int G, int C, double count, float eps,
                     float momentum, vfs_stream_t stream);
+/* vfs_bn_stats_finalize + vfs_bn_act in ONE launch, resp. vfs_bn_bwd_sums_paramgrad + vfs_bn_bwd_apply, for SMALL
+ * statistics row counts (bpg <= ~128 rows per group: ResNet-50's 16x16 / 8x8 stages): every workgroup of the apply
+ * pass reduces the partial rows of its own (group, <= 64-channel slab) in its prologue - same order everywhere, so the
+ * coefficients are identical - and the first workgroup of a slab writes bnp / sums / running statistics (forward) or
+ * sums / dgamma / dbeta (backward).  Removes a dependent ~6 us launch per BatchNorm layer and direction. */
+int vfs_bn_act_fin(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp,
+                   double* sums, float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres,
+                   const float* rbnp, vfs_bf16* y, long long M, int C, int mpg, int relu, double count, float eps,
+                   float momentum, vfs_stream_t stream);
+int vfs_bn_bwd_apply_fin(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, const float* partial,
+                         int bpg, double* sums, float* dgamma, float* dbeta, vfs_bf16* dx, vfs_bf16* gm, long long M, int C,
+                         int mpg, double count, int relu, vfs_stream_t stream);
 /* the same result as vfs_bn_stats_finalize, computed from the stored bf16 output raw [G*rows_per_group][C] instead of the conv
  * kernels' 128-pixel statistics rows: for SMALL groups that are not multiples of 128 rows (the head's BN1d layers,
  * sim_siam_head.py:78-111, 32 rows per view on the ResNet-50 config), so that ONE conv launch covers all groups */

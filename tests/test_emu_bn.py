@@ -339,3 +339,57 @@ def test_bn_stats_from_raw_small_groups(backend, G, rows, C):
     lib.loss_means(loss, means, G + 1, rows, None)
     want = loss.double().mean(1)
     assert torch.allclose(means[:-1].double(), want, rtol=1e-6) and abs(float(means[-1]) - float(want.float().double().sum())) < 1e-6
+
+
+@pytest.mark.parametrize('G,rows,C,ppr', [(2, 6, 128, 32), (1, 33, 64, 16), (2, 3, 32, 64), (2, 16, 256, 128)])
+def test_bn_apply_with_inkernel_finalisation(backend, G, rows, C, ppr):
+    """vfs_bn_act_fin == vfs_bn_stats_finalize + vfs_bn_act and vfs_bn_bwd_apply_fin == vfs_bn_bwd_sums_paramgrad +
+    vfs_bn_bwd_apply on the same partial rows (bnp / sums / running statistics / dgamma / dbeta included)."""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(rows * 7 + C)
+    mpg = rows * ppr
+    M = G * mpg
+    x = rb(torch.randn(M, C, generator=g) * 1.3 + 0.2)
+    xb = x.to(torch.bfloat16)
+    part = torch.stack([x.view(G * rows, ppr, C).sum(1), (x * x).view(G * rows, ppr, C).sum(1)], dim=1).contiguous()   # [G*rows][2][C]
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    res = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+
+    def fwd(fused):
+        rm, rv = torch.full((C,), 0.25), torch.full((C,), 1.5)
+        sums, bnp = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(G, 4, C)
+        y = torch.empty(M, C, dtype=torch.bfloat16)
+        if fused:
+            lib.bn_act_fin(xb, part, rows, gamma, beta, bnp, sums, rm, rv, res, None, None, y, M, C, mpg, 1, float(mpg), 1e-5, 0.1, None)
+        else:
+            scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)
+            lib.bn_stats_finalize(part, sums, scratch, gamma, beta, bnp, rm, rv, G, rows, C, float(mpg), 1e-5, 0.1, None)
+            lib.bn_act(xb, bnp, res, None, None, y, M, C, mpg, 1, None)
+        return y.float(), bnp, sums, rm, rv
+    ya, bnpa, sa, rma, rva = fwd(True)
+    yb, bnpb, sb, rmb, rvb = fwd(False)
+    assert torch.allclose(sa, sb, rtol=1e-13, atol=1e-10) and torch.allclose(bnpa, bnpb, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rma, rmb, rtol=1e-6, atol=1e-7) and torch.allclose(rva, rvb, rtol=1e-6, atol=1e-7)
+    assert relerr(ya, yb) < 1e-6 or (ya - yb).abs().max() <= 2 ** -7 * yb.abs().max()
+
+    # backward: partial rows of {sum g, sum g*xhat}; here any rows do - both paths consume the same ones
+    gy = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    bpart = (torch.randn(G * rows, 2, C, generator=g) * 3).contiguous()
+
+    def bwd(fused):
+        bs = torch.zeros(G, 2, C, dtype=torch.float64)
+        dg, db = torch.full((C,), 0.5), torch.full((C,), -0.25)       # gradients accumulate
+        dx, gm = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+        if fused:
+            lib.bn_bwd_apply_fin(gy, None, xb, bnpb, bpart, rows, bs, dg, db, dx, gm, M, C, mpg, float(mpg), 1, None)
+        else:
+            scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)
+            lib.bn_bwd_sums_paramgrad(bpart, bs, scratch, dg, db, G, rows, C, None)
+            lib.bn_bwd_apply(gy, None, xb, bnpb, bs, dx, gm, M, C, mpg, float(mpg), 1, None)
+        return dx.float(), gm.float(), bs, dg, db
+    da, ga, bsa, dga, dba = bwd(True)
+    dbb, gb, bsb, dgb, dbb2 = bwd(False)
+    assert torch.allclose(bsa, bsb, rtol=1e-13, atol=1e-10)
+    assert torch.allclose(dga, dgb, rtol=1e-6, atol=1e-6) and torch.allclose(dba, dbb2, rtol=1e-6, atol=1e-6)
+    assert torch.equal(ga, gb)
+    assert (da - dbb).abs().max() <= 2 ** -7 * dbb.abs().max()

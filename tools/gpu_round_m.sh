@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_emu_bn.py tests/test_emu_train_step.py -q -m gpu -x 2>&1 | tail -3
+bash tools/gpu_ab_env.sh VFS_FIN_FUSE 0 1 r50
+bash tools/gpu_ab_env.sh VFS_FIN_FUSE 0 1 r18
+bash tools/gpu_ab_env.sh VFS_FIN_MAX_ROWS 128 256 r50
+bash tools/gpu_ab_env.sh VFS_FIN_MAX_ROWS 128 256 r18

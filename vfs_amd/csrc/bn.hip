@@ -358,13 +358,77 @@ static inline dim3 slab_grid(long long M, int C, int mpg, int* ppb_out) {
 }
 static inline bool slab_ok(int C) { return C % 8 == 0 && (C < 64 ? 256 % (C >> 3) == 0 : C % 64 == 0); }
 
-__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int ppb) {
+// prologue helper of the FIN kernels: double sums (row 0, row 1) of the partial rows of group gi for the <= 64
+// channels of this workgroup's slab -> sums_s[2][64] (valid after the call; contains barriers, call uniformly)
+__device__ __forceinline__ void slab_rows_reduce(const BnFin& f, int gi, int C, int cslab, double (*red)[2][64], double (*sums_s)[64]) {
+  const int t = threadIdx.x, ch = t & 63, rl = t >> 6;
+  const int c = blockIdx.y * cslab + ch;
+  double a0 = 0.0, a1 = 0.0;
+  if (ch < cslab) {
+    const float* p = f.partial + (size_t)gi * f.bpg * 2 * C + c;
+    for (int b = rl; b < f.bpg; b += 4) {
+      a0 += (double)p[(size_t)b * 2 * C];
+      a1 += (double)p[(size_t)b * 2 * C + C];
+    }
+  }
+  __syncthreads();               // previous users of red / sums_s are done
+  red[rl][0][ch] = a0;
+  red[rl][1][ch] = a1;
+  __syncthreads();
+  if (rl == 0) {
+    sums_s[0][ch] = (red[0][0][ch] + red[1][0][ch]) + (red[2][0][ch] + red[3][0][ch]);
+    sums_s[1][ch] = (red[0][1][ch] + red[1][1][ch]) + (red[2][1][ch] + red[3][1][ch]);
+  }
+  __syncthreads();
+}
+
+template <bool FIN>
+__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int ppb) {
   const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb);
-  if (s.rt >= s.rows) return;
   float sc[8], sh[8], rsc[8], rsh[8];
-  const float* bp = a.bnp + (size_t)s.gi * 4 * a.C + s.c;
-  ld8f(bp, sc);
-  ld8f(bp + a.C, sh);
+  if (FIN) {
+    __shared__ double red[4][2][64], sums_s[2][64];
+    __shared__ float coef[2][64];
+    const int t = threadIdx.x, cslab = a.C < 64 ? a.C : 64;
+    const bool lead = blockIdx.x == 0;            // first block of group 0: writes bnp / sums / running statistics
+    const int c = blockIdx.y * cslab + t;
+    float rm = 0.f, rv = 0.f;
+    if (lead && t < cslab) { rm = f.running_mean ? f.running_mean[c] : 0.f; rv = f.running_var ? f.running_var[c] : 0.f; }
+    for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
+      slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+      if (t < cslab) {
+        const double mean = sums_s[0][t] / f.count;
+        double var = sums_s[1][t] / f.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float scale = f.gamma[c] * invstd, shift = f.beta[c] - (float)mean * scale;
+        if (g == s.gi) { coef[0][t] = scale; coef[1][t] = shift; }
+        if (lead) {
+          float* o = f.bnp + (size_t)g * 4 * a.C;
+          o[c] = scale; o[a.C + c] = shift; o[2 * a.C + c] = (float)mean; o[3 * a.C + c] = invstd;
+          f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
+          f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
+          const double unbiased = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+          rm = (1.f - f.momentum) * rm + f.momentum * (float)mean;
+          rv = (1.f - f.momentum) * rv + f.momentum * (float)unbiased;
+        }
+      }
+    }
+    if (lead && t < cslab) {
+      if (f.running_mean) f.running_mean[c] = rm;
+      if (f.running_var) f.running_var[c] = rv;
+    }
+    __syncthreads();
+    if (s.rt >= s.rows) return;
+    const int cl = s.c - blockIdx.y * cslab;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = coef[0][cl + i]; sh[i] = coef[1][cl + i]; }
+  } else {
+    if (s.rt >= s.rows) return;
+    const float* bp = a.bnp + (size_t)s.gi * 4 * a.C + s.c;
+    ld8f(bp, sc);
+    ld8f(bp + a.C, sh);
+  }
   if (a.rres) {
     const float* rp = a.rbnp + (size_t)s.gi * 4 * a.C + s.c;
     ld8f(rp, rsc);
@@ -567,9 +631,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 
 // pass 2: dx = scale * (gm - S1/count - xhat * S2/count) = A*gm + B*x + D with per-channel
 // A = scale, B = -scale*invstd*m2, D = scale*(mean*invstd*m2 - m1) held in registers
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int ppb) {
+template <bool FIN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f, int ppb) {
   const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb);
-  if (s.rt >= s.rows) return;
+  double s1d[8], s2d[8];
+  if (FIN) {
+    __shared__ double red[4][2][64], sums_s[2][64], mine[2][64];
+    const int t = threadIdx.x, cslab = a.C < 64 ? a.C : 64;
+    const bool lead = blockIdx.x == 0;            // writes sums, accumulates dgamma / dbeta over the groups
+    const int c = blockIdx.y * cslab + t;
+    double g1 = 0.0, g2 = 0.0;
+    for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
+      slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+      if (t < cslab) {
+        if (g == s.gi) { mine[0][t] = sums_s[0][t]; mine[1][t] = sums_s[1][t]; }
+        if (lead) {
+          f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
+          f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
+          g1 += sums_s[0][t];
+          g2 += sums_s[1][t];
+        }
+      }
+    }
+    if (lead && t < cslab) {
+      f.dbeta[c] += (float)g1;
+      f.dgamma[c] += (float)g2;
+    }
+    __syncthreads();
+    if (s.rt >= s.rows) return;
+    const int cl = s.c - blockIdx.y * cslab;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1d[i] = mine[0][cl + i]; s2d[i] = mine[1][cl + i]; }
+  } else {
+    if (s.rt >= s.rows) return;
+    const double* sp = a.sums + (size_t)s.gi * 2 * a.C + s.c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1d[i] = sp[i]; s2d[i] = sp[a.C + i]; }
+  }
   float A[8], B[8], D[8], sh[8];
   {
     float mean[8], inv[8];
@@ -579,10 +677,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int ppb)
     ld8f(bp + 2 * a.C, mean);
     ld8f(bp + 3 * a.C, inv);
     const float rc = (float)(1.0 / a.count);
-    const double* sp = a.sums + (size_t)s.gi * 2 * a.C + s.c;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float m1 = (float)sp[i] * rc, m2 = (float)sp[a.C + i] * rc;
+      const float m1 = (float)s1d[i] * rc, m2 = (float)s2d[i] * rc;
       B[i] = -A[i] * inv[i] * m2;
       D[i] = A[i] * (mean[i] * inv[i] * m2 - m1);
     }
@@ -816,8 +913,22 @@ int vfs_bn_act_launch(const BnActArgs& a, hipStream_t s) {
   if (a.M <= 0) return VFS_OK;
   int ppb;
   const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
-  hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, s, a, ppb);
+  hipLaunchKernelGGL((bn_act_kernel<false>), grid, dim3(256), 0, s, a, BnFin{}, ppb);
   return vfs_check_launch("bn_act");
+}
+static int fin_check(const BnFin& f, long long M, int mpg, const char* who) {
+  if (!f.partial || !f.sums || f.bpg <= 0 || f.G <= 0 || (long long)f.G * mpg != M) return vfs_set_error(VFS_ERR_ARG, who);
+  return VFS_OK;
+}
+int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s) {
+  if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: C must be 8*2^k below 64, a multiple of 64 above");
+  if (a.M <= 0) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: empty");
+  if (fin_check(f, a.M, a.mpg, "bn_act_fin: statistics rows / groups") || !f.gamma || !f.beta || !f.bnp)
+    return vfs_set_error(VFS_ERR_ARG, "bn_act_fin: null operand or groups do not tile M");
+  int ppb;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
+  hipLaunchKernelGGL((bn_act_kernel<true>), grid, dim3(256), 0, s, a, f, ppb);
+  return vfs_check_launch("bn_act_fin");
 }
 int vfs_bn_relu_maxpool_launch(const BnPoolArgs& a, hipStream_t s) {
   if (a.C % 8) return vfs_set_error(VFS_ERR_SHAPE, "bn_relu_maxpool: C%8");
@@ -840,8 +951,18 @@ int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
   if (a.M <= 0) return VFS_OK;
   int ppb;
   const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, a, ppb);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, a, BnFin{}, ppb);
   return vfs_check_launch("bn_bwd_apply");
+}
+int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s) {
+  if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_fin: C must be 8*2^k below 64, a multiple of 64 above");
+  if (a.M <= 0) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_fin: empty");
+  if (fin_check(f, a.M, a.mpg, "bn_bwd_apply_fin: statistics rows / groups") || !f.dgamma || !f.dbeta)
+    return vfs_set_error(VFS_ERR_ARG, "bn_bwd_apply_fin: null operand or groups do not tile M");
+  int ppb;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, dim3(256), 0, s, a, f, ppb);
+  return vfs_check_launch("bn_bwd_apply_fin");
 }
 int vfs_bn_param_grad_launch(const double* sums, float* dgamma, float* dbeta, int G, int C, hipStream_t s) {
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, dgamma, dbeta, G, C);

@@ -222,6 +222,17 @@ int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const v
   a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
   return vfs_bn_act_launch(a, S(stream));
 }
+int vfs_bn_act_fin(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp, double* sums,
+                   float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+                   long long M, int C, int mpg, int relu, double count, float eps, float momentum, vfs_stream_t stream) {
+  if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: M % mpg");
+  BnActArgs a;
+  a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
+  BnFin f;
+  f.partial = partial; f.bpg = bpg; f.G = (int)(M / mpg); f.gamma = gamma; f.beta = beta; f.bnp = bnp; f.sums = sums;
+  f.running_mean = running_mean; f.running_var = running_var; f.count = count; f.eps = eps; f.momentum = momentum;
+  return vfs_bn_act_fin_launch(a, f, S(stream));
+}
 int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, vfs_bf16* xpool, int N, int H, int W, int C,
                         int Hp, int Wp, int npg, vfs_stream_t stream) {
   BnPoolArgs a;
@@ -249,6 +260,17 @@ int vfs_bn_bwd_apply(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, co
   a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.sums = sums; a.dx = dx; a.gm = gm; a.M = M; a.C = C; a.mpg = mpg; a.count = count;
   a.relu = relu;
   return vfs_bn_bwd_apply_launch(a, S(stream));
+}
+int vfs_bn_bwd_apply_fin(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, const float* partial, int bpg,
+                         double* sums, float* dgamma, float* dbeta, vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg,
+                         double count, int relu, vfs_stream_t stream) {
+  if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_fin: M % mpg");
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.dx = dx; a.gm = gm; a.M = M; a.C = C; a.mpg = mpg; a.count = count; a.relu = relu;
+  BnFin f;
+  f.partial = partial; f.bpg = bpg; f.G = (int)(M / mpg); f.sums = sums; f.dgamma = dgamma; f.dbeta = dbeta;
+  return vfs_bn_bwd_apply_fin_launch(a, f, S(stream));
 }
 int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, const vfs_bf16* x, const vfs_bf16* xpool,
                                 const float* bnp, float* partial, int N, int H, int W, int C, int Hp, int Wp, int npg, int ppb,

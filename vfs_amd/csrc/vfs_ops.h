@@ -14,6 +14,28 @@ struct BnActArgs {
   int C, mpg, relu;     // mpg = pixels per group
 };
 
+// Optional in-kernel statistics finalisation for the apply passes (bn_act / bn_bwd_apply, SMALL row counts): the
+// workgroup reduces the partial rows of its own (group, channel slab) in its prologue - every workgroup gets the same
+// coefficients, in the same summation order - instead of waiting for a separate 6-us launch between the conv and the
+// apply pass.  The leader workgroup of a slab (blockIdx.x == 0) reduces every group and writes the outputs.
+struct BnFin {
+  const float* partial = nullptr;   // [G][bpg][2][C] rows (forward: sum x, sum x^2; backward: S1, S2)
+  int bpg = 0, G = 0;
+  // forward outputs
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* bnp = nullptr;             // [G][4][C]
+  float* running_mean = nullptr;
+  float* running_var = nullptr;
+  float eps = 0.f, momentum = 0.f;
+  double count = 1.0;
+  // both
+  double* sums = nullptr;           // [G][2][C]
+  // backward outputs (accumulated)
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+};
+
 // stem: y = maxpool3x3/s2/p1( relu( x*scale + shift ) ), argmax position (0..8, first maximum in
 // scan order as torch's CPU max_pool2d) saved per element for the backward pass
 struct BnPoolArgs {
@@ -125,6 +147,8 @@ struct LossArgs {
 int vfs_bn_stats_raw_launch(const bf16_t* x, double* sums, int G, int rows, int C, const float* gamma, const float* beta, float* bnp,
                             float* rm, float* rv, double count, float eps, float momentum, hipStream_t s);
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
+int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s);
+int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s);
 int vfs_loss_means_launch(const float* loss, float* means, int K, int N, hipStream_t s);
 int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);
 

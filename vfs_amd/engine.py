@@ -19,6 +19,8 @@ from .packing import igemm_ksplit, bn_fold_eligible, build_pack_table, wgrad_hal
 
 BF16 = torch.bfloat16
 
+FIN_FUSE = os.environ.get('VFS_FIN_FUSE', '1') == '1'      # BatchNorm statistics finished in the apply kernels' prologue
+FIN_MAX_ROWS = int(os.environ.get('VFS_FIN_MAX_ROWS', '128'))   # ... for at most this many statistics rows per group
 KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's Linear layers (slower as measured)
 
 
@@ -140,7 +142,7 @@ class Engine:
         self.lib.pack_weights(tab, n, total, self.stream(dev))
 
     # ------------------------------------------------------------------ forward primitives
-    def conv_fwd(self, u, x, N, H, W, G, train, tag='', in_bn=None):
+    def conv_fwd(self, u, x, N, H, W, G, train, tag='', in_bn=None, defer_fin=False):
         """raw = conv(x); BN statistics/params when the unit has a BN.  Returns (raw, Ho, Wo)."""
         dev = x.device
         s = self.stream(dev)
@@ -193,10 +195,15 @@ class Engine:
                                nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
         if u.bn is not None:
             bn = u.bn
+            assert getattr(self, '_pending_fin', None) is None, 'a deferred BatchNorm finalisation was never consumed'
             if train:
                 u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
                 u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
-                if raw_stats:
+                if (defer_fin and FIN_FUSE and fused and not raw_stats and not self.collectives_on and u.kind != 'stem'
+                        and nblk_g <= FIN_MAX_ROWS):
+                    # the caller's next launch is bn_act on this output: it finishes the statistics in its prologue
+                    self._pending_fin = (u, partial, nblk_g, float(mpg))
+                elif raw_stats:
                     lib.bn_stats_raw_finalize(y, u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var,
                                               G, mpg, u.cout, float(mpg), float(bn.eps), float(bn.momentum), s)
                 elif self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
@@ -254,6 +261,15 @@ class Engine:
         dev = raw.device
         y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
         mpg = M // G if train else M
+        fin = getattr(self, '_pending_fin', None)
+        if fin is not None:
+            assert fin[0] is u, 'deferred BatchNorm finalisation belongs to another unit'
+            self._pending_fin = None
+            bn = u.bn
+            self.lib.bn_act_fin(raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean, bn.running_var,
+                                res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0, fin[3], float(bn.eps), float(bn.momentum),
+                                self.stream(dev))
+            return y
         self.lib.bn_act(raw, u.bnp, res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0, self.stream(dev))
         return y
 
@@ -280,9 +296,14 @@ class Engine:
             partial, nblk = fused[1], fused[2]
         else:
             lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, rl, s)
-        self._bwd_sums(u, partial, G, nblk // G, C, dev)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
+        if FIN_FUSE and not self.collectives_on and nblk // G <= FIN_MAX_ROWS:
+            # few statistics rows: the apply pass sums them in its prologue (and writes bsums, dgamma, dbeta)
+            lib.bn_bwd_apply_fin(g, ymask, raw, u.bnp, partial, nblk // G, u.bsums, u.bn.weight.grad, u.bn.bias.grad, dx, gm, M, C,
+                                 mpg, float(mpg), rl, s)
+            return dx, gm
+        self._bwd_sums(u, partial, G, nblk // G, C, dev)
         lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), rl, s)
         return dx, gm
 

@@ -270,14 +270,20 @@ class ResNet(nn.Module):
         bctx['act_bn'] = []
         for ci, c in enumerate(convs):
             tr = train and c.bn.training
-            raw, oh, ow = eng.conv_fwd(c.unit, a, N, ah, aw, G, tr, in_bn=in_bn)
+            oh, ow = c.unit.out_hw(ah, aw)
+            last = ci == len(convs) - 1
+            fold = (not last) and eng.can_fold_input_bn(convs[ci + 1].unit, N, G, oh, ow, train and convs[ci + 1].bn.training)
+            # the statistics can be finished by the bn_act that follows directly (not by a folding consumer, and not
+            # when the downsample conv - which re-uses the statistics workspace - runs in between)
+            defer = (not fold) and not (last and blk.downsample is not None)
+            raw, oh, ow = eng.conv_fwd(c.unit, a, N, ah, aw, G, tr, in_bn=in_bn, defer_fin=defer)
             bctx['raws'].append(raw)
             bctx['dims'].append((ah, aw, oh, ow))
             M = N * oh * ow
             in_bn = None
-            if ci < len(convs) - 1:
+            if not last:
                 nxt = convs[ci + 1]
-                if eng.can_fold_input_bn(nxt.unit, N, G, oh, ow, train and nxt.bn.training):
+                if fold:
                     # plain conv-BN-ReLU unit feeding a halo-tile conv: the activation is never written; the
                     # consumer (and its weight gradient) reads raw and applies scale/shift/ReLU while staging
                     in_bn = (c.unit.bnp, (N // G) if tr else N)

@@ -92,7 +92,7 @@ class SimSiamHead(nn.Module):
         for ui, u in enumerate(self.units):
             tr = train and (u.bn.training if u.bn is not None else True)
             ctx['ins'].append(a)
-            raw, _, _ = eng.conv_fwd(u, a.view(N, 1, 1, u.cin), N, 1, 1, G, tr)
+            raw, _, _ = eng.conv_fwd(u, a.view(N, 1, 1, u.cin), N, 1, 1, G, tr, defer_fin=u.bn is not None)
             raw = raw.view(N, u.cout)
             ctx['raws'].append(raw)
             if u.bn is not None:
