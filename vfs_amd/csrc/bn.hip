@@ -366,7 +366,16 @@ __device__ __forceinline__ void slab_rows_reduce(const BnFin& f, int gi, int C, 
   double a0 = 0.0, a1 = 0.0;
   if (ch < cslab) {
     const float* p = f.partial + (size_t)gi * f.bpg * 2 * C + c;
-    for (int b = rl; b < f.bpg; b += 4) {
+    int b = rl;
+    for (; b + 12 < f.bpg; b += 16) {      // four rows in flight (eight independent loads), fixed summation order
+      const float x0 = p[(size_t)b * 2 * C], y0 = p[(size_t)b * 2 * C + C];
+      const float x1 = p[(size_t)(b + 4) * 2 * C], y1 = p[(size_t)(b + 4) * 2 * C + C];
+      const float x2 = p[(size_t)(b + 8) * 2 * C], y2 = p[(size_t)(b + 8) * 2 * C + C];
+      const float x3 = p[(size_t)(b + 12) * 2 * C], y3 = p[(size_t)(b + 12) * 2 * C + C];
+      a0 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+      a1 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+    }
+    for (; b < f.bpg; b += 4) {
       a0 += (double)p[(size_t)b * 2 * C];
       a1 += (double)p[(size_t)b * 2 * C + C];
     }
