@@ -4,10 +4,11 @@
 
   python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path over one per-GPU batch: imgs [32, 2, 3, T, 256, 256]
-(BASELINE.json configs[1]: ResNet-18 r2_1xNx8, T=4 -> 128 frame-pairs per GPU per step;
---model r50: configs[2] shape, T=1 -> 32 frame-pairs).  Inputs are resident in HBM before the
-timed region.  Prints ONE JSON line on rank 0."""
+One "step" = one pass of the hot path over one per-GPU batch: imgs [32, 2, 3, T, 256, 256].
+Default = the configuration BASELINE.json's metric is quoted on ("frame-pairs/sec (train) R50 256^2 at
+1/2/4/8 GPUs": configs[2], ResNet-50 r5_1xNx2, T=1 -> 32 frame-pairs per GPU per step; it fits one GPU);
+--model r18: configs[1], ResNet-18 r2_1xNx8, T=4 -> 128 frame-pairs.  Inputs are resident in HBM before
+the timed region.  Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -79,7 +80,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--model', default='r18', choices=['r18', 'r50'])
+    ap.add_argument('--model', default='r50', choices=['r18', 'r50'])
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--batch', type=int, default=32, help='videos per GPU (configs: videos_per_gpu=32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
