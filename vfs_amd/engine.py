@@ -120,11 +120,8 @@ class Engine:
         self._pack = None
         return unit
 
-    def pack_weights(self, overlap=False):
-        """fp32 OIHW master weights -> bf16 MFMA layouts, table-driven: ONE launch for all layers, or (overlap=True,
-        the train step) the stem's table on the launch stream and everything else on the side stream, where it runs
-        under imgs_to_nhwc4 / the stem conv / the pooling pass; the caller joins (wgrad_join) before the first
-        residual block."""
+    def pack_weights(self):
+        """fp32 OIHW master weights -> bf16 MFMA layouts, all layers in ONE launch."""
         if not self.units:
             return
         dev = self.units[0].weight.device
@@ -139,19 +136,12 @@ class Engine:
                     u.wf = torch.empty(u.cout, u.k, u.k, u.cin, dtype=BF16, device=dev)
                     u.wd = torch.empty(u.cin, u.k, u.k, u.cout, dtype=BF16, device=dev) if u.need_wd else None
                 entries.append((u.weight.data, u.wf, u.wd, 1 if u.kind == 'stem' else 0))
-            stem = [e for e in entries if e[3] == 1]
-            rest = [e for e in entries if e[3] == 0]
-            self._pack = (build_pack_table(entries, dev), build_pack_table(stem, dev) if stem else None,
-                          build_pack_table(rest, dev) if rest else None)
+            self._pack = build_pack_table(entries, dev)
             self._pack_key = key
-        full, stem, rest = self._pack
-        if overlap and stem is not None and rest is not None and dev.type == 'cuda' and os.environ.get('VFS_PACK_OVERLAP', '1') == '1':
-            self.lib.pack_weights(stem[0], stem[1], stem[2], self.stream(dev))
-            with self.on_side_stream(dev):
-                self.lib.pack_weights(rest[0], rest[1], rest[2], self.stream(dev))
-            return
-        self.lib.pack_weights(full[0], full[1], full[2], self.stream(dev))
+        tab, n, total = self._pack
+        self.lib.pack_weights(tab, n, total, self.stream(dev))
 
+    # ------------------------------------------------------------------ forward primitives
     def conv_fwd(self, u, x, N, H, W, G, train, tag='', in_bn=None, defer_fin=False):
         """raw = conv(x); BN statistics/params when the unit has a BN.  Returns (raw, Ho, Wo)."""
         dev = x.device

@@ -252,7 +252,6 @@ class ResNet(nn.Module):
         ctx.update(stem_raw=raw, Hs=Hs, Ws=Ws, pooled=pooled, idx=idx, xpool=xpool, Hp=Hp, Wp2=Wp)
         x, h, w = pooled, Hp, Wp
         outs = {}
-        eng.wgrad_join(dev)     # the packed weights of the residual stages (Engine.pack_weights(overlap=True))
         for si, lname in enumerate(self.res_layers):
             for blk in getattr(self, lname):
                 x, h, w, bctx = self._block_fwd(eng, blk, x, N, h, w, G, train)

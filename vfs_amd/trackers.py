@@ -272,7 +272,7 @@ class SimSiamBaseTracker(BaseTracker):
         self.backbone.attach(eng)
         self.img_head.attach(eng)
         self._ensure_arena()
-        eng.pack_weights(overlap=True)      # all but the stem's table on the side stream; joined after the stem
+        eng.pack_weights()
         B, V, _, T, H, W = imgs.shape
         Nv = B * T
         N = V * Nv
