@@ -98,7 +98,11 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        opts = None
+        if os.environ.get('VFS_PG_HIPRIO', '1') == '1':      # the small SyncBN all-reduces sit on the critical path
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world, pg_options=opts)
 
     import vfs_amd
     from vfs_amd.engine import shared_engine
@@ -183,7 +187,9 @@ def main():
                                f'{args.size}] per GPU (configs[{1 if depth == 18 else 2}] shape), SyncBN, fp32 master weights',
                    'frame_pairs_per_step': pairs_per_step, 'parallelism': f'dp{world}'},
         'loss': out['log_vars']['loss'],
-        'launch_mode': 'hipGraph replay (forward chain + backward chain)' if (world == 1 and os.environ.get('VFS_GRAPHS', '1') == '1') else 'eager',
+        'launch_mode': ('hipGraph replay (forward chain + backward chain)' if (world == 1 and os.environ.get('VFS_GRAPHS', '0') == '1')
+                        else 'command-tape replay (recorded C-ABI calls + stream waits / collectives)' if os.environ.get('VFS_TAPE', '1') == '1'
+                        else 'eager'),
     }
     if rank == 0 and prof:
         agg = {}

@@ -35,11 +35,15 @@ def run(rank, world, out_path):
     model, imgs, cfg = build(8)
     per = imgs.shape[0] // world
     local = imgs[rank * per:(rank + 1) * per]
-    out = model.train_step(dict(imgs=local, label=torch.zeros(per, 1)), None)
-    out['loss'].backward()
     import vfs_amd
     opt = vfs_amd.build_optimizer(model, cfg.optimizer)
-    opt.step()
+    # VFS_TEST_STEPS > 1: the later steps run from the recorded command tapes (or eagerly with VFS_TAPE=0)
+    for step in range(int(os.environ.get('VFS_TEST_STEPS', '1'))):
+        batch = local if step == 0 else (local * (1.0 + 0.25 * step)).contiguous()
+        out = model.train_step(dict(imgs=batch, label=torch.zeros(per, 1)), None)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
     res = {'log/' + k: np.float64(v) for k, v in out['log_vars'].items()}
     for n, p in model.named_parameters():
         res['grad/' + n] = p.grad.detach().numpy().copy()

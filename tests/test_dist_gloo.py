@@ -54,3 +54,29 @@ def test_two_ranks_equal_one_process(tmp_path):
                 assert l2(r0[k], s[k]) < 3e-2, (k, l2(r0[k], s[k]))
         elif k.startswith('param/'):
             assert np.array_equal(r0[k], r1[k]), k             # replicas stay in lock-step after SGD
+
+
+def _run_ranks(tmp_path, tag, extra_env):
+    port = str(_free_port())
+    procs, outs = [], []
+    for r in range(2):
+        o = str(tmp_path / f'{tag}_rank{r}.npz')
+        outs.append(o)
+        env = dict(os.environ, WORLD_SIZE='2', RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port, **extra_env)
+        procs.append(subprocess.Popen([sys.executable, WORKER, o], env=env))
+    for p in procs:
+        assert p.wait(timeout=1500) == 0
+    return [np.load(o) for o in outs]
+
+
+def test_command_tape_replay_equals_eager_with_collectives(tmp_path):
+    """4 data-parallel steps on 2 gloo ranks: step 1 eager, step 2 recorded, steps 3-4 replayed from the command tapes
+    (C-ABI calls + SyncBN / gradient all-reduces) must equal the plain eager run bit for bit"""
+    from tests.emu_util import emu_lib
+    emu_lib()
+    tape = _run_ranks(tmp_path, 'tape', dict(VFS_TEST_STEPS='4', VFS_TAPE='1'))
+    eager = _run_ranks(tmp_path, 'eager', dict(VFS_TEST_STEPS='4', VFS_TAPE='0'))
+    for k in eager[0].files:
+        assert np.array_equal(tape[0][k], eager[0][k]), k
+        if k.startswith(('param/', 'grad/', 'buf/')):
+            assert np.array_equal(tape[0][k], tape[1][k]), k

@@ -243,10 +243,16 @@ def test_graph_replay_equals_eager(gpu_backend, monkeypatch):
 
     l0, sd0, used0 = run(False)
     l1, sd1, used1 = run(True)
-    assert not used0 and used1
+    assert used0 and used1          # VFS_GRAPHS=0 replays host-side command tapes, VFS_GRAPHS=1 hipGraphs
     assert l0 == l1, (l0, l1)
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+    monkeypatch.setenv('VFS_TAPE', '0')         # plain eager launches
+    l2, sd2, used2 = run(False)
+    assert not used2
+    assert l0 == l2, (l0, l2)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd2[k]), k
 
 
 @pytest.mark.gpu

@@ -1,8 +1,11 @@
 #!/bin/bash
-# single-GPU view of the multi-GPU code path: eager step + RCCL calls in a 1-rank group
-cd $GRAFT_REPO_ROOT
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-echo "== graphs (N=1 default)"; timeout 300 python bench.py --model r18 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps"
-echo "== eager, no collectives"; VFS_GRAPHS=0 timeout 300 python bench.py --model r18 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps"
-echo "== eager + collectives in a 1-rank RCCL group (the N>1 code path)"; VFS_FORCE_COLLECTIVES=1 timeout 300 python bench.py --model r18 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps|rror"
-echo "== same, R50"; VFS_FORCE_COLLECTIVES=1 timeout 300 python bench.py --model r50 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps|rror"
+# launch modes of the train step on one GPU: graphs / command tape / eager, without and with collectives (1-rank RCCL group = the N>1 code path)
+cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_emu_train_step.py -q -m gpu -x 2>&1 | tail -3
+for M in r50 r18; do
+echo "== $M graphs"; VFS_GRAPHS=1 timeout 300 python bench.py --model $M --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps"
+echo "== $M tape (default)"; timeout 300 python bench.py --model $M --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps"
+echo "== $M eager, no collectives"; VFS_TAPE=0 timeout 300 python bench.py --model $M --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps"
+echo "== $M tape + collectives in a 1-rank RCCL group (the N>1 code path)"; VFS_FORCE_COLLECTIVES=1 timeout 300 python bench.py --model $M --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps|rror"
+echo "== $M eager + collectives"; VFS_TAPE=0 VFS_FORCE_COLLECTIVES=1 timeout 300 python bench.py --model $M --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -E "timed steps|rror"
+done

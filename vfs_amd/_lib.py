@@ -60,6 +60,14 @@ class VfsLib:
     def last_error(self):
         return self._fns['vfs_last_error']().decode()
 
+    def cfunc(self, name):
+        """the raw ctypes function of entry point `name` (without the vfs_ prefix), or None"""
+        return self._fns.get('vfs_' + name)
+
+    def check(self, name, rc):
+        if isinstance(rc, int) and rc != 0:
+            raise VfsError(f'vfs_{name} failed ({rc}): {self.last_error()}')
+
     def __getattr__(self, name):
         fn = self.__dict__.get('_fns', {}).get('vfs_' + name)
         if fn is None:
@@ -90,3 +98,49 @@ def set_lib(lib):
     """Dependency injection for tests (e.g. the host-emulation build of the same sources)."""
     global _LIB
     _LIB = lib
+
+
+class Tape:
+    """Host-side command list of one launch chain: the C-ABI calls (ctypes function + already converted arguments)
+    and the few Python-side actions between them (stream waits, collectives), recorded while a chain runs eagerly
+    and replayed by a tight loop afterwards.  Every pointer argument refers to a persistent engine buffer, exactly
+    the precondition of the hipGraph capture; unlike a graph the replay can contain RCCL collectives, which is
+    what the multi-GPU step needs (there the Python + ctypes marshalling of ~570 launches per step, 25 us each,
+    was slower than the GPU)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.ops = []
+
+    def replay(self):
+        check = self.lib.check
+        for name, fn, args in self.ops:
+            rc = fn(*args)
+            if name is not None and rc:
+                check(name, rc)
+
+
+class TapeLib:
+    """stands in for a VfsLib while a chain is recorded: executes every call and appends it to the tape"""
+
+    def __init__(self, lib, tape):
+        self._lib, self._tape = lib, tape
+        self.path = lib.path
+
+    def last_error(self):
+        return self._lib.last_error()
+
+    def __getattr__(self, name):
+        fn = self._lib.cfunc(name)
+        if fn is None:
+            raise AttributeError(name)
+        lib, ops = self._lib, self._tape.ops
+
+        def call(*args):
+            conv = tuple(a.data_ptr() if hasattr(a, 'data_ptr') else a for a in args)
+            ops.append((name, fn, conv))
+            rc = fn(*conv)
+            lib.check(name, rc)
+            return rc
+        self.__dict__[name] = call
+        return call

@@ -14,7 +14,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from ._lib import get_lib
+from ._lib import Tape, TapeLib, get_lib
 from .packing import igemm_ksplit, bn_fold_eligible, build_pack_table, wgrad_halo_eligible, wgrad_splits
 
 BF16 = torch.bfloat16
@@ -50,9 +50,26 @@ class Engine:
         self._side = {}
         self._side_dirty = False
         self.prof = None     # list collecting (kind, flops, start_event, end_event) when profiling
+        self.tape = None
         for kv in filter(None, os.environ.get('VFS_OPTS', '').split(',')):      # kernel A/B knobs: "name=value,..."
             name, value = kv.split('=')
             self.lib.set_option(name.strip().encode(), int(value))
+
+    # ------------------------------------------------------------------ command tape (see _lib.Tape)
+    def begin_tape(self):
+        assert self.tape is None
+        self.tape = Tape(self.lib)
+        self._real_lib, self.lib = self.lib, TapeLib(self.lib, self.tape)
+        return self.tape
+
+    def end_tape(self):
+        self.lib, self.tape = self._real_lib, None
+
+    def record(self, fn, *args):
+        """run a Python-side action of the chain (stream wait, collective) and put it on the tape if one is recording"""
+        if self.tape is not None:
+            self.tape.ops.append((None, fn, args))
+        return fn(*args)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -112,7 +129,10 @@ class Engine:
 
     def allreduce(self, t):
         if self.collectives_on:
-            dist.all_reduce(t, group=self.process_group)
+            self.record(self._all_reduce, t)
+
+    def _all_reduce(self, t):
+        dist.all_reduce(t, group=self.process_group)
 
     # ------------------------------------------------------------------ weights
     def register(self, unit):
@@ -354,7 +374,7 @@ class Engine:
         side = self._side.get(dev)
         if side is None:
             side = self._side[dev] = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        self.record(side.wait_stream, torch.cuda.current_stream(dev))
         self._side_dirty = True
         return torch.cuda.stream(side)
 
@@ -363,7 +383,7 @@ class Engine:
         if dev.type == 'cuda' and getattr(self, '_side_dirty', False):
             side = self._side.get(dev)
             if side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side)
+                self.record(torch.cuda.current_stream(dev).wait_stream, side)
             self._side_dirty = False
 
     def stem_wgrad_fused(self, u, x4, Hin, Win, gp, yp, idx, raw, N, H, W, Hp, Wp, G, count):

@@ -27,15 +27,46 @@ def add_prefix(inputs, prefix):
     return {f'{prefix}.{k}': v for k, v in inputs.items()}
 
 
+class _hp_chain:
+    """context: run a launch chain on a high-priority stream (VFS_MAIN_PRIO=1), ordered after the caller's stream and
+    joined back into it - the critical-path kernels then win the dispatch against the weight-gradient stream."""
+    _streams = {}
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.on = dev.type == 'cuda' and os.environ.get('VFS_MAIN_PRIO', '0') == '1'
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        hp = self._streams.get(self.dev)
+        if hp is None:
+            hp = self._streams[self.dev] = torch.cuda.Stream(self.dev, priority=-1)
+        self.cur = torch.cuda.current_stream(self.dev)
+        hp.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(hp)
+        self.ctx.__enter__()
+        self.hp = hp
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+            self.cur.wait_stream(self.hp)
+        return False
+
+
 class _TrainStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, tracker, imgs):
         ctx.tracker = tracker
-        return tracker._step_forward(imgs)
+        with _hp_chain(imgs.device):
+            return tracker._step_forward(imgs)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.tracker._step_backward(g)
+        with _hp_chain(g.device):
+            ctx.tracker._step_backward(g)
         return None, None, None
 
 
@@ -55,11 +86,10 @@ class _ReduceLossFn(torch.autograd.Function):
 
 
 class _GraphState:
-    """hipGraph replay of the fused step (single process): after one eager step with a given
-    input signature the forward chain and the backward chain are each captured once
-    (torch.cuda.CUDAGraph over the launch stream; every kernel argument is a pointer into the
-    engine's persistent buffers) and replayed afterwards -- ~400 (R18) / ~1100 (R50) launches per
-    step cost one graph launch instead of one Python->ctypes call each."""
+    """Replay state of the fused step: after one eager step with a given input signature the forward chain and
+    the backward chain are each recorded once - as a host-side command tape (default) or captured into a hipGraph
+    (VFS_GRAPHS=1; torch.cuda.CUDAGraph over the launch stream) - and replayed afterwards; every kernel argument
+    is a pointer into the engine's persistent buffers."""
 
     def __init__(self, key):
         self.key, self.warm = key, 0
@@ -192,6 +222,7 @@ class SimSiamBaseTracker(BaseTracker):
             self.transpose_temporal = self.train_cfg.get('transpose_temporal', False)
         self._anchor = None
         self._ctx = None
+        self._works = []
         self.grad_bucket_bytes = 25 * 1024 * 1024
 
     @property
@@ -203,17 +234,28 @@ class SimSiamBaseTracker(BaseTracker):
             self.img_head.init_weights()
 
     # ------------------------------------------------------------------ the HIP step
-    def _graphs_enabled(self, dev):
+    def _chain_mode(self, dev):
+        """how the forward / backward launch chains are issued after the first (eager) step:
+        'tape'  - default: the chain's C-ABI calls and its stream waits / RCCL calls are recorded once as a host-side
+                  command list (_lib.Tape) and replayed by a tight loop (~4 us of CPU per launch instead of ~25);
+                  works with collectives (N > 1), and on MI355X it also beats the hipGraph replay of the same chain
+                  (R50 10.7 -> 10.1 ms, R18 8.04 -> 7.81: the weight-gradient stream overlaps better with direct launches);
+        'graph' - VFS_GRAPHS=1, single process on a GPU: each chain is captured once into a hipGraph and replayed;
+        None    - plain eager (profiling, VFS_TAPE=0)."""
         eng = shared_engine()
-        return (dev.type == 'cuda' and os.environ.get('VFS_GRAPHS', '1') == '1' and not eng.collectives_on
-                and eng.prof is None)
+        if eng.prof is not None:
+            return None
+        if dev.type == 'cuda' and os.environ.get('VFS_GRAPHS', '0') == '1' and not eng.collectives_on:
+            return 'graph'
+        return 'tape' if os.environ.get('VFS_TAPE', '1') == '1' else None
 
     def _step_forward(self, imgs):
         dev = imgs.device
-        if not self._graphs_enabled(dev):
+        mode = self._chain_mode(dev)
+        if mode is None:
             self._gs = None
             return self._hip_forward_train(imgs)
-        key = (tuple(imgs.shape), imgs.dtype, dev, self.training, id(shared_engine()))
+        key = (tuple(imgs.shape), imgs.dtype, dev, self.training, id(shared_engine()), mode)
         gs = getattr(self, '_gs', None)
         if gs is None or gs.key != key:
             gs = self._gs = _GraphState(key)
@@ -223,9 +265,11 @@ class SimSiamBaseTracker(BaseTracker):
         eng = shared_engine()
         self._ensure_arena()
         if gs.fwd is not None and gs.borrowed and imgs.data_ptr() != gs.imgs.data_ptr():
-            torch.cuda.synchronize(dev)       # the old graphs may still be executing: never destroy them in flight
+            if dev.type == 'cuda':
+                torch.cuda.synchronize(dev)   # the old graphs may still be executing: never destroy them in flight
             gs.fwd = gs.bwd = None            # the caller moved on to another buffer: re-capture on a staging copy
             gs.borrowed = False
+        recorded_now = False
         if gs.fwd is None:
             # a caller that keeps feeding the SAME resident fp32 buffer (bench.py, a device-side loader ring) is
             # read in place; anything else is staged into a private copy the captured chain reads
@@ -233,21 +277,32 @@ class SimSiamBaseTracker(BaseTracker):
             gs.imgs = imgs.detach() if inplace else imgs.detach().clone().contiguous().float()
             gs.borrowed = inplace
             before = {id(u): getattr(u, 'nbt_pending', 0) for u in eng.units}
-            torch.cuda.synchronize(dev)
-            gs.fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs.fwd):
-                gs.loss = self._hip_forward_train(gs.imgs)
+            if mode == 'graph':
+                torch.cuda.synchronize(dev)
+                gs.fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs.fwd):
+                    gs.loss = self._hip_forward_train(gs.imgs)
+            else:                             # the recording pass IS this step's forward
+                tape = eng.begin_tape()
+                try:
+                    gs.loss = self._hip_forward_train(gs.imgs)
+                finally:
+                    eng.end_tape()
+                gs.fwd = tape
+                recorded_now = True
             gs.ctx = self._ctx
             gs.means = self._loss_means
             gs.nbt = [(u, getattr(u, 'nbt_pending', 0) - before[id(u)]) for u in eng.units]
-            for u, n in gs.nbt:               # the capture pass itself launched nothing
-                u.nbt_pending = before[id(u)]
-        if not gs.borrowed:
-            gs.imgs.copy_(imgs)
-        gs.fwd.replay()
-        for u, n in gs.nbt:
-            if n:
-                u.nbt_pending = getattr(u, 'nbt_pending', 0) + n
+            if mode == 'graph':
+                for u, n in gs.nbt:           # the capture pass itself launched nothing
+                    u.nbt_pending = before[id(u)]
+        if not recorded_now:
+            if not gs.borrowed:
+                gs.imgs.copy_(imgs)
+            gs.fwd.replay()
+            for u, n in gs.nbt:
+                if n:
+                    u.nbt_pending = getattr(u, 'nbt_pending', 0) + n
         self._ctx = gs.ctx
         self._loss_means = gs.means
         return gs.loss
@@ -258,10 +313,20 @@ class SimSiamBaseTracker(BaseTracker):
             return self._hip_backward(gl)
         if gs.bwd is None:
             gs.gl = gl.detach().clone().contiguous().float()
-            torch.cuda.synchronize(gl.device)
-            gs.bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs.bwd):
-                self._hip_backward(gs.gl)
+            if isinstance(gs.fwd, torch.cuda.CUDAGraph):
+                torch.cuda.synchronize(gl.device)
+                gs.bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs.bwd):
+                    self._hip_backward(gs.gl)
+            else:
+                eng = shared_engine()
+                tape = eng.begin_tape()
+                try:
+                    self._hip_backward(gs.gl)     # recording pass = this step's backward
+                finally:
+                    eng.end_tape()
+                gs.bwd = tape
+                return
         gs.gl.copy_(gl)
         gs.bwd.replay()
         self._ctx = None
@@ -309,16 +374,15 @@ class SimSiamBaseTracker(BaseTracker):
         gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
         if eng.collectives_on:
             eng.wgrad_join(dev)
-        works = self._allreduce_range(self._head_range(), async_op=True)
+        self._allreduce_range(self._head_range())
 
         def stage_done(module):      # gradients of `module` are final: reduce them while earlier stages run
             if eng.collectives_on:
                 eng.wgrad_join(dev)
-                works.extend(self._allreduce_range(self._param_range(module), async_op=True))
+                self._allreduce_range(self._param_range(module))
         self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat}, on_stage_done=stage_done)
         eng.wgrad_join(dev)
-        for wk in works:
-            wk.wait()
+        eng.record(self._wait_works)
         self._ctx = None
 
     # ------------------------------------------------------------------ data-parallel gradients
@@ -336,25 +400,34 @@ class SimSiamBaseTracker(BaseTracker):
     def _backbone_range(self):
         return self._param_range(self.backbone)
 
-    def _allreduce_range(self, rng, async_op=True):
-        """mean-all-reduce flat_grads[lo:hi] in ~25 MB buckets (torch DDP's default bucket size)."""
-        if not shared_engine().collectives_on:
-            return []
-        lo, hi = rng
+    def _allreduce_range(self, rng):
+        """mean-all-reduce flat_grads[lo:hi] in ~25 MB buckets (torch DDP's default bucket size), asynchronously; the
+        work handles are waited for by _wait_works at the end of the backward chain."""
         eng = shared_engine()
+        if not eng.collectives_on:
+            return
+        lo, hi = rng
         g = self._flat['grads']
         world = dist.get_world_size()
         step = max(1, self.grad_bucket_bytes // 4)
-        works = []
         for a in range(lo, hi, step):
             b = min(hi, a + step)
             chunk = g[a:b]
             if chunk.device.type == 'cuda':
                 eng.lib.scale(chunk, b - a, 1.0 / world, eng.stream(chunk.device))
             else:
-                chunk.mul_(1.0 / world)
-            works.append(dist.all_reduce(chunk, async_op=async_op))
-        return [w for w in works if w is not None]
+                eng.record(chunk.mul_, 1.0 / world)
+            eng.record(self._issue_allreduce, chunk)
+
+    def _issue_allreduce(self, chunk):
+        w = dist.all_reduce(chunk, async_op=True)
+        if w is not None:
+            self._works.append(w)
+
+    def _wait_works(self):
+        for w in self._works:
+            w.wait()
+        del self._works[:]
 
     # ------------------------------------------------------------------ reference API
     def train_step(self, data_batch, optimizer, **kwargs):
