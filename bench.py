@@ -98,11 +98,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        opts = None
-        if os.environ.get('VFS_PG_HIPRIO', '1') == '1':      # the small SyncBN all-reduces sit on the critical path
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world, pg_options=opts)
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     import vfs_amd
     from vfs_amd.engine import shared_engine
