@@ -126,7 +126,9 @@ int vfs_bn_finalize(const double* sums, const float* gamma, const float* beta, f
  * statistics row counts (bpg <= ~128 rows per group: ResNet-50's 16x16 / 8x8 stages): every workgroup of the apply
  * pass reduces the partial rows of its own (group, <= 64-channel slab) in its prologue - same order everywhere, so the
  * coefficients are identical - and the first workgroup of a slab writes bnp / sums / running statistics (forward) or
- * sums / dgamma / dbeta (backward).  Removes a dependent ~6 us launch per BatchNorm layer and direction. */
+ * sums / dgamma / dbeta (backward).  Removes a dependent ~6 us launch per BatchNorm layer and direction.
+ * vfs_bn_act_fin with partial == NULL (SyncBN): `sums` already holds the all-reduced totals and count the global element
+ * count; the kernel then replaces vfs_bn_finalize + vfs_bn_act for any tensor size. */
 int vfs_bn_act_fin(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp,
                    double* sums, float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres,
                    const float* rbnp, vfs_bf16* y, long long M, int C, int mpg, int relu, double count, float eps,

@@ -404,7 +404,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
     float rm = 0.f, rv = 0.f;
     if (lead && t < cslab) { rm = f.running_mean ? f.running_mean[c] : 0.f; rv = f.running_var ? f.running_var[c] : 0.f; }
     for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
-      slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+      if (f.partial) {
+        slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+      } else {                                    // SyncBN: f.sums already holds the all-reduced totals
+        __syncthreads();
+        if (t < cslab) {
+          sums_s[0][t] = f.sums[((size_t)g * 2 + 0) * a.C + c];
+          sums_s[1][t] = f.sums[((size_t)g * 2 + 1) * a.C + c];
+        }
+        __syncthreads();
+      }
       if (t < cslab) {
         const double mean = sums_s[0][t] / f.count;
         double var = sums_s[1][t] / f.count - mean * mean;
@@ -415,8 +424,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
         if (lead) {
           float* o = f.bnp + (size_t)g * 4 * a.C;
           o[c] = scale; o[a.C + c] = shift; o[2 * a.C + c] = (float)mean; o[3 * a.C + c] = invstd;
-          f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
-          f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
+          if (f.partial) {
+            f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
+            f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
+          }
           const double unbiased = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
           rm = (1.f - f.momentum) * rm + f.momentum * (float)mean;
           rv = (1.f - f.momentum) * rv + f.momentum * (float)unbiased;
@@ -925,14 +936,15 @@ int vfs_bn_act_launch(const BnActArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((bn_act_kernel<false>), grid, dim3(256), 0, s, a, BnFin{}, ppb);
   return vfs_check_launch("bn_act");
 }
-static int fin_check(const BnFin& f, long long M, int mpg, const char* who) {
-  if (!f.partial || !f.sums || f.bpg <= 0 || f.G <= 0 || (long long)f.G * mpg != M) return vfs_set_error(VFS_ERR_ARG, who);
+static int fin_check(const BnFin& f, long long M, int mpg, const char* who, bool sums_ok = false) {
+  const bool rows = f.partial && f.bpg > 0;
+  if (!(rows || (sums_ok && !f.partial)) || !f.sums || f.G <= 0 || (long long)f.G * mpg != M) return vfs_set_error(VFS_ERR_ARG, who);
   return VFS_OK;
 }
 int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s) {
   if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: C must be 8*2^k below 64, a multiple of 64 above");
   if (a.M <= 0) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: empty");
-  if (fin_check(f, a.M, a.mpg, "bn_act_fin: statistics rows / groups") || !f.gamma || !f.beta || !f.bnp)
+  if (fin_check(f, a.M, a.mpg, "bn_act_fin: statistics rows / groups", true) || !f.gamma || !f.beta || !f.bnp)
     return vfs_set_error(VFS_ERR_ARG, "bn_act_fin: null operand or groups do not tile M");
   int ppb;
   const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);

@@ -229,8 +229,12 @@ class Engine:
                 elif self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
                     lib.bn_reduce_partials(partial, u.sums, self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
                     self.allreduce(u.sums)
-                    lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
-                                    u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
+                    if defer_fin and FIN_FUSE and u.kind != 'stem':
+                        # the bn_act that follows turns the all-reduced sums into scale / shift itself (any size)
+                        self._pending_fin = (u, None, 0, float(mpg * self.world))
+                    else:
+                        lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
+                                        u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
                 else:
                     lib.bn_stats_finalize(partial, u.sums, self.bn_scratch(G, u.cout, dev), bn.weight.data, bn.bias.data,
                                           u.bnp, bn.running_mean, bn.running_var, G, nblk_g, u.cout, float(mpg),
