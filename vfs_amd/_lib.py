@@ -90,7 +90,7 @@ def get_lib():
     """The product library (gfx950).  Raises VfsError when it has not been built."""
     global _LIB
     if _LIB is None:
-        _LIB = VfsLib(LIB_PATH)
+        _LIB = VfsLib(os.environ.get('VFS_HIP_LIB') or LIB_PATH)     # VFS_HIP_LIB: A/B a variant build of the same ABI
     return _LIB
 
 

@@ -41,7 +41,7 @@
 // Lane l of a DMA piece lands at piece_base + 16*l, so each lane FETCHES the (row, chunk) whose swizzled slot
 // that is.  Rows past the ragged end re-fetch a valid row (their outputs are masked by the epilogue).
 template <int BC, int MODE, int PIPE, bool FBN>
-__global__ __launch_bounds__(256, PIPE >= 3 ? 1 : ((PIPE == 1 && !FBN) ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool ONEK = (PIPE == 1);
   constexpr int BP = 128;
   constexpr int WC = BC / 2;   // channels per wave
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : ((PIPE == 1 && !FBN) ? 3 : 2))
   constexpr int STAGE = 4 * 64 * SROW + (CAN_BN ? 4 * (64 / (WC / 8)) * 2 * WC * 2 : 0);   // + statistics rows (floats)
   constexpr int SMEM = OPER > STAGE ? OPER : STAGE;
   __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
-  __shared__ float sRed[2][BC][2];
+  constexpr bool HAS_STATS = (MODE == GATHER_FWD || MODE == GATHER_STEM);   // forward statistics rows: forward convs only
+  __shared__ float sRed[2][HAS_STATS ? BC : 1][2];
   bf16_t (*sW)[BC * 64] = reinterpret_cast<bf16_t (*)[BC * 64]>(smem);
   bf16_t (*sX)[BP * 64] = reinterpret_cast<bf16_t (*)[BP * 64]>(smem + NBUF * BC * 64);
 
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : ((PIPE == 1 && !FBN) ? 3 : 2))
   // transposes its WC x 64 outputs through a private LDS slab and writes 16-byte pieces of whole pixel
   // rows.  The K loop ended with a barrier: nobody reads the operand tiles any more.
   const int lr = lane & 15, lq = lane >> 4;
-  const bool do_stats = a.stats != nullptr, do_add = a.add != nullptr, do_bias = a.bias != nullptr;
+  const bool do_stats = HAS_STATS && a.stats != nullptr, do_add = a.add != nullptr, do_bias = a.bias != nullptr;
   bf16_t* slab = smem + wave * (64 * SROW);
   auto pixel_dst = [&](int m) -> size_t {         // class-local pixel -> row of the output matrix
     if (MODE != GATHER_DGRAD2) return (size_t)m;
