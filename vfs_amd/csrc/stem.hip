@@ -34,7 +34,10 @@ __global__ __launch_bounds__(256) void stem_fwd_direct_kernel(ConvArgs a, int ti
   __shared__ __attribute__((aligned(16))) bf16_t sW[7 * 64 * 32];
   __shared__ __attribute__((aligned(16))) bf16_t sX[ST_PH * ST_PROW];
   __shared__ __attribute__((aligned(16))) bf16_t sOut[4 * 32 * ST_STAGE_ROW];
-  __shared__ __attribute__((aligned(16))) float sRed[4][2][64];
+  // the statistics hand-off of a wave ([2][64] floats) lives at the head of that wave's OWN output slab: the wave has
+  // read its slab back before it writes there, and the next slab writes come after the loop's closing barriers.
+  // (A separate 2 KB array put the kernel at 55.5 KB of LDS = two workgroups per CU; 53.5 KB fits three.)
+  auto sred = [&](int w) { return reinterpret_cast<float*>(sOut + w * (32 * ST_STAGE_ROW)); };
   constexpr int PL = (ST_PH * 19 + 255) / 256;     // 16-byte patch loads per thread (2)
   const ConvGeom g = a.g;               // H, W = padded input dims (NHWC4), Ho, Wo = output dims
   const int t = threadIdx.x, lane = t & 63, wp = t >> 6;   // wave = 64 cout x 32 pixels (tile rows 2wp, 2wp+1)
@@ -157,14 +160,15 @@ __global__ __launch_bounds__(256) void stem_fwd_direct_kernel(ConvArgs a, int ti
             s1[tm][q] = 0.f; s2[tm][q] = 0.f;
           }
           if (lr == 0) {
-            *reinterpret_cast<f32x4*>(&sRed[wp][0][tm * 16 + lq * 4]) = r1;
-            *reinterpret_cast<f32x4*>(&sRed[wp][1][tm * 16 + lq * 4]) = r2;
+            *reinterpret_cast<f32x4*>(sred(wp) + tm * 16 + lq * 4) = r1;
+            *reinterpret_cast<f32x4*>(sred(wp) + 64 + tm * 16 + lq * 4) = r2;
           }
         }
         __syncthreads();
         if (t < 128) {
           const int st = t >> 6, cl = t & 63;
-          a.stats[(size_t)run_first * 128 + t] = (sRed[0][st][cl] + sRed[1][st][cl]) + (sRed[2][st][cl] + sRed[3][st][cl]);
+          const int o = st * 64 + cl;
+          a.stats[(size_t)run_first * 128 + t] = (sred(0)[o] + sred(1)[o]) + (sred(2)[o] + sred(3)[o]);
         }
         if (tile != run_first && t >= 128) a.stats[(size_t)tile * 128 + (t - 128)] = 0.f;
         run_first = tile + 1;
