@@ -334,9 +334,9 @@ class Engine:
     def _bwd_sums(self, u, partial, G, bpg, C, dev):
         """partial (S1, S2) rows -> u.bsums (all-reduced for SyncBN) and dgamma / dbeta (local sums)"""
         s = self.stream(dev)
-        if self.collectives_on:
-            self.lib.bn_reduce_partials(partial, u.bsums, self.bn_scratch(G, C, dev), G, bpg, C, s)
-            self.lib.bn_param_grad(u.bsums, u.bn.weight.grad, u.bn.bias.grad, G, C, s)
+        if self.collectives_on:     # local sums + local dgamma / dbeta in one launch, then the SyncBN all-reduce of the sums
+            self.lib.bn_bwd_sums_paramgrad(partial, u.bsums, self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad,
+                                           G, bpg, C, s)
             self.allreduce(u.bsums)
         else:
             self.lib.bn_bwd_sums_paramgrad(partial, u.bsums, self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad,

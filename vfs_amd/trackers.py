@@ -420,10 +420,10 @@ class SimSiamBaseTracker(BaseTracker):
                 eng.lib.scale(chunk, b - a, 1.0 / world, eng.stream(chunk.device))
             else:
                 eng.record(chunk.mul_, 1.0 / world)
-            eng.record(self._issue_allreduce, chunk)
+            eng.record(self._issue_allreduce, chunk, dist.ReduceOp.SUM)
 
-    def _issue_allreduce(self, chunk):
-        w = dist.all_reduce(chunk, async_op=True)
+    def _issue_allreduce(self, chunk, op):
+        w = dist.all_reduce(chunk, op=op, async_op=True)
         if w is not None:
             self._works.append(w)
 
@@ -439,9 +439,8 @@ class SimSiamBaseTracker(BaseTracker):
         eager torch launches between the forward and the backward chain (they left the GPU idle for
         0.33 ms of an 8.5 ms ResNet-18 step).  Same keys, same values (double accumulation), same autograd
         contract: outputs['loss'].backward() runs the backward chain."""
-        if (dist.is_available() and dist.is_initialized()) or not self.with_img_head or \
-                not {'imgs'} <= set(k for k, v in data_batch.items() if v is not None) <= {'imgs', 'label'} or \
-                data_batch['imgs'].device.type != 'cuda':
+        if not self.with_img_head or data_batch['imgs'].device.type != 'cuda' or \
+                not {'imgs'} <= set(k for k, v in data_batch.items() if v is not None) <= {'imgs', 'label'}:
             return super().train_step(data_batch, optimizer, **kwargs)
         self.iteration += 1
         imgs = data_batch['imgs']
@@ -453,7 +452,12 @@ class SimSiamBaseTracker(BaseTracker):
             self._anchor = torch.zeros(1, device=imgs.device, requires_grad=True)
         rows = _TrainStepFn.apply(self._anchor, self, imgs)
         loss = _ReduceLossFn.apply(rows, self._loss_means)
-        vals = self._loss_means.tolist()
+        if dist.is_available() and dist.is_initialized():      # log vars are averaged over the ranks (base.py:103-108)
+            packed = self._loss_means / dist.get_world_size()
+            dist.all_reduce(packed)
+            vals = packed.tolist()
+        else:
+            vals = self._loss_means.tolist()
         log_vars = OrderedDict((f'img_head.{i}.loss_feat', vals[i]) for i in range(rows.shape[0]))
         log_vars['loss'] = vals[-1]
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['imgs']))
