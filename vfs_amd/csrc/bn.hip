@@ -221,7 +221,16 @@ __global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __re
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
       const float* p = in + (size_t)gi * bpg * 2 * C;
-      for (int b = r0 + sl; b < r1; b += 8) {
+      int b = r0 + sl;
+      for (; b + 24 < r1; b += 32) {       // four rows (eight independent loads) in flight per lane
+        const float x0 = p[(size_t)b * 2 * C + c], y0 = p[(size_t)b * 2 * C + C + c];
+        const float x1 = p[(size_t)(b + 8) * 2 * C + c], y1 = p[(size_t)(b + 8) * 2 * C + C + c];
+        const float x2 = p[(size_t)(b + 16) * 2 * C + c], y2 = p[(size_t)(b + 16) * 2 * C + C + c];
+        const float x3 = p[(size_t)(b + 24) * 2 * C + c], y3 = p[(size_t)(b + 24) * 2 * C + C + c];
+        a0 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+        a1 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+      }
+      for (; b < r1; b += 8) {
         a0 += (double)p[(size_t)b * 2 * C + c];
         a1 += (double)p[(size_t)b * 2 * C + C + c];
       }
@@ -250,8 +259,17 @@ __global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __re
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
       const double* p = chunks + (size_t)gi * nchunks * 2 * C;
-      for (int b = sl; b < nchunks; b += 8) {
-        a0 += vfs_load_agent(&p[(size_t)b * 2 * C + c]);   // device-coherent loads of the other workgroups' sums
+      int b = sl;                          // device-coherent loads of the other workgroups' sums, four chunks
+      for (; b + 24 < nchunks; b += 32) {  // (eight loads) in flight per lane: they bypass the L2, ~1 us each
+        const double x0 = vfs_load_agent(&p[(size_t)b * 2 * C + c]), y0 = vfs_load_agent(&p[(size_t)b * 2 * C + C + c]);
+        const double x1 = vfs_load_agent(&p[(size_t)(b + 8) * 2 * C + c]), y1 = vfs_load_agent(&p[(size_t)(b + 8) * 2 * C + C + c]);
+        const double x2 = vfs_load_agent(&p[(size_t)(b + 16) * 2 * C + c]), y2 = vfs_load_agent(&p[(size_t)(b + 16) * 2 * C + C + c]);
+        const double x3 = vfs_load_agent(&p[(size_t)(b + 24) * 2 * C + c]), y3 = vfs_load_agent(&p[(size_t)(b + 24) * 2 * C + C + c]);
+        a0 += (x0 + x1) + (x2 + x3);
+        a1 += (y0 + y1) + (y2 + y3);
+      }
+      for (; b < nchunks; b += 8) {
+        a0 += vfs_load_agent(&p[(size_t)b * 2 * C + c]);
         a1 += vfs_load_agent(&p[(size_t)b * 2 * C + C + c]);
       }
     }
@@ -886,8 +904,9 @@ static inline int grid_for(long long total_vec) {
 int vfs_option_bn_ticket = 1;   // capi: vfs_set_option("bn_ticket", 0) = single-workgroup-per-channel-block reduction
 // scratch = [VFS_BN_TICKETS ticket counters (zero before the first use, left zero by every launch)]
 //           [double[G][<=VFS_BN_MAX_CHUNKS][2][C] chunk sums]
+int vfs_option_bn_chunk_rows = 64;   // rows per chunk of the ticket reduction (A/B knob; was 32)
 static inline void bn_chunk_plan(int bpg, int* nchunks, int* rpc) {
-  int n = (bpg + 31) / 32;
+  int n = (bpg + vfs_option_bn_chunk_rows - 1) / vfs_option_bn_chunk_rows;
   if (n > VFS_BN_MAX_CHUNKS) n = VFS_BN_MAX_CHUNKS;
   *rpc = (bpg + n - 1) / n;
   *nchunks = (bpg + *rpc - 1) / *rpc;

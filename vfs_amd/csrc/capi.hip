@@ -26,7 +26,7 @@ int vfs_check_launch(const char* what) {
 
 int vfs_option_halo = 1;
 int vfs_option_stem_blocks = 0;
-extern int vfs_option_bn_ticket;
+extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles;
 
@@ -46,6 +46,7 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo")) { vfs_option_halo = value; return VFS_OK; }
   if (!strcmp(name, "stem_blocks")) { vfs_option_stem_blocks = value; return VFS_OK; }
   if (!strcmp(name, "bn_ticket")) { vfs_option_bn_ticket = value; return VFS_OK; }
+  if (!strcmp(name, "bn_chunk_rows")) { vfs_option_bn_chunk_rows = value > 0 ? value : 64; return VFS_OK; }
   if (!strcmp(name, "stem_direct")) { vfs_option_stem_direct = value; return VFS_OK; }
   if (!strcmp(name, "igemm_bc")) { vfs_option_igemm_bc = value; return VFS_OK; }
   if (!strcmp(name, "igemm_onek")) { vfs_option_igemm_onek = value; return VFS_OK; }
