@@ -258,7 +258,9 @@ class SimSiamBaseTracker(BaseTracker):
         if mode is None:
             self._gs = None
             return self._hip_forward_train(imgs)
-        key = (tuple(imgs.shape), imgs.dtype, dev, self.training, id(shared_engine()), mode)
+        f = self._ensure_arena()              # recorded chains hold raw pointers into the parameter / gradient arenas
+        key = (tuple(imgs.shape), imgs.dtype, dev, self.training, id(shared_engine()), mode,
+               f['params'].data_ptr(), f['grads'].data_ptr())
         gs = getattr(self, '_gs', None)
         if gs is None or gs.key != key:
             gs = self._gs = _GraphState(key)
