@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from tests.emu_util import nchw, nhwc, rb, relerr
-from vfs_amd.packing import build_pack_table, wgrad_halo_eligible, wgrad_splits
+from vfs_amd.packing import build_pack_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible, wgrad_splits
 
 
 def pack(be, w, stem=False):
@@ -36,7 +36,7 @@ def run_conv_case(be, N, H, W, Cin, Cout, k, stride, pad, wgrad_blocks=12):
     xh = d(nhwc(x))
     M = N * Ho * Wo
     y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16, device=be.dev)
-    nblk = (M + 127) // 128
+    nblk = conv_stats_rows(N, 1, H, W, Cin, Cout, k, stride, pad, Ho, Wo)     # spatial tiles (halo kernels) or linear blocks
     stats = torch.full((nblk, 2, Cout), float('nan'), device=be.dev)
     bias = torch.randn(Cout, generator=g)
     lib.conv_fwd(xh, wf, y, d(bias), stats, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
@@ -48,7 +48,7 @@ def run_conv_case(be, N, H, W, Cin, Cout, k, stride, pad, wgrad_blocks=12):
     # kernel, spatial tiles in the halo kernel); what the consumers rely on is that the blocks of
     # the first / second half of the batch (the two views) are the first / second half of the rows
     st = stats.cpu()
-    halves = 2 if (N % 2 == 0 and (M // 2) % 128 == 0) else 1
+    halves = 2 if (N % 2 == 0 and conv_stats_rows(N, 2, H, W, Cin, Cout, k, stride, pad, Ho, Wo) is not None) else 1
     for h in range(halves):
         rows = slice(h * nblk // halves, (h + 1) * nblk // halves)
         pix = yf[h * M // halves:(h + 1) * M // halves].double()
@@ -86,6 +86,9 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (1, 16, 32, 128, 64, 3, 1, 1),    # halo-tile kernel: 8x16 spatial tiles, two channel chunks
     (4, 8, 8, 64, 128, 3, 1, 1),      # halo-tile kernel: two whole 8x8 images per workgroup
     (2, 32, 32, 64, 64, 3, 1, 1),     # halo-tile kernel, 64 output channels: 16x16 tiles, 4 pixel waves
+    (2, 14, 14, 64, 128, 3, 1, 1),    # halo-tile kernel, RAGGED 8x16 tiles (14 x 14 map of a 224 x 224 input)
+    (1, 28, 28, 64, 64, 3, 1, 1),     # halo-tile kernel, RAGGED 16x16 tiles (28 x 28)
+    (3, 7, 14, 128, 128, 3, 1, 1),    # halo-tile kernel, ragged bottom row only, odd image count
 ]
 
 
@@ -129,6 +132,8 @@ def test_pack_weights_ragged(backend, shape):
     (2, 16, 32, 128, 64, 3, 2),     # halo dgrad, 128 output channels, two statistics groups
     (4, 32, 32, 64, 64, 3, 2),      # halo dgrad, 64 output channels: 16x16 tiles, two rows per tile
     (4, 8, 8, 128, 128, 3, 2),      # halo dgrad on whole 8x8 images (two per tile)
+    (2, 14, 14, 128, 64, 3, 2),     # halo dgrad, RAGGED 8x16 tiles, two statistics groups
+    (2, 28, 28, 64, 64, 3, 1),      # halo dgrad, RAGGED 16x16 tiles
     (3, 7, 7, 128, 64, 1, 1),       # generic kernel, ragged M = 147
     (2, 8, 8, 64, 128, 1, 1),       # generic kernel, 64 output channels (32-channel waves)
     (2, 8, 8, 64, 64, 1, 1),        # generic kernel, one K-step
@@ -159,7 +164,7 @@ def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, m
                       + 0.5 * torch.randn(N, H, W, Cin, generator=g)))
     dx0 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
     lib.conv_dgrad(dy, wd, dx0, add, N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
-    nblk = (M + 127) // 128
+    nblk = conv_stats_rows(N, G, H, W, Cout, Cin, k, 1, pad, H, W) * G     # the dgrad as a conv producing [N,H,W,Cin]
     partial = torch.full((nblk, 2, Cin), float('nan'), device=dev)
     dx1 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
     lib.conv_dgrad_bn(dy, wd, dx1, add, d(x.to(torch.bfloat16)), d(y.to(torch.bfloat16)) if mask == 'y' else None, d(bnp), partial, mpg, 1 if mask == 'relu' else 0,

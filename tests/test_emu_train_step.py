@@ -111,7 +111,9 @@ def _maxrel(a, b):
 
 @pytest.mark.parametrize('depth,shape', [(18, [4, 2, 3, 2, 32, 32]), (50, [8, 2, 3, 1, 32, 32]),
                                          # 16x16 feature maps in layer1: halo-tile kernels, folded input BatchNorm, fused dgrad statistics
-                                         (18, [4, 2, 3, 2, 64, 64])])
+                                         (18, [4, 2, 3, 2, 64, 64]),
+                                         # 14x14 / 7x7 maps (the 224 x 224 crop of the shipped configs, scaled down): ragged halo tiles
+                                         (18, [2, 2, 3, 1, 56, 56])])
 def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monkeypatch):
     """Tight orchestration check without the chaos: run the fused step, then for the stem, every
     residual block, the head and the loss feed the ENGINE'S OWN input / incoming-gradient buffers

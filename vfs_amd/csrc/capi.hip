@@ -26,7 +26,7 @@ int vfs_check_launch(const char* what) {
 
 int vfs_option_halo = 1;
 int vfs_option_stem_blocks = 0;
-extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows;
+extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_halo_min_fill;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles;
 
@@ -44,6 +44,7 @@ const char* vfs_last_error(void) { return g_err; }
 int vfs_abi_version(void) { return 1; }
 int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo")) { vfs_option_halo = value; return VFS_OK; }
+  if (!strcmp(name, "halo_min_fill")) { vfs_option_halo_min_fill = value; return VFS_OK; }
   if (!strcmp(name, "stem_blocks")) { vfs_option_stem_blocks = value; return VFS_OK; }
   if (!strcmp(name, "bn_ticket")) { vfs_option_bn_ticket = value; return VFS_OK; }
   if (!strcmp(name, "bn_chunk_rows")) { vfs_option_bn_chunk_rows = value > 0 ? value : 64; return VFS_OK; }
@@ -135,12 +136,16 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
   if (stride != 1) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: stride 1 only (strided dgrads run per parity class)");
   if (!bn_x || !bnp || !bn_partial || bn_mpg <= 0) return vfs_set_error(VFS_ERR_ARG, "conv_dgrad_bn: null statistics operand");
   const long long M = (long long)N * H * W;
-  if (bn_mpg < M && bn_mpg % 128) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: groups must be multiples of 128 pixels");
   ConvArgs a;
   a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
   a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin;
   a.in_bnp = nullptr; a.in_npg = 0;
   a.bn.x = bn_x; a.bn.y = bn_y; a.bn.bnp = bnp; a.bn.partial = bn_partial; a.bn.mpg = bn_mpg; a.bn.relu = bn_relu;
+  // a statistics row must belong to ONE group: spatial tiles never straddle images (halo kernels: groups of whole
+  // images), linear blocks are 128 pixels
+  const bool tiles = vfs_option_halo && Cout % 64 == 0 && vfs_conv_halo_eligible(a, GATHER_DGRAD);
+  if (bn_mpg < M && (tiles ? bn_mpg % ((long long)H * W) != 0 : bn_mpg % 128 != 0))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: groups must be whole images (tile kernels) / multiples of 128 pixels");
   return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ void halo_pixel(int wp, int tn, int lr, int& ti, int&
 // the write -> read hand-over inside the wave needs no barrier.
 #define HALO_STAGE_ROW 72   // bf16 elements per staged pixel row (64 + 8 pad)
 #define HALO_STAGE_WAVE (64 * HALO_STAGE_ROW)
-template <int F, int BC, bool SMALLW>
+template <int F, int BC, bool SMALLW, bool RAGGED>
 __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&acc)[4][4], float* sRed, bf16_t* stage,
                                               int tile, int tn0, int y0, int x0, int c0, int wc, int wp, int lr, int lq, int t) {
   constexpr int TM = 4, TN = 4, WAVES_P = 4 / (BC / 64);
@@ -73,6 +73,25 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[tm][r] = 0.f; s2[tm][r] = 0.f; }
+  // ragged tiles (right / bottom edge of maps that are not multiples of the tile, e.g. 56 x 56): validity of this
+  // lane's pixels in the accumulator layout (bit tn) and in the row-store layout (bit i)
+  // (RAGGED is a separate instantiation: exact tilings keep constant masks and pay nothing)
+  unsigned okt = RAGGED ? 0u : 0xFu, oki = RAGGED ? 0u : 0xFFu;
+  if (RAGGED) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      int ti, py, px;
+      halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
+      if (y0 + py < g.H && x0 + px < g.W && tn0 + ti < g.N) okt |= 1u << tn;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = i * 8 + (lane >> 3);
+      int ti, py, px;
+      halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
+      if (y0 + py < g.H && x0 + px < g.W && tn0 + ti < g.N) oki |= 1u << i;
+    }
+  }
   // fused BatchNorm-backward statistics: this lane's eight (pixel, 8-channel chunk) operands are
   // requested NOW, before the accumulators are converted and staged, and consumed in the row-store loop
   u32x4 bxv[8], byv[8];
@@ -83,21 +102,23 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
       int ti, py, px;
       halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
       const size_t o = (((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px)) * a.Cout + c0 + wc * 64 + (lane & 7) * 8;
-      bxv[i] = ld16(a.bn.x + o);
-      if (a.bn.y) byv[i] = ld16(a.bn.y + o);
+      const bool ok = (oki >> i) & 1u;
+      bxv[i] = ok ? ld16(a.bn.x + o) : zero16();
+      byv[i] = (ok && a.bn.y) ? ld16(a.bn.y + o) : zero16();
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     u32x2 ad[TM];
+    const bool okp = (okt >> tn) & 1u;
     if (do_add) {
       int ti, py, px;
       halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
       const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
       const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) ad[tm] = ld8(a.add + obase + tm * 16);
+      for (int tm = 0; tm < TM; ++tm) ad[tm] = okp ? ld8(a.add + obase + tm * 16) : (u32x2){0u, 0u};
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -114,7 +135,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
       pk.x = pack2bf(v[0], v[1]);
       pk.y = pack2bf(v[2], v[3]);
       st8(&slab[(tn * 16 + lr) * HALO_STAGE_ROW + tm * 16 + lq * 4], pk);
-      if (do_stats) {   // statistics of the STORED (bf16) values
+      if (do_stats && okp) {   // statistics of the STORED (bf16) values
         const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
         s1[tm][0] += q0; s2[tm][0] += q0 * q0;
         s1[tm][1] += q1; s2[tm][1] += q1 * q1;
@@ -134,10 +155,14 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
     const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
     const size_t o = mdst * a.Cout + c0 + wc * 64 + ch * 8;
     const u32x4 gv = ld16(&slab[p * HALO_STAGE_ROW + ch * 8]);
-    st16(a.out + o, gv);
+    const bool ok = (oki >> i) & 1u;
+    if (ok) st16(a.out + o, gv);
     if (do_bn) {
-      if (i == 0) bnfuse_init(bl, a.bn, a.Cout, (int)(mdst / a.bn.mpg), c0 + wc * 64 + ch * 8);
-      bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);
+      if (i == 0) {   // statistics group of this wave's pixels: from the tile's first pixel (always inside the map)
+        const size_t m0 = ((size_t)(tn0 + (SMALLW ? wp : 0)) * g.H + y0) * g.W + x0;
+        bnfuse_init(bl, a.bn, a.Cout, (int)(m0 / a.bn.mpg), c0 + wc * 64 + ch * 8);
+      }
+      if (ok) bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);
     }
   }
   if (do_bn) {
@@ -184,19 +209,19 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
     }
   }
 }
-template <int BC, bool SMALLW>
+template <int BC, bool SMALLW, bool RAGGED>
 __device__ __forceinline__ void halo_epilogue_dispatch(const ConvArgs& a, const f32x4 (&acc)[4][4], float* sRed, bf16_t* stage,
                                                        int tile, int tn0, int y0, int x0, int c0, int wc, int wp, int lr, int lq, int t) {
   const int flags = (a.stats ? 1 : 0) | (a.add ? 2 : 0) | (a.bias ? 4 : 0) | (a.bn.partial ? 8 : 0);
-  if (flags == 1) halo_epilogue<1, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
-  else if (flags == 2) halo_epilogue<2, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
-  else if (flags == 0) halo_epilogue<0, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
-  else if (flags == 8) halo_epilogue<8, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
-  else if (flags == 10) halo_epilogue<10, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
-  else halo_epilogue<15, BC, SMALLW>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  if (flags == 1) halo_epilogue<1, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 2) halo_epilogue<2, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 0) halo_epilogue<0, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 8) halo_epilogue<8, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else if (flags == 10) halo_epilogue<10, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  else halo_epilogue<15, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
 
-template <int BC, bool DGRAD, bool SMALLW>
+template <int BC, bool DGRAD, bool SMALLW, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   constexpr int WAVES_C = BC / 64, WAVES_P = 4 / WAVES_C;      // wave grid: channels x pixels
   constexpr int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   const int ncb = a.Cout / BC;
   const int tile = blockIdx.x / ncb, cb = blockIdx.x - tile * ncb;
   const int c0 = cb * BC;
-  const int tiles_x = g.W / TW, tiles_y = g.H / TH;
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;     // ragged edge tiles are masked in the epilogue
   const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tn0 = (tile / (tiles_x * tiles_y)) * TI;
   const int y0 = ty * TH, x0 = tx * TW;
   const int j = t & 7, row0 = t >> 3;
@@ -365,18 +390,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   }
 
   // the loop's final barrier has passed: no wave reads the patch / weight tiles any more
-  halo_epilogue_dispatch<BC, SMALLW>(a, acc, &sRed[0][0][0], smem, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
+  halo_epilogue_dispatch<BC, SMALLW, RAGGED>(a, acc, &sRed[0][0][0], smem, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
 
 template <int BC, bool DGRAD, bool SMALLW>
 static int launch_halo(const ConvArgs& a, hipStream_t stream) {
   const int WAVES_P = 4 / (BC / 64);
   const int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
-  const int tiles = ((a.g.N + TI - 1) / TI) * (a.g.H / TH) * (a.g.W / TW);
+  const int tiles = ((a.g.N + TI - 1) / TI) * ((a.g.H + TH - 1) / TH) * ((a.g.W + TW - 1) / TW);
   const int ncb = a.Cout / BC;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW>), dim3(tiles * ncb), dim3(256), 0, stream, a);
+  const bool ragged = !SMALLW && (a.g.H % TH != 0 || a.g.W % TW != 0);
+  if (ragged) hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, !SMALLW>), dim3(tiles * ncb), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, false>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   return vfs_check_launch("conv3x3_halo");
 }
+
+int vfs_option_halo_min_fill = 70;    // percent of a ragged tiling that must be real pixels (100: exact tilings only)
 
 // eligibility: 3x3 / stride 1 / pad 1, 64-channel granularity, and a spatial tiling that keeps the
 // per-128-pixel statistics rows aligned with the two halves of the batch:
@@ -388,15 +417,16 @@ bool vfs_conv_halo_eligible(const ConvArgs& a, int mode) {
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
   if (a.Cout % 64 || g.C % 64) return false;
   if (g.H != g.Ho || g.W != g.Wo) return false;
-  if (a.Cout % 128 == 0) {
-    if (g.H % 8 == 0 && g.W % 16 == 0) return true;
-    return g.W == 8 && g.H == 8 && g.N % 2 == 0;
-  }
-  return g.H % 16 == 0 && g.W % 16 == 0;
+  if (g.W == 8 && g.H == 8 && a.Cout % 128 == 0) return g.N % 2 == 0;
+  // other maps: 8x16 (Cout % 128 == 0) or 16x16 tiles; edge tiles may be ragged (masked stores / statistics) as long
+  // as the tiles are mostly full: 56 x 56 -> 87 / 77 %, 28 x 28 and 14 x 14 -> 77 %, 7 x 7 -> 38 % (not taken)
+  const int th = a.Cout % 128 == 0 ? 8 : 16, tw = 16;
+  const long long cover = (long long)((g.H + th - 1) / th * th) * ((g.W + tw - 1) / tw * tw);
+  return (long long)g.H * g.W * 100 >= cover * vfs_option_halo_min_fill;
 }
 
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
-  const bool wide = (a.Cout % 128 == 0), smallw = a.g.W == 8, dg = mode == GATHER_DGRAD;
+  const bool wide = (a.Cout % 128 == 0), smallw = a.g.W == 8 && a.g.H == 8, dg = mode == GATHER_DGRAD;
   if (wide) {
     if (dg) return smallw ? launch_halo<128, true, true>(a, stream) : launch_halo<128, true, false>(a, stream);
     return smallw ? launch_halo<128, false, true>(a, stream) : launch_halo<128, false, false>(a, stream);

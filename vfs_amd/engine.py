@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import Tape, TapeLib, get_lib
-from .packing import igemm_ksplit, bn_fold_eligible, build_pack_table, wgrad_halo_eligible, wgrad_splits
+from .packing import igemm_ksplit, bn_fold_eligible, build_pack_table, conv_stats_rows, wgrad_halo_eligible, wgrad_splits
 
 BF16 = torch.bfloat16
 
@@ -176,8 +176,11 @@ class Engine:
         want_stats = u.bn is not None and train
         Ng = N // G
         mpg = Ng * Ho * Wo
-        fused = G == 1 or mpg % 128 == 0
-        nblk_g = (mpg + 127) // 128
+        # statistics rows per group when ONE launch covers all groups (spatial tiles of the halo kernels, ragged
+        # edges included, or linear 128-pixel blocks), else one launch per group
+        rows = None if u.kind == 'stem' else conv_stats_rows(N, G, H, W, u.cin, u.cout, u.k, u.stride, u.pad, Ho, Wo)
+        fused = rows is not None
+        nblk_g = rows if fused else (mpg + 127) // 128
         if u.kind == 'stem':      # the stem kernel emits one statistics row per 8x16 spatial tile
             fused = True
             nblk_g = Ng * ((Ho + 7) // 8) * ((Wo + 15) // 16)
@@ -450,8 +453,10 @@ class Engine:
             pu, praw, pymask, prelu, G = bn_next
             Min = N * H * W
             mpg = Min // G
-            if G == 1 or mpg % 128 == 0:
-                nblk = (Min + 127) // 128
+            # the dgrad as a conv [N,Ho,Wo,cout] -> [N,H,W,cin]: its statistics rows (tiles or linear blocks)
+            rows = conv_stats_rows(N, G, Ho, Wo, u.cout, u.cin, u.k, u.stride, u.pad, H, W)
+            if rows is not None:
+                nblk = rows * G
                 partial = self.ws('ws.bnbwd_fused', nblk * 2 * u.cin, torch.float32, dev)
                 self.timed('conv_igemm', (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + (1 if pymask is not None else 0))),
                            dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,

@@ -34,13 +34,41 @@ def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
     return W % 16 == 0 or (W == 8 and H == 8)
 
 
+HALO_MIN_FILL = int(os.environ.get('VFS_HALO_MIN_FILL', '70'))      # mirror of vfs_option_halo_min_fill (A/B: set both)
+
+
 def conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
-    """mirror of vfs_conv_halo_eligible (csrc/conv_halo.hip), forward"""
+    """mirror of vfs_conv_halo_eligible (csrc/conv_halo.hip), forward / stride-1 dgrad"""
     if k != 3 or stride != 1 or pad != 1 or Cin % 64 or Cout % 64:
         return False
+    if W == 8 and H == 8 and Cout % 128 == 0:
+        return N % 2 == 0
+    th, tw = (8 if Cout % 128 == 0 else 16), 16
+    cover = ((H + th - 1) // th * th) * ((W + tw - 1) // tw * tw)
+    return H * W * 100 >= cover * HALO_MIN_FILL
+
+
+def halo_stats_rows(N, H, W, Cout):
+    """statistics rows the halo kernels emit for an [N,H,W,Cout] output: one per 128 tile pixels (ragged edge tiles
+    included), tiles enumerated image-major - so a group of whole images owns a contiguous block of rows"""
+    if W == 8 and H == 8 and Cout % 128 == 0:
+        return N // 2
     if Cout % 128 == 0:
-        return (H % 8 == 0 and W % 16 == 0) or (W == 8 and H == 8 and N % 2 == 0)
-    return H % 16 == 0 and W % 16 == 0
+        return N * ((H + 7) // 8) * ((W + 15) // 16)
+    return N * ((H + 15) // 16) * ((W + 15) // 16) * 2
+
+
+def conv_stats_rows(N, G, H, W, Cin, Cout, k, stride, pad, Ho, Wo, halo=True):
+    """rows per statistics group of the per-block (sum, sum of squares) rows a forward conv - or a stride-1 dgrad seen
+    as a conv producing [N,Ho,Wo,Cout] - writes in ONE launch, or None when the groups do not own whole rows (the
+    caller then launches per group): spatial tiles for the halo kernels, linear 128-pixel blocks otherwise."""
+    if halo and conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
+        total = halo_stats_rows(N, Ho, Wo, Cout)
+        return total // G if (N % G == 0 and total % G == 0) else None
+    mpg = (N // G) * Ho * Wo
+    if G == 1 or mpg % 128 == 0:
+        return (mpg + 127) // 128
+    return None
 
 
 def bn_fold_eligible(N, G, H, W, Cin, Cout, k, stride, pad):
