@@ -188,6 +188,8 @@ def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, m
     (2, 16, 32, 128, 128, 2),     # 8x16 tiles, two channel chunks, two groups
     (2, 32, 32, 64, 64, 2),       # 16x16 tiles (64 output channels)
     (4, 8, 8, 64, 128, 2),        # whole 8x8 images, two per tile
+    (2, 14, 14, 64, 128, 2),      # ragged 8x16 tiles
+    (2, 28, 28, 64, 64, 1),       # ragged 16x16 tiles (forward) / 8x16 tiles (weight gradient)
 ])
 def test_conv_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):
     """vfs_conv_fwd_bnin / vfs_conv_wgrad_bnin (the activation of the producer unit is never materialised)
@@ -204,7 +206,7 @@ def test_conv_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):
     rawd, bnpd = d(raw), d(bnp)
     act = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
     lib.bn_act(rawd, bnpd, None, None, None, act, M, Cin, M // G, 1, None)
-    nblk = (M + 127) // 128
+    nblk = conv_stats_rows(N, 1, H, W, Cin, Cout, 3, 1, 1, H, W)
     y0 = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
     y1 = torch.full_like(y0, float('nan'))
     st0 = torch.full((nblk, 2, Cout), float('nan'), device=dev)

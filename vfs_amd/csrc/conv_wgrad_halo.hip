@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
   const int cb = b % ncb; b /= ncb;
   const int split = b;
   const int j = t & 7, row0 = t >> 3;
-  const int tiles_x = g.W / TW, tiles_y = g.H / TH;
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;   // ragged edge tiles: their dY rows load as zero
 
   // loader geometry (fixed per thread): patch slots and dY rows
   int p_ti[PLD], p_y[PLD], p_x[PLD];
@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + d_ti[i];
-      const unsigned off = n < g.N ? (unsigned)((((size_t)(n * g.H + y0 + d_y[i]) * g.W + x0 + d_x[i]) * a.Cout +
-                                                 cb * 64 + j * 8) * 2) : OOB_OFFSET;
+      const bool ok = n < g.N && y0 + d_y[i] < g.H && x0 + d_x[i] < g.W;     // pixels past the map contribute nothing
+      const unsigned off = ok ? (unsigned)((((size_t)(n * g.H + y0 + d_y[i]) * g.W + x0 + d_x[i]) * a.Cout +
+                                            cb * 64 + j * 8) * 2) : OOB_OFFSET;
       dv[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0);
     }
   };
@@ -203,19 +204,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     }
 }
 
+extern int vfs_option_halo_min_fill;
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode) {
   const ConvGeom& g = a.g;
   if (mode != GATHER_FWD || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
-  if (g.H != g.Ho || g.W != g.Wo || g.H % 8 || g.C % 64 || a.Cout % 64) return false;
+  if (g.H != g.Ho || g.W != g.Wo || g.C % 64 || a.Cout % 64) return false;
   if ((size_t)g.N * g.H * g.W * g.C * 2 >= 0xFFFFFFF0ull || (size_t)g.N * g.H * g.W * a.Cout * 2 >= 0xFFFFFFF0ull) return false;
-  if (g.W % 16 == 0) return true;
-  return g.W == 8 && g.H == 8;
+  if (g.W == 8 && g.H == 8) return true;
+  // 8x16 tiles, ragged at the right / bottom edge when the map is not a multiple (zero dY rows), mostly full
+  const long long cover = (long long)((g.H + 7) / 8 * 8) * ((g.W + 15) / 16 * 16);
+  return (long long)g.H * g.W * 100 >= cover * vfs_option_halo_min_fill;
 }
 
 int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsplit) {
-  const bool smallw = a.g.W == 8;
+  const bool smallw = a.g.W == 8 && a.g.H == 8;
   const int TW = smallw ? 8 : 16, TI = smallw ? 2 : 1;
-  const int ntiles = ((a.g.N + TI - 1) / TI) * (a.g.H / 8) * (a.g.W / TW);
+  const int ntiles = ((a.g.N + TI - 1) / TI) * ((a.g.H + 7) / 8) * ((a.g.W + TW - 1) / TW);
   const int nsplit = a.nsplit < ntiles ? a.nsplit : ntiles;
   const int tps = (ntiles + nsplit - 1) / nsplit;
   WgradArgs b = a;

@@ -29,9 +29,12 @@ def build_pack_table(entries, device):
 
 def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
     """mirror of vfs_wgrad_halo_eligible (csrc/conv_wgrad_halo.hip)"""
-    if k != 3 or stride != 1 or pad != 1 or H % 8 or Cin % 64 or Cout % 64:
+    if k != 3 or stride != 1 or pad != 1 or Cin % 64 or Cout % 64:
         return False
-    return W % 16 == 0 or (W == 8 and H == 8)
+    if W == 8 and H == 8:
+        return True
+    cover = ((H + 7) // 8 * 8) * ((W + 15) // 16 * 16)
+    return H * W * 100 >= cover * HALO_MIN_FILL
 
 
 HALO_MIN_FILL = int(os.environ.get('VFS_HALO_MIN_FILL', '70'))      # mirror of vfs_option_halo_min_fill (A/B: set both)
@@ -106,7 +109,7 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
     128-pixel spatial tiles)."""
     if halo_geom is not None:
         N, H, W, Cin = halo_geom
-        ntiles = ((N + 1) // 2) if W == 8 else N * (H // 8) * (W // 16)
+        ntiles = ((N + 1) // 2) if (W == 8 and H == 8) else N * ((H + 7) // 8) * ((W + 15) // 16)
         colblocks = (Cin // 64) * (Cout // 64)
         # every workgroup writes a 9x64x64 fp32 partial (147 KB): keep ~2 workgroups per CU so
         # the split-K traffic (blocks x 147 KB, written then re-read) stays well below the MFMA time
