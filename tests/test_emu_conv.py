@@ -89,6 +89,7 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (2, 14, 14, 64, 128, 3, 1, 1),    # halo-tile kernel, RAGGED 8x16 tiles (14 x 14 map of a 224 x 224 input)
     (1, 28, 28, 64, 64, 3, 1, 1),     # halo-tile kernel, RAGGED 16x16 tiles (28 x 28)
     (3, 7, 14, 128, 128, 3, 1, 1),    # halo-tile kernel, ragged bottom row only, odd image count
+    (4, 7, 7, 64, 128, 3, 1, 1),      # halo-tile kernel, whole 7x7 images in pairs (8x8 tiles, masked)
 ]
 
 
@@ -133,6 +134,7 @@ def test_pack_weights_ragged(backend, shape):
     (4, 32, 32, 64, 64, 3, 2),      # halo dgrad, 64 output channels: 16x16 tiles, two rows per tile
     (4, 8, 8, 128, 128, 3, 2),      # halo dgrad on whole 8x8 images (two per tile)
     (2, 14, 14, 128, 64, 3, 2),     # halo dgrad, RAGGED 8x16 tiles, two statistics groups
+    (4, 7, 7, 128, 128, 3, 2),      # halo dgrad on whole 7x7 images (two per tile)
     (2, 28, 28, 64, 64, 3, 1),      # halo dgrad, RAGGED 16x16 tiles
     (3, 7, 7, 128, 64, 1, 1),       # generic kernel, ragged M = 147
     (2, 8, 8, 64, 128, 1, 1),       # generic kernel, 64 output channels (32-channel waves)
@@ -189,6 +191,7 @@ def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, m
     (2, 32, 32, 64, 64, 2),       # 16x16 tiles (64 output channels)
     (4, 8, 8, 64, 128, 2),        # whole 8x8 images, two per tile
     (2, 14, 14, 64, 128, 2),      # ragged 8x16 tiles
+    (4, 7, 7, 64, 128, 2),        # whole 7x7 images, two per tile
     (2, 28, 28, 64, 64, 1),       # ragged 16x16 tiles (forward) / 8x16 tiles (weight gradient)
 ])
 def test_conv_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):

@@ -26,7 +26,7 @@ int vfs_check_launch(const char* what) {
 
 int vfs_option_halo = 1;
 int vfs_option_stem_blocks = 0;
-extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_halo_min_fill;
+extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles;
 
@@ -103,7 +103,7 @@ int vfs_conv_fwd_bnin(const vfs_bf16* x_raw, const float* in_bnp, int in_npg, co
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
   a.src = x_raw; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
   a.in_bnp = in_bnp; a.in_npg = in_npg;
-  const bool smallw = (W == 8 && H == 8);
+  const bool smallw = vfs_small_map(H, W);
   if (!vfs_option_halo || Cin % 64 || (size_t)N * H * W * Cin * 2 >= 0xFFFFFFF0ull || !vfs_conv_halo_eligible(a, GATHER_FWD) ||
       (smallw && in_npg % 2))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_fwd_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
@@ -172,7 +172,7 @@ int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* 
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
   a.dy = dy; a.x = x_raw; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
   a.in_bnp = in_bnp; a.in_npg = in_npg;
-  if (!vfs_option_halo || !vfs_wgrad_halo_eligible(a, GATHER_FWD) || (W == 8 && H == 8 && in_npg % 2))
+  if (!vfs_option_halo || !vfs_wgrad_halo_eligible(a, GATHER_FWD) || (vfs_small_map(H, W) && in_npg % 2))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
   int rc = vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);
   if (rc) return rc;

@@ -399,8 +399,8 @@ static int launch_halo(const ConvArgs& a, hipStream_t stream) {
   const int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
   const int tiles = ((a.g.N + TI - 1) / TI) * ((a.g.H + TH - 1) / TH) * ((a.g.W + TW - 1) / TW);
   const int ncb = a.Cout / BC;
-  const bool ragged = !SMALLW && (a.g.H % TH != 0 || a.g.W % TW != 0);
-  if (ragged) hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, !SMALLW>), dim3(tiles * ncb), dim3(256), 0, stream, a);
+  const bool ragged = a.g.H % TH != 0 || a.g.W % TW != 0;
+  if (ragged) hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, true>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, false>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   return vfs_check_launch("conv3x3_halo");
 }
@@ -417,7 +417,7 @@ bool vfs_conv_halo_eligible(const ConvArgs& a, int mode) {
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
   if (a.Cout % 64 || g.C % 64) return false;
   if (g.H != g.Ho || g.W != g.Wo) return false;
-  if (g.W == 8 && g.H == 8 && a.Cout % 128 == 0) return g.N % 2 == 0;
+  if (vfs_small_map(g.H, g.W) && a.Cout % 128 == 0) return g.N % 2 == 0;
   // other maps: 8x16 (Cout % 128 == 0) or 16x16 tiles; edge tiles may be ragged (masked stores / statistics) as long
   // as the tiles are mostly full: 56 x 56 -> 87 / 77 %, 28 x 28 and 14 x 14 -> 77 %, 7 x 7 -> 38 % (not taken)
   const int th = a.Cout % 128 == 0 ? 8 : 16, tw = 16;
@@ -426,7 +426,7 @@ bool vfs_conv_halo_eligible(const ConvArgs& a, int mode) {
 }
 
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
-  const bool wide = (a.Cout % 128 == 0), smallw = a.g.W == 8 && a.g.H == 8, dg = mode == GATHER_DGRAD;
+  const bool wide = (a.Cout % 128 == 0), smallw = vfs_small_map(a.g.H, a.g.W), dg = mode == GATHER_DGRAD;
   if (wide) {
     if (dg) return smallw ? launch_halo<128, true, true>(a, stream) : launch_halo<128, true, false>(a, stream);
     return smallw ? launch_halo<128, false, true>(a, stream) : launch_halo<128, false, false>(a, stream);

@@ -204,20 +204,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     }
 }
 
-extern int vfs_option_halo_min_fill;
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode) {
   const ConvGeom& g = a.g;
   if (mode != GATHER_FWD || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
   if (g.H != g.Ho || g.W != g.Wo || g.C % 64 || a.Cout % 64) return false;
   if ((size_t)g.N * g.H * g.W * g.C * 2 >= 0xFFFFFFF0ull || (size_t)g.N * g.H * g.W * a.Cout * 2 >= 0xFFFFFFF0ull) return false;
-  if (g.W == 8 && g.H == 8) return true;
+  if (vfs_small_map(g.H, g.W)) return true;
   // 8x16 tiles, ragged at the right / bottom edge when the map is not a multiple (zero dY rows), mostly full
   const long long cover = (long long)((g.H + 7) / 8 * 8) * ((g.W + 15) / 16 * 16);
   return (long long)g.H * g.W * 100 >= cover * vfs_option_halo_min_fill;
 }
 
 int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsplit) {
-  const bool smallw = a.g.W == 8 && a.g.H == 8;
+  const bool smallw = vfs_small_map(a.g.H, a.g.W);
   const int TW = smallw ? 8 : 16, TI = smallw ? 2 : 1;
   const int ntiles = ((a.g.N + TI - 1) / TI) * ((a.g.H + 7) / 8) * ((a.g.W + TW - 1) / TW);
   const int nsplit = a.nsplit < ntiles ? a.nsplit : ntiles;

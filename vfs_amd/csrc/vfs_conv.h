@@ -89,6 +89,10 @@ __device__ __forceinline__ u32x4 bn_relu_vec(u32x4 v, const f32x4& sc0, const f3
 
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode);
+// maps of at most 8x8 pixels that fill most of an 8x8 tile (8x8, 7x7 with the default 70 %): the halo kernels take
+// two whole images per workgroup
+extern int vfs_option_halo_min_fill;
+static inline bool vfs_small_map(int H, int W) { return H <= 8 && W <= 8 && H * W * 100 >= 64 * vfs_option_halo_min_fill; }
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode);
 int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsplit);

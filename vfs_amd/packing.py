@@ -27,11 +27,16 @@ def build_pack_table(entries, device):
     return t, len(entries), tiles
 
 
+def small_map(H, W):
+    """mirror of vfs_small_map (csrc/vfs_conv.h): whole images of <= 8x8 pixels, two per halo tile"""
+    return H <= 8 and W <= 8 and H * W * 100 >= 64 * HALO_MIN_FILL
+
+
 def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
     """mirror of vfs_wgrad_halo_eligible (csrc/conv_wgrad_halo.hip)"""
     if k != 3 or stride != 1 or pad != 1 or Cin % 64 or Cout % 64:
         return False
-    if W == 8 and H == 8:
+    if small_map(H, W):
         return True
     cover = ((H + 7) // 8 * 8) * ((W + 15) // 16 * 16)
     return H * W * 100 >= cover * HALO_MIN_FILL
@@ -44,7 +49,7 @@ def conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
     """mirror of vfs_conv_halo_eligible (csrc/conv_halo.hip), forward / stride-1 dgrad"""
     if k != 3 or stride != 1 or pad != 1 or Cin % 64 or Cout % 64:
         return False
-    if W == 8 and H == 8 and Cout % 128 == 0:
+    if small_map(H, W) and Cout % 128 == 0:
         return N % 2 == 0
     th, tw = (8 if Cout % 128 == 0 else 16), 16
     cover = ((H + th - 1) // th * th) * ((W + tw - 1) // tw * tw)
@@ -54,7 +59,7 @@ def conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
 def halo_stats_rows(N, H, W, Cout):
     """statistics rows the halo kernels emit for an [N,H,W,Cout] output: one per 128 tile pixels (ragged edge tiles
     included), tiles enumerated image-major - so a group of whole images owns a contiguous block of rows"""
-    if W == 8 and H == 8 and Cout % 128 == 0:
+    if small_map(H, W) and Cout % 128 == 0:
         return N // 2
     if Cout % 128 == 0:
         return N * ((H + 7) // 8) * ((W + 15) // 16)
@@ -80,7 +85,7 @@ def bn_fold_eligible(N, G, H, W, Cin, Cout, k, stride, pad):
     must not straddle two statistics groups (8x8 images are tiled in pairs)."""
     if not (conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad) and wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad)):
         return False
-    if W == 8 and H == 8 and (N // G) % 2:
+    if small_map(H, W) and (N // G) % 2:
         return False
     return N % G == 0 and G <= 8
 
@@ -109,7 +114,7 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
     128-pixel spatial tiles)."""
     if halo_geom is not None:
         N, H, W, Cin = halo_geom
-        ntiles = ((N + 1) // 2) if (W == 8 and H == 8) else N * ((H + 7) // 8) * ((W + 15) // 16)
+        ntiles = ((N + 1) // 2) if small_map(H, W) else N * ((H + 7) // 8) * ((W + 15) // 16)
         colblocks = (Cin // 64) * (Cout // 64)
         # every workgroup writes a 9x64x64 fp32 partial (147 KB): keep ~2 workgroups per CU so
         # the split-K traffic (blocks x 147 KB, written then re-read) stays well below the MFMA time
