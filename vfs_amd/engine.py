@@ -54,6 +54,9 @@ class Engine:
         for kv in filter(None, os.environ.get('VFS_OPTS', '').split(',')):      # kernel A/B knobs: "name=value,..."
             name, value = kv.split('=')
             self.lib.set_option(name.strip().encode(), int(value))
+            if name.strip() == 'halo_min_fill':      # the host mirrors of the tiling rules must agree with the library
+                from . import packing
+                packing.HALO_MIN_FILL = int(value)
 
     # ------------------------------------------------------------------ command tape (see _lib.Tape)
     def begin_tape(self):

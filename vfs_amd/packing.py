@@ -42,7 +42,7 @@ def wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
     return H * W * 100 >= cover * HALO_MIN_FILL
 
 
-HALO_MIN_FILL = int(os.environ.get('VFS_HALO_MIN_FILL', '70'))      # mirror of vfs_option_halo_min_fill (A/B: set both)
+HALO_MIN_FILL = 70      # mirror of vfs_option_halo_min_fill (VFS_OPTS=halo_min_fill=.. sets both, see Engine)
 
 
 def conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad):
