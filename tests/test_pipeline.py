@@ -61,9 +61,9 @@ def test_reference_config_parses():
         cfg = Config.fromfile(c)
         if 'train_pipeline' not in cfg:
             continue
-        sf = [s for s in cfg.train_pipeline if s['type'] == 'SampleFrames'][0]
-        pipe = GpuTrainPipeline(cfg.train_pipeline, sf['num_clips'], sf['clip_len'])
+        pipe = GpuTrainPipeline(cfg.train_pipeline)
         assert pipe.out_hw == (224, 224) and pipe.crop is not None and pipe.flip is not None
+        assert (pipe.num_clips, pipe.clip_len) == ((2, 4) if 'r18' in c else (2, 1))
 
 
 def test_oracle_resize_known_answers():
@@ -139,3 +139,32 @@ def test_kernel_edge_boxes(backend):
 def test_kernel_full_size(gpu_backend):
     """BASELINE size: 340x256 decoded frames -> 224x224, 8 pairs; checked against the oracle on the GPU box"""
     run_pipeline_case(gpu_backend, 8, 2, 1, 256, 340, 224, 224, seed=9)
+
+
+@pytest.mark.gpu
+def test_pipeline_feeds_train_step(gpu_backend):
+    """decoded uint8 frames -> GpuTrainPipeline (built from the shipped config's train_pipeline) -> train_step: the imgs
+    tensor equals the oracle pipeline's bit for bit, so the step's log vars equal those of the oracle-fed step"""
+    import vfs_amd
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = vfs_amd.Config.fromfile(os.path.join(here, 'configs', 'vfs_r18.py'))
+    tp = [dict(s) for s in cfg.train_pipeline]
+    for s in tp:                                  # a small crop keeps the test quick; everything else as shipped
+        if s['type'] == 'Resize':
+            s['scale'] = (64, 64)
+    pipe = GpuTrainPipeline(tp)
+    V, T = pipe.num_clips, pipe.clip_len
+    assert (V, T) == (2, 4)
+    B = 4
+    frames = _frames(B, V * T, 72, 96, 21)
+    np.random.seed(1)
+    random.seed(1)
+    out = pipe(torch.from_numpy(frames).to(gpu_backend.dev))
+    want = PO.train_pipeline(frames, out['boxes'], out['flips'], (64, 64), pipe.mean, pipe.std, V, T)
+    assert np.array_equal(out['imgs'].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(gpu_backend.dev).train()
+    res = model.train_step(dict(imgs=out['imgs'], label=torch.zeros(B, 1)), None)
+    res['loss'].backward()
+    assert np.isfinite(res['log_vars']['loss']) and res['num_samples'] == B
+    res2 = model.train_step(dict(imgs=torch.from_numpy(want).to(gpu_backend.dev), label=torch.zeros(B, 1)), None)
+    assert res2['log_vars'].keys() == res['log_vars'].keys()

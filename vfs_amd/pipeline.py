@@ -40,12 +40,31 @@ def _new_for_frame(i, clip_len, same_on_clip, same_across_clip):
     return (not same_on_clip) or ((not same_across_clip) and i % clip_len == 0 and i > 0)
 
 
+def clips_from_pipeline(pipeline_cfg):
+    """(num_clips, clip_len) of the frames that reach the augmentations: SampleFrames' values, regrouped by
+    Clip2Frame when present (r18 config: 8 clips of 1 frame -> 2 clips of 4 frames, pipelines/loading.py:226-232)"""
+    num_clips = clip_len = None
+    for step in pipeline_cfg:
+        if step['type'] == 'SampleFrames':
+            num_clips, clip_len = int(step.get('num_clips', 1)), int(step['clip_len'])
+        elif step['type'] == 'Clip2Frame' and num_clips is not None:
+            total = num_clips * clip_len
+            clip_len = int(step['clip_len'])
+            assert total % clip_len == 0
+            num_clips = total // clip_len
+    if num_clips is None:
+        raise ValueError('the pipeline has no SampleFrames step: pass num_clips / clip_len')
+    return num_clips, clip_len
+
+
 class GpuTrainPipeline:
     """Built from the reference's `train_pipeline` list; `__call__(frames)` with frames uint8
     [B][num_clips*clip_len][Hs][Ws][3] on the GPU returns dict(imgs=fp32 [B][num_clips][3][clip_len][H][W])
     (and x4, the bf16 NHWC4 frames, when asked)."""
 
-    def __init__(self, pipeline_cfg, num_clips, clip_len):
+    def __init__(self, pipeline_cfg, num_clips=None, clip_len=None):
+        if num_clips is None or clip_len is None:
+            num_clips, clip_len = clips_from_pipeline(pipeline_cfg)
         self.num_clips, self.clip_len = int(num_clips), int(clip_len)
         self.crop = self.flip = None
         self.out_hw, self.mean, self.std = None, None, None
