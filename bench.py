@@ -185,7 +185,7 @@ def main():
 
     pairs_per_step = B * T * world
     res = {
-        'metric': 'frame-pairs/sec (train)', 'value': pairs_per_step * args.steps / dt, 'unit': 'frame-pairs/s',
+        'metric': f'frame-pairs/sec (train) R{depth} {args.size}\u00b2', 'value': pairs_per_step * args.steps / dt, 'unit': 'frame-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'ResNet-{depth} SimSiam (VFS) forward_train+backward+SGD, imgs [{B},2,3,{T},{args.size},'
