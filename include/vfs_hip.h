@@ -87,6 +87,12 @@ int vfs_conv_fwd_splitk(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, cons
 int vfs_conv_dgrad_splitk(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, float* ks_ws,
                           int ksplit, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                           int stride, int pad, vfs_stream_t stream);
+/* forward conv with dilated taps (resnet.py:51-58,172-179: ConvModule(padding=dilation, dilation=dilation) of a ResNet built
+ * with dilations != 1 - the frozen backbone of the SiamFC probe, projects/siamfc-pytorch/siamfc/default_config_base.py:40-49).
+ * Forward only: there is no dgrad / wgrad for dilated layers.  Ho = (H + 2 pad - dilation (KH - 1) - 1) / stride + 1. */
+int vfs_conv_fwd_dilated(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, int N,
+                         int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                         int dilation, vfs_stream_t stream);
 /* conv-BN-ReLU -> conv without materialising the activation: x_raw is the RAW output of the producer unit,
  * in_bnp its float[G][4][Cin] {scale, shift, mean, invstd}, in_npg images per group; relu(x*scale+shift)
  * (rounded to bf16 exactly as vfs_bn_act) is applied while the halo patch is staged, padding stays zero.

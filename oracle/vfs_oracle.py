@@ -87,9 +87,9 @@ class ConvBN(nn.Module):
     optional ReLU; sub-module names ``conv`` / ``bn`` feed the state_dict keys
     (resnet.py:51-73, 163-191, 267-277, 425-434)."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, relu=True):
+    def __init__(self, cin, cout, k, stride=1, padding=0, relu=True, dilation=1):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, dilation=dilation, bias=False)
         self.bn = nn.BatchNorm2d(cout)  # eps 1e-5, momentum 0.1 (torch defaults, as mmcv)
         self.relu = relu
         self.emulate_bf16 = False
@@ -104,7 +104,7 @@ class ConvBN(nn.Module):
 
     def raw(self, x):
         e = self.emulate_bf16
-        y = F.conv2d(x, _w_round(self.conv.weight, e), None, self.conv.stride, self.conv.padding)
+        y = F.conv2d(x, _w_round(self.conv.weight, e), None, self.conv.stride, self.conv.padding, self.conv.dilation)
         return _act_round(y, e)
 
     def forward(self, x, residual=None):
@@ -126,9 +126,9 @@ class BasicBlock(nn.Module):
     """resnet.py:15-113: relu(bn2(conv2(relu(bn1(conv1(x))))) + identity)."""
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
         super().__init__()
-        self.conv1 = ConvBN(inplanes, planes, 3, stride, 1, relu=True)
+        self.conv1 = ConvBN(inplanes, planes, 3, stride, dilation, relu=True, dilation=dilation)   # resnet.py:51-58
         self.conv2 = ConvBN(planes, planes, 3, 1, 1, relu=False)
         self.downsample = downsample
 
@@ -142,10 +142,10 @@ class Bottleneck(nn.Module):
     """resnet.py:116-232, style='pytorch': the stride sits on the 3x3."""
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
         super().__init__()
         self.conv1 = ConvBN(inplanes, planes, 1, 1, 0, relu=True)
-        self.conv2 = ConvBN(planes, planes, 3, stride, 1, relu=True)
+        self.conv2 = ConvBN(planes, planes, 3, stride, dilation, relu=True, dilation=dilation)     # resnet.py:172-179
         self.conv3 = ConvBN(planes, planes * 4, 1, 1, 0, relu=False)
         self.downsample = downsample
 
@@ -162,7 +162,7 @@ class ResNet(nn.Module):
                      152: (Bottleneck, (3, 8, 36, 3))}
 
     def __init__(self, depth, strides=(1, 2, 2, 2), out_indices=(3,), zero_init_residual=True,
-                 stop_after_out=False, num_stages=4):
+                 stop_after_out=False, num_stages=4, dilations=(1, 1, 1, 1)):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError(f'invalid depth {depth} for resnet')
@@ -178,9 +178,10 @@ class ResNet(nn.Module):
             down = None
             if stride != 1 or inplanes != planes * block.expansion:   # resnet.py:266-277
                 down = ConvBN(inplanes, planes * block.expansion, 1, stride, 0, relu=False)
-            layers = [block(inplanes, planes, stride, down)]
+            dil = dilations[i]                                            # resnet.py:279-300
+            layers = [block(inplanes, planes, stride, down, dil if dil == 1 else dil // 2)]
             inplanes = planes * block.expansion
-            layers += [block(inplanes, planes, 1, None) for _ in range(1, nb)]
+            layers += [block(inplanes, planes, 1, None, dil) for _ in range(1, nb)]
             self.add_module(f'layer{i + 1}', nn.Sequential(*layers))
             self.res_layers.append(f'layer{i + 1}')
         self.feat_dim = inplanes

@@ -337,3 +337,20 @@ def test_splitk_linear_matches_plain_kernel(backend, M, Cin, Cout):
         want = torch.einsum('mo,oi->mi', dy[:, :, 0, 0], w[:, :, 0, 0]) + add[:, :, 0, 0]
         assert relerr(dx.float().cpu()[:, 0, 0], want) < 6e-3
         assert torch.equal(ws2[:1024].cpu(), torch.zeros(1024))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride,dil', [(2, 12, 16, 64, 128, 1, 2), (1, 16, 16, 128, 64, 1, 4), (2, 13, 13, 64, 64, 2, 2)])
+def test_dilated_forward_conv(backend, N, H, W, Cin, Cout, stride, dil):
+    """vfs_conv_fwd_dilated (3x3, padding = dilation: the frozen dilated backbone of the SiamFC probe) vs torch conv2d"""
+    lib, d = backend.lib, backend.d
+    g = torch.Generator().manual_seed(N + H + dil)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5)
+    wf, _ = pack(backend, w)
+    Ho, Wo = (H + 2 * dil - 2 * dil - 1) // stride + 1, (W + 2 * dil - 2 * dil - 1) // stride + 1
+    y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16, device=backend.dev)
+    lib.conv_fwd_dilated(d(nhwc(x)), wf, y, None, None, N, H, W, Cin, Ho, Wo, Cout, 3, 3, stride, dil, dil, None)
+    ref = F.conv2d(x, w, None, stride, dil, dil)
+    assert relerr(nchw(y.cpu()), ref) < 6e-3
+    with pytest.raises(Exception):      # the output size must follow the dilated formula
+        lib.conv_fwd_dilated(d(nhwc(x)), wf, y, None, None, N, H, W, Cin, Ho + 1, Wo, Cout, 3, 3, stride, dil, dil, None)

@@ -294,3 +294,36 @@ def test_fast_train_step_equals_parse_losses_path(gpu_backend, monkeypatch):
             assert isinstance(a[k], float) and abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), (k, a[k], b[k])
     for k in sda:
         assert torch.equal(sda[k], sdb[k]), k
+
+
+@pytest.mark.parametrize('depth', [18, 50])
+def test_dilated_frozen_backbone_matches_oracle(backend, depth):
+    """ResNet(dilations=(1,1,2,4), strides=(1,2,1,1), frozen, norm_eval) as the SiamFC probe builds it
+    (projects/siamfc-pytorch/siamfc/default_config_base.py:40-49): ResNet.forward (eval) through the HIP kernels vs the
+    oracle with bf16-storage emulation (the oracle itself is pinned to the reference in test_oracle_golden.py); the
+    backward of a dilated layer is refused."""
+    import vfs_amd
+    kw = dict(strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), out_indices=(3,))
+    ref = O.ResNet(depth, zero_init_residual=False, **kw)
+    O.fill_state_dict_(ref, seed=depth + 100)
+    net = vfs_amd.ResNet(depth, frozen_stages=4, norm_eval=True, norm_cfg=dict(type='BN', requires_grad=True),
+                         zero_init_residual=False, **kw)
+    net.load_state_dict(ref.state_dict())
+    net.to(backend.dev).eval()
+    x = O.fill_tensor([2, 3, 32, 48], seed=9, scale=2.0)
+    with torch.no_grad():
+        got = net(x.to(backend.dev)).cpu()
+        ref.eval()
+        want32 = ref(x)
+        for m in ref.modules():
+            if hasattr(m, 'emulate_bf16'):
+                m.emulate_bf16 = True
+        want = ref(O.round_bf16(x))
+    assert got.shape == want.shape
+    err_emul = float((want - want32).norm() / want32.norm())
+    err_hip = float((got - want32).norm() / want32.norm())
+    assert err_hip < max(2.0 * err_emul, 2e-2), (err_hip, err_emul)
+    u = net.layer4[1].conv1.unit if depth == 18 else net.layer4[1].conv2.unit
+    assert u.dil == 4
+    with pytest.raises(NotImplementedError):
+        backend.eng.conv_bwd(u, got, got, 1, 1, 1, 1, 1, True)

@@ -140,3 +140,20 @@ def test_forward_test_all_blocks_matches_reference():
     assert out.shape == g['seg_preds'].shape == (2, T, H, W) and out.dtype == np.uint8
     assert (out != g['seg_preds']).mean() == 0.0
 
+
+
+@pytest.mark.parametrize('depth', [18, 50])
+def test_dilated_resnet_eval_matches_reference(depth):
+    """the backbone as the SiamFC probe builds it (dilations (1,1,2,4), strides (1,2,1,1), eval): oracle vs features
+    captured from the reference class (tests/golden/gen_dilated_golden.py)"""
+    g = load(f'resnet{depth}_dilated_eval')
+    net = O.ResNet(depth, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), out_indices=(3,), zero_init_residual=False)
+    assert list(net.state_dict().keys()) == [str(k) for k in g['keys']]
+    O.fill_state_dict_(net, seed=depth + 100)
+    net.eval()
+    with torch.no_grad():
+        y = net(O.fill_tensor([2, 3, 64, 80], seed=9, scale=2.0))
+    assert list(y.shape) == list(g['shape'])
+    flat = y.flatten()
+    assert rel(flat[::13].numpy(), g['sample']) < 1e-5
+    assert abs(flat.double().abs().sum().item() - g['checksum'][1]) < 1e-5 * g['checksum'][1]

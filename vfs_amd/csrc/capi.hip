@@ -72,6 +72,18 @@ int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float
   a.in_bnp = nullptr; a.in_npg = 0;
   return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
 }
+int vfs_conv_fwd_dilated(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, int N, int H, int W,
+                         int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int dilation, vfs_stream_t stream) {
+  if (dilation < 1) return vfs_set_error(VFS_ERR_ARG, "conv_fwd_dilated: dilation >= 1");
+  if (Ho != (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 || Wo != (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1)
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_fwd_dilated: output size does not match (H + 2 pad - dilation (K - 1) - 1) / stride + 1");
+  ConvArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.g.dil = dilation;
+  a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
+  return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
+}
 int vfs_conv_fwd_splitk(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, float* ks_ws, int ksplit,
                         int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                         vfs_stream_t stream) {

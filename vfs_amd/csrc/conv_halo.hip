@@ -414,7 +414,7 @@ int vfs_option_halo_min_fill = 70;    // percent of a ragged tiling that must be
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode) {
   const ConvGeom& g = a.g;
   if (mode != GATHER_FWD && mode != GATHER_DGRAD) return false;
-  if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return false;
+  if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1 || g.dil != 1) return false;
   if (a.Cout % 64 || g.C % 64) return false;
   if (g.H != g.Ho || g.W != g.Wo) return false;
   if (vfs_small_map(g.H, g.W) && a.Cout % 128 == 0) return g.N % 2 == 0;

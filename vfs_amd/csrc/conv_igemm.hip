@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
           for (int si = 0; si < ns; ++si) {
             const int r = r0 + tstep * ri, s = s0 + tstep * si;
             int hi, wi;
-            if (MODE == GATHER_FWD) { hi = hb + r; wi = wb + s; }
+            if (MODE == GATHER_FWD) { hi = hb + r * g.dil; wi = wb + s * g.dil; }
             else if (MODE == GATHER_DGRAD) { hi = hb - r; wi = wb - s; }
             else { hi = hb + (ph + g.pad - r) / 2; wi = wb + (pw + g.pad - s) / 2; }
             if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) mask |= 1u << (ri * ns + si);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
         if (++l_si == ns) { l_si = 0; ++l_ri; }
       }
       int dh, dw;
-      if (MODE == GATHER_FWD) { dh = r; dw = s; }
+      if (MODE == GATHER_FWD) { dh = r * g.dil; dw = s * g.dil; }
       else if (MODE == GATHER_DGRAD) { dh = -r; dw = -s; }
       else { dh = (ph + g.pad - r) / 2; dw = (pw + g.pad - s) / 2; }
       delta = ((dh * g.W + dw) * g.C + cc) * 2;
@@ -451,6 +451,7 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
   if (mode != GATHER_STEM && a.g.KH * a.g.KW > 32) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: more than 32 taps");
   if ((size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 >= 0xFFFFFFF0ull || (size_t)a.Cout * a.g.Ktot * 2 >= 0xFFFFFFF0ull)
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: tensor >= 4 GiB (split the batch)");
+  if (a.g.dil != 1 && mode != GATHER_FWD) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: dilation is forward-only");
   if (a.bn.partial && (mode != GATHER_DGRAD || a.g.stride != 1))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: fused BatchNorm-backward statistics need a stride-1 dgrad");
   const bool wide = (a.Cout % 128 == 0) && vfs_option_igemm_bc != 64;

@@ -23,6 +23,7 @@ struct ConvGeom {
   int KH, KW, stride, pad;
   int Ktot;         // GEMM K (multiple of 64)
   int M;            // N*Ho*Wo
+  int dil = 1;      // tap spacing (forward gather of the implicit-GEMM kernel only: frozen dilated backbones)
 };
 
 // BatchNorm-backward statistics fused into the epilogue of the dgrad that PRODUCES the gradient g (the

@@ -27,16 +27,17 @@ KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's L
 class ConvUnit:
     """Host state of one conv / linear layer (+ its BatchNorm)."""
 
-    def __init__(self, name, weight, bias, bn, k, stride, pad, kind='conv'):
+    def __init__(self, name, weight, bias, bn, k, stride, pad, kind='conv', dil=1):
         self.name, self.weight, self.bias, self.bn = name, weight, bias, bn
-        self.k, self.stride, self.pad, self.kind = k, stride, pad, kind
+        self.k, self.stride, self.pad, self.kind, self.dil = k, stride, pad, kind, dil
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.wf = self.wd = None
         self.bnp = self.sums = self.bsums = None
         self.need_wd = True
 
     def out_hw(self, H, W):
-        return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+        span = self.dil * (self.k - 1) + 1
+        return (H + 2 * self.pad - span) // self.stride + 1, (W + 2 * self.pad - span) // self.stride + 1
 
 
 class Engine:
@@ -181,7 +182,8 @@ class Engine:
         mpg = Ng * Ho * Wo
         # statistics rows per group when ONE launch covers all groups (spatial tiles of the halo kernels, ragged
         # edges included, or linear 128-pixel blocks), else one launch per group
-        rows = None if u.kind == 'stem' else conv_stats_rows(N, G, H, W, u.cin, u.cout, u.k, u.stride, u.pad, Ho, Wo)
+        rows = None if u.kind == 'stem' else conv_stats_rows(N, G, H, W, u.cin, u.cout, u.k, u.stride, u.pad, Ho, Wo,
+                                                             halo=u.dil == 1)
         fused = rows is not None
         nblk_g = rows if fused else (mpg + 127) // 128
         if u.kind == 'stem':      # the stem kernel emits one statistics row per 8x16 spatial tile
@@ -209,6 +211,11 @@ class Engine:
                                           2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd_bnin,
                            x, in_bn[0], in_bn[1], u.wf, y, bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
                            u.k, u.k, u.stride, u.pad, s)
+            elif u.dil != 1:            # dilated taps: implicit-GEMM forward only (frozen backbones)
+                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
+                                          2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev,
+                           lib.conv_fwd_dilated, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
+                           u.k, u.k, u.stride, u.pad, u.dil, s)
             else:
                 ks, ksws = igemm_ksplit(nn_ * Ho * Wo, u.cout, u.k * u.k * u.cin) if (u.k == 1 and KSPLIT) else (1, 0)
                 work = (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
@@ -254,7 +261,7 @@ class Engine:
 
     def can_fold_input_bn(self, u, N, G, H, W, train):
         """may conv unit u read the raw output of its producer (BatchNorm + ReLU folded into the load)?"""
-        if os.environ.get('VFS_BNACT_FUSE', '1') != '1' or u.kind == 'stem':
+        if os.environ.get('VFS_BNACT_FUSE', '1') != '1' or u.kind == 'stem' or u.dil != 1:
             return False
         # pays only where the saved activation pass is large: the fold costs VALU work in the staging of
         # the consumer's forward and weight-gradient kernels (measured: + on ResNet-18's wide early layers,
@@ -419,6 +426,9 @@ class Engine:
         s = self.stream(dev)
         lib = self.lib
         M = N * Ho * Wo
+        if u.dil != 1:
+            raise NotImplementedError(f'{u.name}: dilated convolutions are forward-only here (the SiamFC probe freezes its '
+                                      'dilated backbone: frozen_stages=4, norm_eval=True)')
         if u.kind == 'stem':
             nsplit, pps = wgrad_splits(M, 64, 256)
             partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)

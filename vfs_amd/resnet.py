@@ -21,9 +21,9 @@ def _kaiming_fan_out_relu_(w):
 class ConvBN(nn.Module):
     """Parameter container with mmcv ConvModule's sub-module names (conv, bn)."""
 
-    def __init__(self, cin, cout, k, stride, pad, norm_cfg, relu):
+    def __init__(self, cin, cout, k, stride, pad, norm_cfg, relu, dilation=1):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dilation, bias=False)
         ntype = norm_cfg.get('type', 'BN')
         if ntype not in ('BN', 'BN2d', 'SyncBN'):
             raise KeyError(f'unsupported norm type {ntype}')
@@ -59,17 +59,17 @@ class _Block(nn.Module):
 class BasicBlock(_Block):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride, downsample, norm_cfg):
-        super().__init__([ConvBN(inplanes, planes, 3, stride, 1, norm_cfg, True),
+    def __init__(self, inplanes, planes, stride, downsample, norm_cfg, dilation=1):
+        super().__init__([ConvBN(inplanes, planes, 3, stride, dilation, norm_cfg, True, dilation),   # resnet.py:51-58
                           ConvBN(planes, planes, 3, 1, 1, norm_cfg, False)], downsample)
 
 
 class Bottleneck(_Block):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride, downsample, norm_cfg):
+    def __init__(self, inplanes, planes, stride, downsample, norm_cfg, dilation=1):
         super().__init__([ConvBN(inplanes, planes, 1, 1, 0, norm_cfg, True),
-                          ConvBN(planes, planes, 3, stride, 1, norm_cfg, True),     # style='pytorch'
+                          ConvBN(planes, planes, 3, stride, dilation, norm_cfg, True, dilation),     # style='pytorch', resnet.py:172-179
                           ConvBN(planes, planes * 4, 1, 1, 0, norm_cfg, False)], downsample)
 
 
@@ -90,8 +90,8 @@ class ResNet(nn.Module):
         assert 1 <= num_stages <= 4
         assert len(strides) == len(dilations) == num_stages
         assert max(out_indices) < num_stages
-        if in_channels != 3 or style != 'pytorch' or any(d != 1 for d in dilations):
-            raise NotImplementedError('HIP path covers in_channels=3, style=pytorch, dilation 1')
+        if in_channels != 3 or style != 'pytorch':
+            raise NotImplementedError('HIP path covers in_channels=3, style=pytorch')
         self.depth, self.pretrained, self.torchvision_pretrain = depth, pretrained, torchvision_pretrain
         self.in_channels, self.num_stages = in_channels, num_stages
         self.strides, self.dilations = tuple(strides), tuple(dilations)
@@ -111,9 +111,10 @@ class ResNet(nn.Module):
             down = None
             if stride != 1 or inplanes != planes * self.block.expansion:
                 down = ConvBN(inplanes, planes * self.block.expansion, 1, stride, 0, norm_cfg, False)
-            blocks = [self.block(inplanes, planes, stride, down, norm_cfg)]
+            dil = dilations[i]          # make_res_layer (resnet.py:279-300): the first block of a dilated stage gets dil // 2
+            blocks = [self.block(inplanes, planes, stride, down, norm_cfg, dil if dil == 1 else dil // 2)]
             inplanes = planes * self.block.expansion
-            blocks += [self.block(inplanes, planes, 1, None, norm_cfg) for _ in range(1, nb)]
+            blocks += [self.block(inplanes, planes, 1, None, norm_cfg, dil) for _ in range(1, nb)]
             self.add_module(f'layer{i + 1}', nn.Sequential(*blocks))
             self.res_layers.append(f'layer{i + 1}')
         self.feat_dim = self.block.expansion * 64 * 2 ** (len(self.stage_blocks) - 1)
@@ -226,7 +227,7 @@ class ResNet(nn.Module):
         for name, m in self.conv_modules():
             k = m.conv.kernel_size[0]
             u = ConvUnit(f'{prefix}.{name}', m.conv.weight, None, m.bn, k, m.conv.stride[0], m.conv.padding[0],
-                         'stem' if name == 'conv1' else 'conv')
+                         'stem' if name == 'conv1' else 'conv', dil=m.conv.dilation[0])
             u.need_wd = name != 'conv1'
             m.unit = engine.register(u)
         self._engine = engine
