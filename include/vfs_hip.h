@@ -258,6 +258,12 @@ int vfs_crop_resize_flip_norm(const uint8_t* src, const int* boxes, const uint8_
                               double mean_g, double mean_b, double std_r, double std_g, double std_b,
                               vfs_stream_t stream);
 
+/* ---- SiamFC probe head (projects/siamfc-pytorch/siamfc/heads.py:16-23,51-58 `_fast_xcorr`): response maps
+ * out[m][i][j] = scale * sum_{u,v,c} z[m % nz][u][v][c] * x[m][i+u][j+v][c]; z bf16 [nz][Hz][Wz][C], x bf16 [nx][H][W][C] (NHWC),
+ * out fp32 [nx][H-Hz+1][W-Wz+1]; nx % nz == 0, C % 8 == 0.  Forward only (inference of a trained probe). */
+int vfs_xcorr_fwd(const vfs_bf16* z, const vfs_bf16* x, float* out, int nz, int nx, int Hz, int Wz, int H, int W, int C,
+                  float scale, vfs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,6 +343,13 @@ int vfs_cosine_loss_fwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
   a.weight = weight;
   return vfs_cosine_loss_fwd_launch(a, S(stream));
 }
+int vfs_xcorr_fwd(const vfs_bf16* z, const vfs_bf16* x, float* out, int nz, int nx, int Hz, int Wz, int H, int W, int C, float scale,
+                  vfs_stream_t stream) {
+  if (!z || !x || !out) return vfs_set_error(VFS_ERR_ARG, "xcorr_fwd: null buffer");
+  XcorrArgs a;
+  a.z = z; a.x = x; a.out = out; a.nz = nz; a.nx = nx; a.Hz = Hz; a.Wz = Wz; a.H = H; a.W = W; a.C = C; a.scale = scale;
+  return vfs_xcorr_fwd_launch(a, S(stream));
+}
 int vfs_loss_means(const float* loss, float* means, int K, int N, vfs_stream_t stream) {
   if (!loss || !means) return vfs_set_error(VFS_ERR_ARG, "loss_means: null buffer");
   return vfs_loss_means_launch(loss, means, K, N, S(stream));

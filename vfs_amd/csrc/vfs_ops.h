@@ -146,6 +146,15 @@ struct LossArgs {
 };
 int vfs_bn_stats_raw_launch(const bf16_t* x, double* sums, int G, int rows, int C, const float* gamma, const float* beta, float* bnp,
                             float* rm, float* rv, double count, float eps, float momentum, hipStream_t s);
+// SiamFC cross-correlation (xcorr.hip)
+struct XcorrArgs {
+  const bf16_t* z;   // [nz][Hz][Wz][C] exemplar features
+  const bf16_t* x;   // [nx][H][W][C] search features
+  float* out;        // [nx][H-Hz+1][W-Wz+1]
+  int nz, nx, Hz, Wz, H, W, C;
+  float scale;
+};
+int vfs_xcorr_fwd_launch(const XcorrArgs& a, hipStream_t s);
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
 int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s);
 int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s);
