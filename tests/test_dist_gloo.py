@@ -70,12 +70,12 @@ def _run_ranks(tmp_path, tag, extra_env):
 
 
 def test_command_tape_replay_equals_eager_with_collectives(tmp_path):
-    """3 data-parallel steps on 2 gloo ranks: step 1 eager, step 2 recorded, step 3 replayed from the command tapes
+    """4 data-parallel steps on 2 gloo ranks: step 1 eager, step 2 recorded, steps 3-4 replayed from the command tapes
     (C-ABI calls + SyncBN / gradient all-reduces) must equal the plain eager run bit for bit"""
     from tests.emu_util import emu_lib
     emu_lib()
-    tape = _run_ranks(tmp_path, 'tape', dict(VFS_TEST_STEPS='3', VFS_TAPE='1'))
-    eager = _run_ranks(tmp_path, 'eager', dict(VFS_TEST_STEPS='3', VFS_TAPE='0'))
+    tape = _run_ranks(tmp_path, 'tape', dict(VFS_TEST_STEPS='4', VFS_TAPE='1'))
+    eager = _run_ranks(tmp_path, 'eager', dict(VFS_TEST_STEPS='4', VFS_TAPE='0'))
     for k in eager[0].files:
         assert np.array_equal(tape[0][k], eager[0][k]), k
         if k.startswith(('param/', 'grad/', 'buf/')):
