@@ -119,3 +119,25 @@ def test_torchvision_checkpoint_key_mapping(tmp_path):
     assert torch.equal(net2.layer2[0].downsample.conv.weight, tv['layer2.0.downsample.0.weight'])
     assert torch.equal(net2.layer3[1].conv2.bn.running_var, tv['layer3.1.bn2.running_var'])
     assert torch.equal(net2.conv1.conv.weight, tv['conv1.weight'])
+
+
+def test_command_tape_records_and_checks_return_codes():
+    """_lib.Tape / TapeLib: calls are recorded with converted arguments, replayed in order, and a failing entry point
+    raises both while recording and on replay (host logic only: vfs_set_option launches nothing)"""
+    from vfs_amd._lib import Tape, TapeLib, VfsError, get_lib
+    lib = get_lib()
+    tape = Tape(lib)
+    rec = TapeLib(lib, tape)
+    seen = []
+    rec.set_option(b'halo', 1)
+    tape.ops.append((None, seen.append, ('py',)))          # a Python-side action between two C calls
+    rec.set_option(b'bn_ticket', 1)
+    assert [op[0] for op in tape.ops] == ['set_option', None, 'set_option'] and tape.ops[0][2] == (b'halo', 1)
+    tape.replay()
+    assert seen == ['py']
+    with pytest.raises(VfsError):
+        rec.set_option(b'no_such_option', 1)
+    with pytest.raises(VfsError):
+        tape.replay()                                       # the failing call was recorded too
+    with pytest.raises(AttributeError):
+        rec.no_such_entry_point

@@ -168,3 +168,23 @@ def test_pipeline_feeds_train_step(gpu_backend):
     assert np.isfinite(res['log_vars']['loss']) and res['num_samples'] == B
     res2 = model.train_step(dict(imgs=torch.from_numpy(want).to(gpu_backend.dev), label=torch.zeros(B, 1)), None)
     assert res2['log_vars'].keys() == res['log_vars'].keys()
+
+
+def test_pipeline_config_errors_and_clip_layout():
+    from vfs_amd.pipeline import clips_from_pipeline
+    base = [dict(type='SampleFrames', clip_len=1, num_clips=8), dict(type='Clip2Frame', clip_len=4),
+            dict(type='Resize', scale=(32, 24), keep_ratio=False), dict(type='Normalize', mean=MEAN, std=STD, to_bgr=False)]
+    assert clips_from_pipeline(base) == (2, 4)
+    assert clips_from_pipeline([dict(type='SampleFrames', clip_len=3, num_clips=2)]) == (2, 3)
+    with pytest.raises(ValueError):
+        clips_from_pipeline([dict(type='Resize', scale=(8, 8))])
+    pipe = GpuTrainPipeline(base)
+    assert pipe.out_hw == (24, 32) and pipe.crop is None and pipe.flip is None
+    boxes, flips = pipe.sample(8, (50, 70))          # no crop / flip steps: full frames, never flipped
+    assert boxes.tolist() == [[0, 0, 70, 50]] * 8 and not flips.any()
+    for bad in (dict(type='ColorJitter'), dict(type='Resize', scale=(8, 8)), dict(type='Flip', direction='vertical'),
+                dict(type='Normalize', mean=MEAN, std=STD, to_bgr=True), dict(type='FormatShape', input_format='NCHW')):
+        with pytest.raises(NotImplementedError):
+            GpuTrainPipeline(base + [bad])
+    with pytest.raises(ValueError):
+        GpuTrainPipeline([dict(type='SampleFrames', clip_len=1, num_clips=2)])     # no Resize / Normalize
