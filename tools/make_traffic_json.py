@@ -8,14 +8,38 @@ import json
 import os
 import sys
 
-CLASSES = {   # bench.py's Engine.timed() classes -> kernels launched under them
-    'conv_igemm': ('conv3x3_halo_kernel', 'conv_igemm_kernel', 'stem_fwd_direct_kernel'),
-    'conv_wgrad': ('conv3x3_wgrad_halo_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_kernel', 'stem_wgrad_fused_kernel'),
+CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels launched under them
+    'conv_igemm': ('conv_igemm_kernel',),
+    'conv3x3_halo': ('conv3x3_halo_kernel',),
+    'stem_fwd': ('stem_fwd_direct_kernel',),
+    'conv_wgrad': ('conv_wgrad_kernel',),          # (the wgrad_reduce launch that follows every weight gradient is not attributed)
+    'conv3x3_wgrad_halo': ('conv3x3_wgrad_halo_kernel',),
+    'stem_wgrad': ('stem_wgrad_fused_kernel',),
 }
-NOT_A_LAUNCH = ('wgrad_reduce_kernel',)   # second kernel of one conv_wgrad call
+NOT_A_LAUNCH = ()
+
+
+def aggregate(kernels):
+    classes = {}
+    for cls, names in CLASSES.items():
+        tot, launches = 0.0, 0
+        for k, v in kernels.items():
+            if any(n in k for n in names):
+                tot += (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) * v['calls']
+                launches += v['calls']
+        if launches:
+            classes[cls] = {'launches': launches, 'hbm_bytes_per_launch': tot / launches}
+    return classes
 
 
 def main():
+    if sys.argv[1] == '--reaggregate':      # recompute the class table of existing files from their per-kernel entries
+        for path in sys.argv[2:]:
+            d = json.load(open(path))
+            d['classes'] = aggregate(d['kernels'])
+            json.dump(d, open(path, 'w'), indent=1)
+            print(path, json.dumps(d['classes']))
+        return
     model, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'r01')
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     raw = json.load(open(os.path.join(repo, 'gpurun_out', f'pmc_{model}.json')))
@@ -24,16 +48,7 @@ def main():
         w = raw.get('WRITE_SIZE', {}).get(name, {'sum': 0.0, 'calls': v['calls']})
         kernels[name] = {'calls': v['calls'], 'fetch_bytes_per_launch': 2.0 * v['sum'] * 1024 / v['calls'],
                          'write_bytes_per_launch': w['sum'] * 1024 / max(w['calls'], 1)}
-    classes = {}
-    for cls, names in CLASSES.items():
-        tot, launches = 0.0, 0
-        for k, v in kernels.items():
-            if any(n in k for n in names):
-                tot += (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) * v['calls']
-                if not any(n in k for n in NOT_A_LAUNCH):
-                    launches += v['calls']
-        if launches:
-            classes[cls] = {'launches': launches, 'hbm_bytes_per_launch': tot / launches}
+    classes = aggregate(kernels)
     out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on '
                      f'`VFS_GRAPHS=0 VFS_SIDE_STREAM=0 bench.py --model {model} --steps 3 --warmup 1` (tools/gpu_pmc.sh); '
                      'counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)',

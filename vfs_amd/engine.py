@@ -15,7 +15,8 @@ import torch
 import torch.distributed as dist
 
 from ._lib import Tape, TapeLib, get_lib
-from .packing import igemm_ksplit, bn_fold_eligible, build_pack_table, conv_stats_rows, wgrad_halo_eligible, wgrad_splits
+from .packing import (igemm_ksplit, bn_fold_eligible, build_pack_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible,
+                      wgrad_splits)
 
 BF16 = torch.bfloat16
 
@@ -105,6 +106,15 @@ class Engine:
             t = torch.empty(int(numel), dtype=dtype, device=dev)
             self.bufs[key] = t
         return t
+
+    @staticmethod
+    def conv_kind(u, N, H, W, dgrad=False):
+        """kernel family a forward / dgrad launch of unit u lands in (bench.py's per-kernel roofline classes; mirrors the
+        dispatch of csrc/conv_igemm.hip): stem_fwd | conv3x3_halo | conv_igemm"""
+        if u.kind == 'stem':
+            return 'stem_fwd'
+        cin, cout = (u.cout, u.cin) if dgrad else (u.cin, u.cout)
+        return 'conv3x3_halo' if (u.dil == 1 and conv_halo_eligible(N, H, W, cin, cout, u.k, u.stride, u.pad)) else 'conv_igemm'
 
     def timed(self, kind, work, dev, fn, *args):
         """launch through `fn`; with profiling on, bracket it with events on the launch stream.
@@ -203,12 +213,12 @@ class Engine:
             (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_rows else None) for g in range(G)]
         for n0, nn_, part in groups:
             if u.kind == 'stem':
-                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * 64 * 147, 2.0 * nn_ * (H * W * 4 + Ho * Wo * 64)), dev, lib.stem_fwd,
+                self.timed('stem_fwd', (2.0 * nn_ * Ho * Wo * 64 * 147, 2.0 * nn_ * (H * W * 4 + Ho * Wo * 64)), dev, lib.stem_fwd,
                            x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
             elif in_bn is not None:     # x is the producer's RAW output: BatchNorm + ReLU folded into the operand load
                 assert (n0, nn_) == (0, N), 'folded input BatchNorm needs the single-launch (fused statistics) path'
-                self.timed('conv_igemm', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
-                                          2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd_bnin,
+                self.timed('conv3x3_halo', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
+                                            2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd_bnin,
                            x, in_bn[0], in_bn[1], u.wf, y, bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
                            u.k, u.k, u.stride, u.pad, s)
             elif u.dil != 1:            # dilated taps: implicit-GEMM forward only (frozen backbones)
@@ -224,7 +234,7 @@ class Engine:
                     self.timed('conv_igemm', work, dev, lib.conv_fwd_splitk, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
                                self.ksplit_ws(ksws, dev), ks, nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
                 else:
-                    self.timed('conv_igemm', work, dev, lib.conv_fwd, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
+                    self.timed(self.conv_kind(u, nn_, H, W), work, dev, lib.conv_fwd, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
                                nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
         if u.bn is not None:
             bn = u.bn
@@ -411,7 +421,7 @@ class Engine:
         nblocks = (ntiles + tpb - 1) // tpb
         partial = self.ws('ws.wgrad', nblocks * 64 * 224, torch.float32, dev)
         with self.on_side_stream(dev):      # ws.wgrad belongs to the side stream
-            self.timed('conv_wgrad', (2.0 * N * H * W * 64 * 147,
+            self.timed('stem_wgrad', (2.0 * N * H * W * 64 * 147,
                                       2.0 * N * (Hin * Win * 4 + H * W * 64) + 5.0 * N * Hp * Wp * 64 + 8.0 * nblocks * 64 * 224),
                        dev, self.lib.stem_wgrad_fused,
                        x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
@@ -433,7 +443,7 @@ class Engine:
             nsplit, pps = wgrad_splits(M, 64, 256)
             partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)
             with self.on_side_stream(dev):
-                self.timed('conv_wgrad', (2.0 * M * 64 * 147, 2.0 * (M * 64 + N * H * W * 4) + 8.0 * nsplit * 64 * 256), dev, lib.stem_wgrad,
+                self.timed('stem_wgrad', (2.0 * M * 64 * 147, 2.0 * (M * 64 + N * H * W * 4) + 8.0 * nsplit * 64 * 256), dev, lib.stem_wgrad,
                            dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, self.stream(dev))
             return None
         ktot = u.k * u.k * u.cin
@@ -450,10 +460,10 @@ class Engine:
         with self.on_side_stream(dev):
             ss = self.stream(dev)
             if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
-                self.timed('conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
+                self.timed('conv3x3_wgrad_halo', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
                            u.weight.grad, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             else:
-                self.timed('conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
+                self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
                            Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             if u.bias is not None:
                 lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)
@@ -471,7 +481,7 @@ class Engine:
             if rows is not None:
                 nblk = rows * G
                 partial = self.ws('ws.bnbwd_fused', nblk * 2 * u.cin, torch.float32, dev)
-                self.timed('conv_igemm', (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + (1 if pymask is not None else 0))),
+                self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + (1 if pymask is not None else 0))),
                            dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,
                            mpg, 1 if (prelu and pymask is None) else 0, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k,
                            u.stride, u.pad, s)
@@ -482,7 +492,7 @@ class Engine:
             self.timed('conv_igemm', work, dev, lib.conv_dgrad_splitk, dx, u.wd, gin, add, self.ksplit_ws(ksws, dev), ks, N, H, W, u.cin,
                        Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
         else:
-            self.timed('conv_igemm', work, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
+            self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), work, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
                        u.k, u.k, u.stride, u.pad, s)
         return gin
 
