@@ -327,3 +327,82 @@ def test_dilated_frozen_backbone_matches_oracle(backend, depth):
     assert u.dil == 4
     with pytest.raises(NotImplementedError):
         backend.eng.conv_bwd(u, got, got, 1, 1, 1, 1, 1, True)
+
+
+def _full_size_properties(dev, cfg_name, shape, nsteps=2, check_replay=True, shallow=False):
+    """size-independent properties of the train step (used at the BASELINE size on the GPU, at a toy size on the emulator):
+    * the replayed step equals the eager step bit for bit (loss, every parameter after SGD);
+    * backward is linear in the incoming gradient: gradients of 2*loss are exactly 2x the gradients of loss
+      (a power-of-two scale is exact in bf16 and fp32);
+    * permuting the videos of the batch leaves the loss unchanged up to the summation order."""
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', cfg_name))
+    mcfg = dict(cfg.model)
+    if shallow:          # one block per stage: the emulator is slow
+        mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE)
+        mcfg['img_head'] = dict(mcfg['img_head'], **SHALLOW_HEAD)
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(*shape, generator=g).to(dev)
+
+    def fresh():
+        torch.manual_seed(0)
+        m = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev).train()
+        return m, vfs_amd.build_optimizer(m, cfg.optimizer)
+
+    def run(model, opt, batch, steps, scale=1.0, do_step=True):
+        losses = []
+        for _ in range(steps):
+            out = model.train_step(dict(imgs=batch, label=torch.zeros(shape[0], 1)), opt)
+            opt.zero_grad()
+            (out['loss'] * scale).backward()
+            if do_step:
+                opt.step()
+            losses.append(out['log_vars']['loss'])
+        return losses
+
+    # replay == eager
+    l1 = None
+    if check_replay:
+        os.environ['VFS_TAPE'] = '1'
+        m1, o1 = fresh()
+        l1 = run(m1, o1, imgs, nsteps + 2)
+        os.environ['VFS_TAPE'] = '0'
+        try:
+            m2, o2 = fresh()
+            l2 = run(m2, o2, imgs, nsteps + 2)
+        finally:
+            os.environ['VFS_TAPE'] = '1'
+        assert l1 == l2, (l1, l2)
+        for (k, a), b in zip(m1.state_dict().items(), m2.state_dict().values()):
+            assert torch.equal(a, b), k
+    # linearity in the incoming gradient
+    m3, o3 = fresh()
+    run(m3, o3, imgs, 1, scale=1.0, do_step=False)
+    g1 = {n: p.grad.clone() for n, p in m3.named_parameters()}
+    m4, o4 = fresh()
+    run(m4, o4, imgs, 1, scale=2.0, do_step=False)
+    for n, p in m4.named_parameters():
+        assert torch.equal(p.grad, 2.0 * g1[n]), n
+    # permutation of the videos
+    perm = torch.randperm(shape[0], generator=g).to(dev)
+    m5, o5 = fresh()
+    lp = run(m5, o5, imgs[perm].contiguous(), 1, do_step=False)
+    l0 = run(*fresh(), imgs, 1, do_step=False)
+    assert abs(lp[0] - l0[0]) <= 2e-3 * abs(l0[0]), (lp, l0)
+    # (per-parameter gradients are NOT compared under the permutation: at initialisation, with the zero-initialised last
+    # BatchNorm of every block, many of them are sums that cancel to rounding noise, and bf16 storage makes that noise
+    # order-dependent - measured at the BASELINE size: up to 0.56 relative difference on such tensors while the loss agrees)
+    return l1
+
+
+def test_train_step_properties_toy_size(backend):
+    if backend.name == 'gpu':
+        pytest.skip('the GPU runs the BASELINE size (test_train_step_properties_at_baseline_size)')
+    # (replay == eager is covered on the emulator by the 2-rank tape test and on the GPU by test_graph_replay_equals_eager)
+    _full_size_properties(backend.dev, 'vfs_r18.py', [2, 2, 3, 1, 32, 32], nsteps=1, check_replay=False, shallow=True)
+
+
+@pytest.mark.gpu
+def test_train_step_properties_at_baseline_size(gpu_backend):
+    """BASELINE.json configs[2]: ResNet-50, imgs [32,2,3,1,256,256]"""
+    _full_size_properties(gpu_backend.dev, 'vfs_r50.py', [32, 2, 3, 1, 256, 256])
