@@ -354,3 +354,28 @@ def test_dilated_forward_conv(backend, N, H, W, Cin, Cout, stride, dil):
     assert relerr(nchw(y.cpu()), ref) < 6e-3
     with pytest.raises(Exception):      # the output size must follow the dilated formula
         lib.conv_fwd_dilated(d(nhwc(x)), wf, y, None, None, N, H, W, Cin, Ho + 1, Wo, Cout, 3, 3, stride, dil, dil, None)
+
+
+def _sweep_shapes(n, seed):
+    """pseudo-random conv problems around the dispatch boundaries (ragged tiles, 7/8/14-pixel maps, odd batch sizes,
+    64/128/192 channels, 1x1 and 3x3, stride 1 and 2); fixed seed, so the set is reproducible"""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    while len(out) < n:
+        k = rnd.choice([1, 3, 3])
+        stride = rnd.choice([1, 1, 2])
+        shape = (rnd.choice([1, 2, 3, 4]), rnd.choice([5, 7, 8, 9, 12, 14, 16, 20]), rnd.choice([6, 7, 8, 14, 16, 17, 24, 28]),
+                 rnd.choice([64, 128]), rnd.choice([64, 128, 192]), k, stride, 1 if k == 3 else 0)
+        if shape not in out:
+            out.append(shape)
+    return out
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', _sweep_shapes(28, 20260927))
+def test_conv_shape_sweep(backend, N, H, W, Cin, Cout, k, stride, pad):
+    """forward (+ statistics rows), dgrad (+ residual add) and wgrad of every sampled problem vs torch: exercises the
+    host mirrors of the tiling rules (conv_halo_eligible / conv_stats_rows / wgrad_splits) together with the kernels"""
+    if backend.name == 'gpu':
+        pytest.skip('emulator-only this round: the sweep was added after the GPU budget was spent')
+    run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
