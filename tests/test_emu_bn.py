@@ -393,3 +393,57 @@ def test_bn_apply_with_inkernel_finalisation(backend, G, rows, C, ppr):
     assert torch.allclose(dga, dgb, rtol=1e-6, atol=1e-6) and torch.allclose(dba, dbb2, rtol=1e-6, atol=1e-6)
     assert torch.equal(ga, gb)
     assert (da - dbb).abs().max() <= 2 ** -7 * dbb.abs().max()
+
+
+def _bn_sweep(n, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    while len(out) < n:
+        G = rnd.choice([1, 2])
+        npg = rnd.choice([1, 2, 3])
+        case = (G, npg, rnd.choice([3, 5, 7, 8, 9, 14]), rnd.choice([4, 7, 8, 13, 16]), rnd.choice([8, 16, 32, 64, 128, 192]))
+        if case not in out:
+            out.append(case)
+    return out
+
+
+@pytest.mark.parametrize('G,npg,H,W,C', _bn_sweep(14, 7))
+def test_bn_shape_sweep(backend, G, npg, H, W, C):
+    """BatchNorm apply / backward over odd pixel counts and every supported channel width (slab geometry of bn.hip):
+    statistics from raw, bn_act (+ReLU), bn_bwd_reduce / apply with the mask recomputed from x, vs autograd per group"""
+    if backend.name == 'gpu':
+        pytest.skip('emulator-only this round: the sweep was added after the GPU budget was spent')
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(G * 1000 + H * 10 + C)
+    N = G * npg
+    M, mpg = N * H * W, npg * H * W
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.7 + 0.4)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    sums, bnp = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(G, 4, C)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xh = nhwc(x).to(torch.bfloat16)
+    lib.bn_stats_raw_finalize(xh, sums, gamma, beta, bnp, rm, rv, G, mpg, C, float(mpg), 1e-5, 0.1, None)
+    y = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.bn_act(xh, bnp, None, None, None, y, M, C, mpg, 1, None)
+    xs = x.clone().requires_grad_(True)
+    gm_, bt_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    outs = [F.relu(F.batch_norm(xs[i * npg:(i + 1) * npg], None, None, gm_, bt_, True, 0.1, 1e-5)) for i in range(G)]
+    ref = torch.cat(outs)
+    assert relerr(nchw(y), ref.detach()) < 6e-3
+    gout = rb(torch.randn(N, C, H, W, generator=g))
+    ref.backward(gout * (nchw(y) > 0))
+    import math
+    ppb = math.gcd(mpg, 512)
+    if ppb < 16:
+        ppb = mpg
+    nblk = M // ppb
+    partial = torch.zeros(nblk, 2, C)
+    gh = nhwc(gout).to(torch.bfloat16)
+    lib.bn_bwd_reduce(gh, y, xh, bnp, partial, M, C, mpg, ppb, 0, None)
+    bs = torch.zeros(G, 2, C, dtype=torch.float64)
+    dg, db = torch.zeros(C), torch.zeros(C)
+    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16)
+    lib.bn_bwd_apply_fin(gh, y, xh, bnp, partial, nblk // G, bs, dg, db, dx, None, M, C, mpg, float(mpg), 0, None)
+    assert relerr(nchw(dx), xs.grad) < 1e-2
+    assert relerr(dg, gm_.grad) < 2e-3 and relerr(db, bt_.grad) < 2e-3
