@@ -113,13 +113,18 @@ def _maxrel(a, b):
                                          # 16x16 feature maps in layer1: halo-tile kernels, folded input BatchNorm, fused dgrad statistics
                                          (18, [4, 2, 3, 2, 64, 64]),
                                          # 14x14 / 7x7 maps (the 224 x 224 crop of the shipped configs, scaled down): ragged halo tiles
-                                         (18, [2, 2, 3, 1, 56, 56])])
+                                         (18, [2, 2, 3, 1, 56, 56]),
+                                         # odd, non-square maps (10x14 ... 2x2): views that are not multiples of the 128-pixel
+                                         # statistics rows (one launch per view, statistics from the stored output)
+                                         (18, [8, 2, 3, 1, 40, 56])])
 def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monkeypatch):
     """Tight orchestration check without the chaos: run the fused step, then for the stem, every
     residual block, the head and the loss feed the ENGINE'S OWN input / incoming-gradient buffers
     to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
     and require outputs, input gradients and parameter gradients to agree to bf16 rounding."""
     import vfs_amd
+    if backend.name == 'gpu' and shape[-2:] == [40, 56]:
+        pytest.skip('emulator-only this round: this case was added after the GPU budget was spent')
     monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)
     eng = backend.eng
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
