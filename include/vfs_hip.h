@@ -31,6 +31,7 @@ int vfs_abi_version(void);
  * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default), "bn_ticket",
  * "igemm_onek" (single-buffer implicit-GEMM variant: 0 never, 1 one-K-step problems, 2 every 1x1 (default), 3 all),
  * "igemm_ring_tiles" (1x1 problems with at most this many tiles use the LDS-DMA ring, default 512, 0 = off),
+ * "igemm_ring_upfront" (ring variant: all fragment reads of a K-step before its MFMAs; default 0, not yet measured),
  * "igemm_bc" (64 forces the 64-channel tile) */
 int vfs_set_option(const char* name, int value);
 

@@ -379,3 +379,28 @@ def test_conv_shape_sweep(backend, N, H, W, Cin, Cout, k, stride, pad):
     if backend.name == 'gpu':
         pytest.skip('emulator-only this round: the sweep was added after the GPU budget was spent')
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
+
+
+def test_ring_upfront_reads_bit_identical(backend):
+    """option igemm_ring_upfront (all fragment reads of a K-step before its MFMAs; prepared for the next round, off by
+    default): same MFMA order, so the outputs must be bit-identical to the default schedule"""
+    if backend.name == 'gpu':
+        pytest.skip('emulator-only this round: added after the GPU budget was spent')
+    lib, d = backend.lib, backend.d
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = 2, 8, 8, 512, 256
+    x = d(nhwc(rb(torch.randn(N, Cin, H, W, generator=g))))
+    w = rb(torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wf, wd = pack(backend, w)
+    outs = []
+    for flag in (0, 1):
+        lib.set_option(b'igemm_ring_upfront', flag)
+        try:
+            y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=backend.dev)
+            st = torch.full((1, 2, Cout), float('nan'), device=backend.dev)
+            lib.conv_fwd(x, wf, y, None, st, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, None)
+            outs.append((y.cpu(), st.cpu()))
+        finally:
+            lib.set_option(b'igemm_ring_upfront', 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert relerr(nchw(outs[1][0]), F.conv2d(nchw(x.cpu()), w)) < 6e-3

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
       const int nst = st == 0 ? PIPE - 1 : st - 1;   // the stage step kt - 1 used
       if (kt + PIPE - 1 < kend) issue(kt + PIPE - 1, nst);
       __builtin_amdgcn_sched_barrier(0);
-      mma_kstep<TM, TN, false>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
+      if (a.ring_upfront) mma_kstep_upfront<TM, TN>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
+      else mma_kstep<TM, TN, false>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
       __builtin_amdgcn_sched_barrier(0);
       st = st == PIPE - 1 ? 0 : st + 1;
     }
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
 
 // ------------------------------------------------------------------ host launcher
 int vfs_option_igemm_bc = 0;     // 64: force the 64-channel tile (A/B knob)
+int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a K-step before its MFMAs (prepared, not yet measured)
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
 int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
 
@@ -464,8 +466,10 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
                     a.g.Ktot >= 256 && tiles <= vfs_option_igemm_ring_tiles && !a.bn.partial &&
                     (mode == GATHER_FWD || mode == GATHER_DGRAD);
   if (ring) {
-    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(a, stream) : launch_igemm<64, GATHER_FWD, 3>(a, stream);
-    return wide ? launch_igemm<128, GATHER_DGRAD, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3>(a, stream);
+    ConvArgs b = a;
+    b.ring_upfront = vfs_option_igemm_ring_upfront;
+    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(b, stream) : launch_igemm<64, GATHER_FWD, 3>(b, stream);
+    return wide ? launch_igemm<128, GATHER_DGRAD, 3>(b, stream) : launch_igemm<64, GATHER_DGRAD, 3>(b, stream);
   }
   switch (mode) {
     case GATHER_FWD:

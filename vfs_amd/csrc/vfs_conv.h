@@ -61,6 +61,7 @@ struct ConvArgs {
   // partials in slice order (deterministic) and runs the epilogue.
   float* ks_ws = nullptr;
   int ksplit = 1;
+  int ring_upfront = 0;   // DMA-ring variant: mma_kstep_upfront (set by the dispatcher from vfs_option_igemm_ring_upfront)
 };
 #define KS_TICKETS 1024
 
@@ -242,6 +243,32 @@ __device__ __forceinline__ void bnfuse_spill(const BnFuseLane& L, float* sB, int
   *reinterpret_cast<f32x4*>(d + 4) = (f32x4){L.s1[4], L.s1[5], L.s1[6], L.s1[7]};
   *reinterpret_cast<f32x4*>(d + wch) = (f32x4){L.s2[0], L.s2[1], L.s2[2], L.s2[3]};
   *reinterpret_cast<f32x4*>(d + wch + 4) = (f32x4){L.s2[4], L.s2[5], L.s2[6], L.s2[7]};
+}
+
+// The same K-step with ALL fragment reads (both 32-deep halves) issued before the first MFMA: the compiler's default
+// order re-uses a minimal set of fragment registers and so waits for an LDS round trip ~6 times per K-step - hidden by
+// other waves at 3-4 waves per SIMD, fully exposed in the one-workgroup-per-CU DMA-ring variant (ISA inspection,
+// tools: hipcc -S).  Costs 32 more VGPRs.  Same MFMA order, bit-identical results.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_kstep_upfront(const bf16_t* __restrict__ sA, const bf16_t* __restrict__ sB,
+                                                  int rowA0, int rowB0, int lane, f32x4 (&acc)[TM][TN]) {
+  const int lr = lane & 15, lq = lane >> 4;
+  bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) af[kk][tm] = *reinterpret_cast<const bf16x8*>(sA + lds_off(rowA0 + tm * 16 + lr, kk * 4 + lq));
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bfr[kk][tn] = *reinterpret_cast<const bf16x8*>(sB + lds_off(rowB0 + tn * 16 + lr, kk * 4 + lq));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][tm], bfr[kk][tn], acc[tm][tn], 0, 0, 0);
 }
 
 // one 64-deep K-step of MFMAs for a wave: acc[tm][tn] += A(rowsA + tm*16) x B(rowsB + tn*16)
