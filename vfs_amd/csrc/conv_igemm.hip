@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
   constexpr bool CAN_BN = FBN;
   // one arena [weight tiles | pixel tiles]; after the K loop the epilogue re-uses it as output stage
   constexpr int SROW = WC + 8;                    // staged pixel row: WC channels + 16 bytes of padding
-  constexpr int NBUF = PIPE >= 3 ? PIPE : (ONEK ? 1 : 2);
+  constexpr int NBUF = PIPE >= 3 ? 3 : (ONEK ? 1 : 2);     // PIPE 4 = PIPE 3 with mma_kstep_upfront
   constexpr int OPER = NBUF * (BC * 64 + BP * 64);
   constexpr int STAGE = 4 * 64 * SROW + (CAN_BN ? 4 * (64 / (WC / 8)) * 2 * WC * 2 : 0);   // + statistics rows (floats)
   constexpr int SMEM = OPER > STAGE ? OPER : STAGE;
@@ -221,22 +221,23 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
 #pragma unroll
       for (int q = 0; q < WQ; ++q) vfs_dma16_async(wrw, sW[st] + (wave_u * WQ + q) * 512, wvo[q], (unsigned)kt * 128u);
     };
+    constexpr int RING = 3;
 #pragma unroll
-    for (int d = 0; d < PIPE - 1; ++d)
+    for (int d = 0; d < RING - 1; ++d)
       if (kbeg + d < kend) issue(kbeg + d, d);
     int st = 0;
     for (int kt = kbeg; kt < kend; ++kt) {
       // this wave's pieces of step kt have landed: at most the pieces of the later steps already issued stay in flight
-      const int ahead = min(PIPE - 2, kend - 1 - kt);
+      const int ahead = min(RING - 2, kend - 1 - kt);
       if (ahead >= 2) vfs_dma_wait<2 * NPW>(); else if (ahead == 1) vfs_dma_wait<NPW>(); else vfs_dma_wait<0>();
       __syncthreads();                       // ... everybody's have, and everybody is done with step kt - 1
-      const int nst = st == 0 ? PIPE - 1 : st - 1;   // the stage step kt - 1 used
-      if (kt + PIPE - 1 < kend) issue(kt + PIPE - 1, nst);
+      const int nst = st == 0 ? RING - 1 : st - 1;   // the stage step kt - 1 used
+      if (kt + RING - 1 < kend) issue(kt + RING - 1, nst);
       __builtin_amdgcn_sched_barrier(0);
-      if (a.ring_upfront) mma_kstep_upfront<TM, TN>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
+      if (PIPE == 4) mma_kstep_upfront<TM, TN>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);     // opt-in schedule, own instantiation
       else mma_kstep<TM, TN, false>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
       __builtin_amdgcn_sched_barrier(0);
-      st = st == PIPE - 1 ? 0 : st + 1;
+      st = st == RING - 1 ? 0 : st + 1;
     }
     __syncthreads();                         // the epilogue re-uses the arena
   } else if (kend > kbeg) {
@@ -465,11 +466,13 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
   const bool ring = vfs_option_igemm_ring_tiles > 0 && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
                     a.g.Ktot >= 256 && tiles <= vfs_option_igemm_ring_tiles && !a.bn.partial &&
                     (mode == GATHER_FWD || mode == GATHER_DGRAD);
+  if (ring && vfs_option_igemm_ring_upfront) {
+    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 4>(a, stream) : launch_igemm<64, GATHER_FWD, 4>(a, stream);
+    return wide ? launch_igemm<128, GATHER_DGRAD, 4>(a, stream) : launch_igemm<64, GATHER_DGRAD, 4>(a, stream);
+  }
   if (ring) {
-    ConvArgs b = a;
-    b.ring_upfront = vfs_option_igemm_ring_upfront;
-    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(b, stream) : launch_igemm<64, GATHER_FWD, 3>(b, stream);
-    return wide ? launch_igemm<128, GATHER_DGRAD, 3>(b, stream) : launch_igemm<64, GATHER_DGRAD, 3>(b, stream);
+    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(a, stream) : launch_igemm<64, GATHER_FWD, 3>(a, stream);
+    return wide ? launch_igemm<128, GATHER_DGRAD, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3>(a, stream);
   }
   switch (mode) {
     case GATHER_FWD:

@@ -61,7 +61,6 @@ struct ConvArgs {
   // partials in slice order (deterministic) and runs the epilogue.
   float* ks_ws = nullptr;
   int ksplit = 1;
-  int ring_upfront = 0;   // DMA-ring variant: mma_kstep_upfront (set by the dispatcher from vfs_option_igemm_ring_upfront)
 };
 #define KS_TICKETS 1024
 
