@@ -376,16 +376,12 @@ def _sweep_shapes(n, seed):
 def test_conv_shape_sweep(backend, N, H, W, Cin, Cout, k, stride, pad):
     """forward (+ statistics rows), dgrad (+ residual add) and wgrad of every sampled problem vs torch: exercises the
     host mirrors of the tiling rules (conv_halo_eligible / conv_stats_rows / wgrad_splits) together with the kernels"""
-    if backend.name == 'gpu':
-        pytest.skip('emulator-only this round: the sweep was added after the GPU budget was spent')
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
 
 
 def test_ring_upfront_reads_bit_identical(backend):
     """option igemm_ring_upfront (all fragment reads of a K-step before its MFMAs; prepared for the next round, off by
     default): same MFMA order, so the outputs must be bit-identical to the default schedule"""
-    if backend.name == 'gpu':
-        pytest.skip('emulator-only this round: added after the GPU budget was spent')
     lib, d = backend.lib, backend.d
     g = torch.Generator().manual_seed(5)
     N, H, W, Cin, Cout = 2, 8, 8, 512, 256
