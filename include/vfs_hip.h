@@ -226,18 +226,54 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
 /* masked_attention_efficient (local_attention.py:237-348) + spatial_neighbor 'circle'
  * (affinity_utils.py:144-156): fbank [frames][H*W][C] normalised bf16, sbank [frames][H*W][CO]
  * fp32; key frames kslot[0..nkeys) in the reference's order (first frame first, duplicates
- * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), topk <= 10.
- * workspace: 24*H*W*10*8 bytes (per-split partial top-k lists: key frames are split over
- * workgroups because a DAVIS frame has only 8x14 query tiles) */
+ * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), the first non_mask_len
+ * key frames are never masked (test_cfg.with_first_neighbor=False -> 1), topk <= 10, nkeys <= 24,
+ * C % 64 == 0.  workspace: 24*H*W*10*8 bytes (per-split partial top-k lists: key frames are split
+ * over workgroups because a DAVIS frame has only 8x14 query tiles) */
 int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe,
-                  const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int topk,
-                  float temperature, vfs_stream_t stream);
+                  const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len,
+                  int topk, float temperature, vfs_stream_t stream);
 /* bilinear upsample (align_corners=False) + per-channel min-max normalisation where max > 0 +
  * argmax -> uint8 [Ho][Wo] (vanilla_tracker.py:162-181); partial: workspace float[64*CO*2] */
 int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho,
                         int Wo, vfs_stream_t stream);
 /* F.one_hot of the resized first-frame label map into the seg bank (vanilla_tracker.py:96-100) */
 int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t stream);
+
+/* ---- fp32 evaluation path ("exact" precision; csrc/exact_f32.hip) ------------------------------------
+ * The reference evaluates in fp32 and its outputs are INTEGER label maps, so the default forward_test path stores
+ * and computes in fp32 with bit-defined arithmetic: every dot product is one ascending chain acc = fma(a_k, b_k, acc)
+ * on v_mfma_f32_32x32x2_f32, every other step a single correctly rounded fp32 operation, exp() an explicit
+ * polynomial, top-k ties to the lowest candidate index.  oracle/exact_oracle.c states the same arithmetic in C and
+ * the results agree bit for bit (tests/test_exact_f32.py); the bf16 entry points above remain as the fast mode.
+ *
+ * mmcv ConvModule in eval mode (conv -> BN(running statistics) [-> + identity] [-> ReLU]; resnet.py:51-73,102-111,
+ * 163-191,221-230): y[N,Ho,Wo,Cout] = [relu]( fma(conv(x, w), scale, shift) [+ res] ), fp32 NHWC, w [Cout][KH][KW][Cin]
+ * (the chain runs kh, kw, cin ascending), Cin % 4 == 0 (3-channel frames as NHWC4 with zero weights on channel 3),
+ * scale/shift [Cout] or both NULL, any stride / padding / dilation */
+int vfs_conv_f32_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res, float* y,
+                     int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                     int dilation, int relu, vfs_stream_t stream);
+/* imgs fp32 [B][V][3][T][H][W] -> fp32 NHWC4 frames out[(v*B+b)*T+t][h][w][4], channel 3 = 0 (common/utils.py:45-53) */
+int vfs_imgs_to_nhwc4_f32(const float* imgs, float* out, int B, int V, int T, int H, int W, vfs_stream_t stream);
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:435), fp32 NHWC, C % 4 == 0 */
+int vfs_maxpool_f32(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, vfs_stream_t stream);
+/* F.normalize(dim=channel, eps=1e-12) of fp32 rows [P][C] (local_attention.py:277-279), C % 4 == 0 */
+int vfs_l2norm_rows_f32(const float* x, float* y, long long P, int C, vfs_stream_t stream);
+/* vfs_labelprop on an fp32 bank: score = chain(key . query) / temperature, top-k by (score desc, candidate id asc) with
+ * id = key_position * H*W + pixel, softmax weights exp(s - s_max) / sum in sorted order; the first non_mask_len key
+ * frames are not masked (test_cfg.with_first_neighbor=False -> 1, local_attention.py:303-309); workspace as vfs_labelprop */
+int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot,
+                      int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature,
+                      vfs_stream_t stream);
+/* F.interpolate(mode='bilinear', align_corners=False) of a C-channel fp32 map between layouts (NCHW [C][H][W] or NHWC
+ * [H][W][C], chosen per side): one-hot reference maps -> feature resolution, soft label maps -> original resolution
+ * (vanilla_tracker.py:101-111,162-166 when ref_seg_map is 4-D) */
+int vfs_bilinear_resize_f32(const float* src, float* dst, int C, int H, int W, int Ho, int Wo, int src_nhwc, int dst_nhwc,
+                            vfs_stream_t stream);
+/* vfs_seg_postprocess with every step a single fp32 operation (no contraction) */
+int vfs_seg_postprocess_exact(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
+                              vfs_stream_t stream);
 
 /* ---- DAVIS-2017 semi-supervised J&F (datasets/davis_dataset.py:68-140 -> davis2017.evaluation) -----
  * pred / gt: uint8 label maps [T][H][W]; frames 1..T-2 are evaluated (first = given, last excluded);

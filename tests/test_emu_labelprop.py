@@ -31,7 +31,7 @@ def run_labelprop_case(be, T, H, W, C, CO, radius, slots, qframe, topk=10, seed=
     out = torch.full((H * W, CO), float('nan'))
     ks = (ctypes.c_int * len(slots))(*slots)
     ws = torch.zeros(24 * H * W * 10 * 2)
-    lib.labelprop(fb, seg, out, ws, qframe, ks, len(slots), H, W, C, CO, radius, topk, 0.07, None)
+    lib.labelprop(fb, seg, out, ws, qframe, ks, len(slots), H, W, C, CO, radius, 0, topk, 0.07, None)
     # oracle on the SAME normalised bf16 features (normalize=False), reference tensor layout, fp64
     fn = fb.double()
     q = fn[qframe].t().reshape(1, C, H, W)
@@ -95,15 +95,16 @@ def test_seg_postprocess_and_onehot(backend):
 
 
 def test_forward_test_matches_reference_golden_labels(backend):
-    """VanillaTracker.forward_test end to end vs the uint8 label maps captured from the REAL
-    reference (tests/golden/forward_test_r18.npz: fp32 torch).  The HIP path computes features
-    in bf16, so agreement is statistical (labels flip only where the top-2 classes are close)."""
+    """VanillaTracker.forward_test with test_cfg.precision='bf16' (the fast mode) vs the uint8 label maps captured from
+    the REAL reference (tests/golden/forward_test_r18.npz: fp32 torch).  Features are bf16 here, so agreement is
+    statistical (labels flip only where the top-2 classes are close); the default fp32 mode is held to 100 % in
+    tests/test_exact_f32.py."""
     import os
     import vfs_amd
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'forward_test_r18.npz'))
     cfg = vfs_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(__file__)), 'configs', 'vfs_r18.py'))
     tc = vfs_amd.ConfigDict(cfg.test_cfg)
-    tc['neighbor_range'], tc['precede_frames'] = 8, 3
+    tc['neighbor_range'], tc['precede_frames'], tc['precision'] = 8, 3, 'bf16'      # the fast mode (fp32 default: test_exact_f32.py)
     bb = dict(cfg.model['backbone'])
     bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']          # tools/test.py:129-133
     model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
@@ -124,7 +125,7 @@ def test_forward_test_matches_reference_golden_labels(backend):
     assert agree > 0.97, agree
     # ... and (near-)bit-exact against the oracle when it is fed the HIP path's own feature bank
     from vfs_amd.labelprop import extract_features
-    bank, h, w, C = extract_features(model, backend.eng, imgs.reshape(1, 3, T, H, W).to(backend.dev), 10)
+    bank, h, w, C = extract_features(model, backend.eng, imgs.reshape(1, 3, T, H, W).to(backend.dev), 10, precision='bf16')
     feats = bank.float().cpu().permute(2, 0, 1).reshape(1, C, T, h, w)
     lab = O.label_propagate(feats, g['ref_seg'], (H, W), precede_frames=3, topk=10, temperature=0.07,
                             neighbor_range=8, with_first=True, normalize=False)
@@ -140,7 +141,7 @@ def test_forward_test_all_blocks(backend):
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'forward_test_r18_all_blocks.npz'))
     cfg = vfs_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(__file__)), 'configs', 'vfs_r18.py'))
     tc = vfs_amd.ConfigDict(cfg.test_cfg)
-    tc['neighbor_range'], tc['precede_frames'], tc['all_blocks'] = 8, 3, True
+    tc['neighbor_range'], tc['precede_frames'], tc['all_blocks'], tc['precision'] = 8, 3, True, 'bf16'
     bb = dict(cfg.model['backbone'])
     bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']
     model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)

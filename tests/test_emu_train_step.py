@@ -313,6 +313,7 @@ def test_dilated_frozen_backbone_matches_oracle(backend, depth):
                          zero_init_residual=False, **kw)
     net.load_state_dict(ref.state_dict())
     net.to(backend.dev).eval()
+    net.eval_precision = 'bf16'       # the bf16 dilated kernels (fp32 default: test_exact_f32.py)
     x = O.fill_tensor([2, 3, 32, 48], seed=9, scale=2.0)
     with torch.no_grad():
         got = net(x.to(backend.dev)).cpu()

@@ -1,0 +1,341 @@
+"""The fp32 ("exact") evaluation path (csrc/exact_f32.hip, vfs_amd/exact.py): BIT-EXACT against the C oracle
+(oracle/exact_oracle.c) on the same inputs, pixel-exact / 1e-5 against the vectors captured from the reference.
+backend=emu (CPU, the same sources through the fiber emulator) / gpu (MI355X, -m gpu)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import exact_oracle as X
+from oracle import vfs_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(REPO, 'tests', 'golden')
+
+
+def _rand(shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).contiguous()
+
+
+def same_bits(a, b):
+    """bitwise equality up to the sign of zero"""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all(a == b))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, relu, res, affine
+    (2, 9, 11, 4, 64, 7, 2, 3, 1, True, False, True),        # stem geometry (NHWC4 input), ragged pixel tile
+    (1, 12, 10, 64, 64, 3, 1, 1, 1, True, True, True),       # basic-block join
+    (2, 8, 8, 64, 128, 3, 2, 1, 1, True, False, True),       # strided 3x3
+    (2, 7, 9, 128, 256, 1, 2, 0, 1, False, False, True),     # strided 1x1 downsample, no ReLU
+    (1, 10, 10, 64, 64, 3, 1, 2, 2, True, False, True),      # dilated (SiamFC backbone)
+    (1, 6, 6, 256, 96, 1, 1, 0, 1, False, False, False),     # plain GEMM: no affine, Cout not a multiple of 64
+]
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad,dil,relu,res,affine', CONV_CASES)
+def test_conv_f32_bit_exact(backend, N, H, W, Cin, Cout, k, stride, pad, dil, relu, res, affine):
+    lib = backend.hostlib
+    x = _rand((N, H, W, Cin), 1)
+    w = _rand((Cout, Cin, k, k), 2, (2.0 / (Cin * k * k)) ** 0.5)
+    if Cin == 4:
+        x[..., 3] = 0
+        w[:, 3] = 0
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    scale = (_rand((Cout,), 3) * 0.3 + 1.0) if affine else None
+    shift = _rand((Cout,), 4, 0.2) if affine else None
+    r = _rand((N, Ho, Wo, Cout), 5) if res else None
+    y = torch.full((N, Ho, Wo, Cout), float('nan'))
+    lib.conv_f32_fwd(x, w.permute(0, 2, 3, 1).contiguous(), scale, shift, r, y, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, dil,
+                     1 if relu else 0, None)
+    want = X.conv2d(x.numpy(), w.numpy(), None if scale is None else scale.numpy(), None if shift is None else shift.numpy(),
+                    res=None if r is None else r.numpy(), stride=stride, pad=pad, dil=dil, relu=relu)
+    assert same_bits(y.numpy(), want)
+    # and it is the convolution (fp64 torch on the same operands)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=stride, padding=pad, dilation=dil)
+    if affine:
+        ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.permute(0, 3, 1, 2).double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert (y.permute(0, 3, 1, 2).double() - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_small_ops_bit_exact(backend):
+    lib = backend.hostlib
+    # frames -> NHWC4
+    imgs = _rand((2, 1, 3, 3, 6, 5), 1)
+    out = torch.full((6, 6, 5, 4), float('nan'))
+    lib.imgs_to_nhwc4_f32(imgs, out, 2, 1, 3, 6, 5, None)
+    want = torch.zeros(6, 6, 5, 4)
+    want[..., :3] = imgs[:, 0].permute(0, 2, 3, 4, 1).reshape(6, 6, 5, 3)
+    assert torch.equal(out, want)
+    # max-pool
+    x = _rand((2, 9, 7, 8), 2)
+    y = torch.full((2, 5, 4, 8), float('nan'))
+    lib.maxpool_f32(x, y, 2, 9, 7, 8, 5, 4, None)
+    assert same_bits(y.numpy(), X.maxpool3x3s2(x.numpy()))
+    assert torch.equal(y.permute(0, 3, 1, 2), torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1))
+    # L2 normalisation
+    for C in (256, 1024, 20):
+        f = _rand((37, C), 3, 3.0)
+        n = torch.full_like(f, float('nan'))
+        lib.l2norm_rows_f32(f, n, 37, C, None)
+        assert same_bits(n.numpy(), X.l2norm_rows(f.numpy()))
+        assert (n - torch.nn.functional.normalize(f, dim=1)).abs().max() < 1e-6
+    # bilinear resize between layouts
+    src = _rand((3, 7, 9), 4)
+    dst = torch.full((12, 10, 3), float('nan'))
+    lib.bilinear_resize_f32(src, dst, 3, 7, 9, 12, 10, 0, 1, None)
+    ref = torch.nn.functional.interpolate(src[None], size=(12, 10), mode='bilinear', align_corners=False)[0]
+    assert (dst.permute(2, 0, 1) - ref).abs().max() < 1e-6
+    back = torch.full((3, 5, 4), float('nan'))
+    lib.bilinear_resize_f32(dst, back, 3, 12, 10, 5, 4, 1, 0, None)
+    ref2 = torch.nn.functional.interpolate(dst.permute(2, 0, 1)[None], size=(5, 4), mode='bilinear', align_corners=False)[0]
+    assert (back - ref2).abs().max() < 1e-6
+
+
+def _bank(T, H, W, C, CO, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(T, H * W, C, generator=g)
+    feats = feats + 2.0 * torch.randn(1, 1, C, generator=g) + torch.linspace(0, 3, H * W)[None, :, None] * torch.randn(1, 1, C, generator=g)
+    seg = torch.rand(T, H * W, CO, generator=g)
+    return feats, seg
+
+
+LP_CASES = [
+    dict(T=6, H=12, W=16, C=64, CO=3, radius=4, slots=[0, 1, 2, 3, 4], qframe=5),
+    dict(T=4, H=9, W=13, C=128, CO=5, radius=3, slots=[0, 0, 1, 2], qframe=3),       # duplicated first frame: exact ties
+    dict(T=3, H=8, W=8, C=64, CO=2, radius=0, slots=[0, 1], qframe=2, topk=5),       # no spatial mask
+    dict(T=3, H=20, W=28, C=20, CO=3, radius=6, slots=[0, 1], qframe=2),             # ragged channel stage, several key blocks
+    dict(T=4, H=9, W=13, C=64, CO=3, radius=3, slots=[0, 1, 2], qframe=3, non_mask_len=1),   # with_first_neighbor=False
+]
+
+
+def run_labelprop_f32(be, T, H, W, C, CO, radius, slots, qframe, topk=10, non_mask_len=0, seed=0):
+    lib = be.hostlib
+    feats, seg = _bank(T, H, W, C, CO, seed)
+    fb = torch.empty(T, H * W, C)
+    lib.l2norm_rows_f32(feats.reshape(-1, C).contiguous(), fb, T * H * W, C, None)
+    out = torch.full((H * W, CO), float('nan'))
+    ks = (ctypes.c_int * len(slots))(*slots)
+    ws = torch.zeros(24 * H * W * 10 * 2)
+    lib.labelprop_f32(fb, seg, out, ws, qframe, ks, len(slots), H, W, C, CO, radius, non_mask_len, topk, 0.07, None)
+    want = X.labelprop(fb.numpy(), seg.numpy(), qframe, slots, H, W, radius, topk, 0.07, non_mask_len=non_mask_len)
+    assert same_bits(out.numpy(), want), float(np.abs(out.numpy() - want).max())
+    return fb, seg, out
+
+
+@pytest.mark.parametrize('case', LP_CASES)
+def test_labelprop_f32_bit_exact(backend, case):
+    fb, seg, out = run_labelprop_f32(backend, **case)
+    if case.get('non_mask_len', 0) == 0:
+        # ... and it is masked_attention_efficient: the torch restatement (fp64) on the same bank
+        T, H, W, C, CO = case['T'], case['H'], case['W'], case['C'], case['CO']
+        slots, q = case['slots'], case['qframe']
+        fn = fb.double()
+        qq = fn[q].t().reshape(1, C, H, W)
+        k = torch.stack([fn[s].t().reshape(C, H, W) for s in slots], dim=1)[None]
+        v = torch.stack([seg[s].t().reshape(CO, H, W) for s in slots], dim=1)[None].double()
+        mask = O.spatial_neighbor_circle(H, W, 2 * case['radius']) if case['radius'] > 0 else None
+        ref = O.masked_attention_efficient(qq, k, v, mask, 0.07, case.get('topk', 10), normalize=False)
+        ref = ref[0].reshape(CO, H * W).t().float()
+        err = (out - ref).abs().max(dim=1)[0]
+        # duplicated key frames produce exact ties which torch.topk may resolve either way without changing the result;
+        # anything else must agree to fp32 rounding
+        assert (err > 1e-4).float().mean() < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,radius', [(256, 12), (1024, 18)])
+def test_labelprop_f32_davis_size_bit_exact(gpu_backend, C, radius):
+    """DAVIS feature size 60x107, R18 (C=256, r=12) and R50 (C=1024, r=18) settings, duplicated first frame"""
+    run_labelprop_f32(gpu_backend, T=5, H=60, W=107, C=C, CO=4, radius=radius, slots=[0, 0, 1, 2, 3], qframe=4)
+
+
+def test_seg_postprocess_exact(backend):
+    lib = backend.hostlib
+    H, W, CO, Ho, Wo = 12, 16, 4, 96, 128
+    seg = torch.rand(H * W, CO, generator=torch.Generator().manual_seed(1))
+    seg[:, 3] = -seg[:, 3]            # a channel whose max is <= 0 stays un-normalised
+    partial = torch.zeros(64 * CO * 2)
+    lab = torch.zeros(Ho, Wo, dtype=torch.uint8)
+    lib.seg_postprocess_exact(seg, partial, lab, H, W, CO, Ho, Wo, None)
+    assert np.array_equal(lab.numpy(), X.seg_postprocess(seg.numpy(), H, W, Ho, Wo))
+    want = O.seg_postprocess(seg.t().reshape(1, CO, H, W), (Ho, Wo))[0]
+    assert (lab != want).float().mean() < 1e-3       # torch's own kernel may fuse differently at exact channel ties
+
+
+def _davis_model(dev, depth=18, **over):
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    tc = vfs_amd.ConfigDict(cfg.test_cfg)
+    tc['neighbor_range'], tc['precede_frames'] = 8, 3
+    tc.update(over)
+    bb = dict(cfg.model['backbone'])
+    bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']          # tools/test.py:129-133
+    model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
+    ref = O.VanillaTracker(depth, dict(tc))
+    O.fill_state_dict_(ref, seed=5)
+    ref.eval()
+    missing = model.load_state_dict(ref.state_dict(), strict=False)
+    assert not [k for k in missing.missing_keys if 'iteration' not in k]
+    return model.to(dev).eval(), ref, tc
+
+
+def _clip():
+    T, H, W = 6, 96, 128
+    imgs = O.fill_tensor([1, 1, 3, T, H, W], 41, scale=2.0)
+    g = np.load(os.path.join(G, 'forward_test_r18.npz'))
+    return imgs, g['ref_seg'], (H, W), g
+
+
+def test_forward_test_fp32_equals_reference_labels_100pct(backend):
+    """default precision (fp32): every pixel of every frame equals the label maps captured from the reference,
+    features agree with the reference's to 1e-5, and everything equals the C oracle bit for bit"""
+    model, ref, tc = _davis_model(backend.dev)
+    imgs, seg, (H, W), g = _clip()
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                img_meta=[dict(original_shape=(H, W, 3))])
+    assert isinstance(out, list) and out[0].shape == (6, H, W) and out[0].dtype == np.uint8
+    agree = float((out[0] == g['seg_preds']).mean())
+    assert agree == 1.0, f'label agreement with the reference: {agree:.6f}'
+    want = X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc)
+    assert np.array_equal(out[0], want)
+    # features of the evaluated stage: HIP == C oracle (bits), == reference golden (1e-5)
+    from vfs_amd.labelprop import extract_features
+    bank, h, w, C = extract_features(model, backend.eng, imgs.reshape(1, 3, 6, H, W).to(backend.dev), 10, precision='fp32',
+                                     with_norm=False)
+    frames = imgs[0, 0].permute(1, 0, 2, 3).numpy()
+    feat = X.resnet_eval(ref.state_dict(), 18, frames, strides=(1, 2, 1, 1), out_indices=(2,), prefix='backbone.')[2]
+    assert same_bits(bank.cpu().numpy().reshape(feat.shape), feat)
+    flat = np.transpose(feat, (0, 3, 1, 2)).reshape(-1)
+    assert np.abs(flat[::997] - g['feat_sample']).max() < 1e-5 * np.abs(g['feat_sample']).max()
+
+
+def test_forward_test_fp32_all_blocks(backend):
+    model, ref, tc = _davis_model(backend.dev, all_blocks=True)
+    imgs, seg, (H, W), _ = _clip()
+    g = np.load(os.path.join(G, 'forward_test_r18_all_blocks.npz'))
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                img_meta=[dict(original_shape=(H, W, 3))])
+    assert len(out) == 1 and out[0].shape == (2, 6, H, W)
+    assert float((out[0] == g['seg_preds']).mean()) >= 0.9999
+    assert np.array_equal(out[0], X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc))
+
+
+@pytest.mark.parametrize('opts', [dict(with_first_neighbor=False), dict(with_norm=False), dict(with_first=False),
+                                  dict(neighbor_range=None), dict(topk=5, precede_frames=1)])
+def test_forward_test_fp32_options_bit_exact_vs_oracle(backend, opts):
+    """the option surface of test_cfg (vanilla_tracker.py:133-159): unmasked first frame, no feature normalisation,
+    no first frame, no spatial mask, other top-k / window"""
+    model, ref, tc = _davis_model(backend.dev, **opts)
+    imgs, seg, (H, W), _ = _clip()
+    imgs = imgs[:, :, :, :4]
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                img_meta=[dict(original_shape=(H, W, 3))])
+    want = X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc)
+    assert np.array_equal(out[0], want)
+    # ... and the torch restatement of the reference's own code path agrees (statistically: different fp32 order)
+    lab = ref.forward_test(imgs, seg, (H, W, 3)) if not set(opts) & {'with_first_neighbor', 'with_norm'} else None
+    if lab is not None:
+        assert float((out[0] == lab).mean()) > 0.999
+
+
+def test_forward_test_onehot_reference_map(backend):
+    """4-D (one-hot / soft) ref_seg_map (vanilla_tracker.py:94-111): bilinear resizes, soft maps returned"""
+    model, ref, tc = _davis_model(backend.dev)
+    imgs, seg, (H, W), _ = _clip()
+    imgs = imgs[:, :, :, :3]
+    onehot = torch.nn.functional.one_hot(torch.from_numpy(seg).long(), 3).permute(2, 0, 1)[None].float()
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=onehot, img_meta=[dict(original_shape=(H, W, 3))])
+    assert out[0].shape == (3, 3, H, W) and out[0].dtype == np.float32
+    want = X.forward_test(ref.state_dict(), 18, imgs, onehot[0].numpy(), (H, W, 3), tc)
+    assert same_bits(out[0], want)
+    # torch restatement of the same branch
+    frames = imgs[0, 0].permute(1, 0, 2, 3)
+    with torch.no_grad():
+        feats = O.images2video(ref.backbone(frames), 3)
+    import torch.nn.functional as F
+    h, w = feats.shape[-2:]
+    seg0 = F.interpolate(onehot, size=(h, w), mode='bilinear', align_corners=False)
+    mask = O.spatial_neighbor_circle(h, w, 8)
+    bank = [seg0]
+    for f in (1, 2):
+        k = torch.cat([feats[:, :, 0:1], feats[:, :, 0:f]], dim=2)
+        v = torch.stack([bank[0]] + bank[0:f], dim=2)
+        s = O.masked_attention_efficient(feats[:, :, f], k, v, mask, 0.07, 10, True)
+        bank.append(s)
+        up = F.interpolate(s, size=(H, W), mode='bilinear', align_corners=False)[0].numpy()
+        assert np.abs(out[0][f] - up).max() < 2e-3
+    assert np.abs(out[0][0] - onehot[0].numpy()).max() < 1e-6
+
+
+def test_save_np(backend, tmp_path, monkeypatch):
+    model, ref, tc = _davis_model(backend.dev, save_np=True)
+    imgs, seg, (H, W), _ = _clip()
+    imgs = imgs[:, :, :, :2]
+    monkeypatch.chdir(tmp_path)
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                img_meta=[dict(original_shape=(H, W, 3))])
+    assert isinstance(out[0], str) and out[0].endswith('.npy') and os.path.dirname(out[0]).endswith('.eval')
+    arr = np.load(out[0])
+    assert arr.shape == (2, H, W) and arr.dtype == np.uint8
+
+
+@pytest.mark.parametrize('depth', [18, 50])
+def test_resnet_eval_forward_fp32_vs_reference_golden(backend, depth):
+    """ResNet.forward in eval mode (fp32 default) vs the features the reference class produced (SiamFC probe
+    settings: dilations (1,1,2,4), strides (1,2,1,1)) at 1e-5, and bit-exact vs the C oracle"""
+    import vfs_amd
+    if backend.name == 'emu' and depth == 50:
+        pytest.skip('R50 on the emulator takes minutes; the GPU runs it')
+    g = np.load(os.path.join(G, f'resnet{depth}_dilated_eval.npz'))
+    net = vfs_amd.ResNet(depth, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), out_indices=(3,), frozen_stages=4, norm_eval=True,
+                         zero_init_residual=False)
+    ref = O.ResNet(depth, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), out_indices=(3,), zero_init_residual=False)
+    O.fill_state_dict_(ref, seed=depth + 100)
+    net.load_state_dict(ref.state_dict())
+    net.to(backend.dev).eval()
+    x = O.fill_tensor([2, 3, 64, 80], seed=9, scale=2.0)
+    y = net(x.to(backend.dev)).cpu().numpy()
+    assert tuple(y.shape) == tuple(g['shape'])
+    want = g['sample']
+    rel = np.abs(y.reshape(-1)[::13] - want).max() / np.abs(want).max()
+    assert rel < 1e-5, rel
+    orc = X.resnet_eval(ref.state_dict(), depth, x, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), out_indices=(3,))[3]
+    assert same_bits(y, np.transpose(orc, (0, 3, 1, 2)))
+
+
+@pytest.mark.gpu
+def test_full_size_davis_clip_fp32_bit_exact_vs_oracle(gpu_backend):
+    """480x854, 6 frames, R18 test-time config as shipped (radius 12, 20 preceding frames + first): the label maps of
+    the HIP path equal the C oracle's on every pixel (2.46 M pixels), and so do the res4 features"""
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', 'vfs_r18.py'))
+    tc = vfs_amd.ConfigDict(cfg.test_cfg)
+    bb = dict(cfg.model['backbone'])
+    bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']
+    model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
+    ref = O.VanillaTracker(18, dict(tc))
+    O.fill_state_dict_(ref, seed=5)
+    model.load_state_dict(ref.state_dict(), strict=False)
+    model.to(gpu_backend.dev).eval()
+    T, H, W = 6, 480, 854
+    imgs = O.fill_tensor([1, 1, 3, T, H, W], 43, scale=2.0)
+    yy, xx = np.mgrid[0:H, 0:W]
+    seg = np.zeros((H, W), np.uint8)
+    seg[(yy > 100) & (yy < 300) & (xx > 150) & (xx < 400)] = 1
+    seg[(yy > 250) & (yy < 450) & (xx > 500) & (xx < 800)] = 2
+    seg[(yy - 120) ** 2 + (xx - 650) ** 2 < 80 ** 2] = 3
+    out = model(imgs.to(gpu_backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                img_meta=[dict(original_shape=(H, W, 3))])
+    want = X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc)
+    assert out[0].shape == (T, H, W)
+    assert np.array_equal(out[0], want), float((out[0] != want).mean())
+    assert len(np.unique(out[0][-1])) == 4

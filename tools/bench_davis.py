@@ -76,10 +76,10 @@ def main():
     ks = (ctypes.c_int * len(slots))(*slots)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
-        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 10, 0.07, s)
+        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
     e0.record()
     for _ in range(5):
-        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 10, 0.07, s)
+        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
     e1.record()
     torch.cuda.synchronize()
     t_lp = e0.elapsed_time(e1) / 5 * 1e-3

@@ -376,14 +376,15 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
   return vfs_l2norm_rows_launch(x, y, P, C, S(stream));
 }
 int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
-                  int H, int W, int C, int CO, int radius, int topk, float temperature, vfs_stream_t stream) {
+                  int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {
   if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 24");
+  if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop: 0 <= non_mask_len < nkeys");
   LabelPropArgs a;
   a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;
   a.pval = (float*)workspace;
   a.pidx = workspace ? (int*)((float*)workspace + (size_t)LP_MAX_SPLIT * H * W * 10) : nullptr;
   for (int i = 0; i < LP_MAX_KEYS; ++i) a.kslot[i] = i < nkeys ? kslot[i] : 0;   // kslot is a HOST array
-  a.H = H; a.W = W; a.C = C; a.CO = CO; a.radius = radius; a.topk = topk; a.inv_temp = 1.0f / temperature;
+  a.H = H; a.W = W; a.C = C; a.CO = CO; a.radius = radius; a.non_mask_len = non_mask_len; a.topk = topk; a.inv_temp = 1.0f / temperature;
   return vfs_labelprop_launch(a, S(stream));
 }
 int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
@@ -392,6 +393,49 @@ int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H,
 }
 int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t stream) {
   return vfs_onehot_launch(labels, out, P, CO, S(stream));
+}
+
+// ---- fp32 evaluation path (exact_f32.hip) ----
+int vfs_conv_f32_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res, float* y, int N, int H,
+                     int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int dilation, int relu,
+                     vfs_stream_t stream) {
+  if (!x || !w || !y) return vfs_set_error(VFS_ERR_ARG, "conv_f32_fwd: null buffer");
+  ConvF32Args a;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
+  a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu;
+  return vfs_conv_f32_launch(a, S(stream));
+}
+int vfs_imgs_to_nhwc4_f32(const float* imgs, float* out, int B, int V, int T, int H, int W, vfs_stream_t stream) {
+  return vfs_imgs_to_nhwc4_f32_launch(imgs, out, B, V, T, H, W, S(stream));
+}
+int vfs_maxpool_f32(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, vfs_stream_t stream) {
+  return vfs_maxpool_f32_launch(x, y, N, H, W, C, Ho, Wo, S(stream));
+}
+int vfs_l2norm_rows_f32(const float* x, float* y, long long P, int C, vfs_stream_t stream) {
+  return vfs_l2norm_rows_f32_launch(x, y, P, C, S(stream));
+}
+int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
+                      int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {
+  if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 24");
+  if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32: 0 <= non_mask_len < nkeys");
+  LabelPropF32Args a;
+  a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;
+  a.pval = (float*)workspace;
+  a.pidx = workspace ? (int*)((float*)workspace + (size_t)LP_MAX_SPLIT * H * W * 10) : nullptr;
+  for (int i = 0; i < LP_MAX_KEYS; ++i) a.kslot[i] = i < nkeys ? kslot[i] : 0;   // kslot is a HOST array
+  a.H = H; a.W = W; a.C = C; a.CO = CO; a.radius = radius; a.topk = topk; a.temperature = temperature;
+  a.non_mask_len = non_mask_len;
+  return vfs_labelprop_f32_launch(a, S(stream));
+}
+int vfs_bilinear_resize_f32(const float* src, float* dst, int C, int H, int W, int Ho, int Wo, int src_nhwc, int dst_nhwc,
+                            vfs_stream_t stream) {
+  if (!src || !dst) return vfs_set_error(VFS_ERR_ARG, "bilinear_resize_f32: null buffer");
+  return vfs_bilinear_resize_f32_launch(src, dst, C, H, W, Ho, Wo, src_nhwc, dst_nhwc, S(stream));
+}
+int vfs_seg_postprocess_exact(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
+                              vfs_stream_t stream) {
+  return vfs_seg_postprocess_exact_launch(seg, partial, label, H, W, CO, Ho, Wo, S(stream));
 }
 
 int vfs_davis_counts(const uint8_t* pred, const uint8_t* gt, int* counts, void* scratch, int T, int H, int W, int nobj, int radius,

@@ -75,14 +75,6 @@ __global__ __launch_bounds__(256) void labelprop_kernel(LabelPropArgs a) {
   const int H = a.H, W = a.W, C = a.C, HW = H * W;
   const int tiles_x = (W + 7) >> 3;
   const int qy0 = (blockIdx.x / tiles_x) * 8, qx0 = (blockIdx.x % tiles_x) * 8;
-  const int r = a.radius;
-  int wy0 = 0, wy1 = H - 1, wx0 = 0, wx1 = W - 1;
-  if (r > 0) {
-    wy0 = max(0, qy0 - (r - 1)); wy1 = min(H - 1, qy0 + 7 + (r - 1));
-    wx0 = max(0, qx0 - (r - 1)); wx1 = min(W - 1, qx0 + 7 + (r - 1));
-  }
-  const int ww = wx1 - wx0 + 1, nwin = (wy1 - wy0 + 1) * ww;
-  const int nkb = (nwin + BK - 1) / BK;
   const int nkt = C >> 6;
   const int j = t & 7, row0 = t >> 3;
 
@@ -112,6 +104,15 @@ __global__ __launch_bounds__(256) void labelprop_kernel(LabelPropArgs a) {
   const int f_begin = (int)blockIdx.y * fpb, f_end = min(a.nkeys, f_begin + fpb);
   for (int f = f_begin; f < f_end; ++f) {
     const int slot = a.kslot[f];
+    // the first non_mask_len key frames are not masked (local_attention.py:303-309: with_first_neighbor=False)
+    const int r = f < a.non_mask_len ? 0 : a.radius;
+    int wy0 = 0, wy1 = H - 1, wx0 = 0, wx1 = W - 1;
+    if (r > 0) {
+      wy0 = max(0, qy0 - (r - 1)); wy1 = min(H - 1, qy0 + 7 + (r - 1));
+      wx0 = max(0, qx0 - (r - 1)); wx1 = min(W - 1, qx0 + 7 + (r - 1));
+    }
+    const int ww = wx1 - wx0 + 1, nwin = (wy1 - wy0 + 1) * ww;
+    const int nkb = (nwin + BK - 1) / BK;
     for (int kb = 0; kb < nkb; ++kb) {
       // key rows of this block
       size_t koff[4];

@@ -181,6 +181,7 @@ struct LabelPropArgs {
   int kslot[LP_MAX_KEYS];
   int H, W, C, CO;
   int radius;           // neighbor_range // 2 (mask: distance < radius); <= 0: no spatial mask
+  int non_mask_len;     // leading key frames WITHOUT the spatial mask (with_first_neighbor=False: 1)
   int topk;             // <= 10
   float inv_temp;
 };
@@ -189,6 +190,38 @@ int vfs_labelprop_launch(const LabelPropArgs& a, hipStream_t s);
 int vfs_seg_postprocess_launch(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
                                hipStream_t s);
 int vfs_onehot_launch(const uint8_t* lab, float* out, int P, int CO, hipStream_t s);
+
+// ---- exact_f32.hip: the fp32 evaluation path (bit-defined arithmetic, see the file header) -----------
+struct ConvF32Args {
+  const float* x;      // [N][H][W][Cin] fp32 NHWC, Cin % 4 == 0
+  const float* w;      // [Cout][KH][KW][Cin]
+  const float* scale;  // [Cout] or null: y = fmaf(acc, scale, shift) (BatchNorm in eval mode / bias)
+  const float* shift;  // [Cout]
+  const float* res;    // [N][Ho][Wo][Cout] identity branch or null
+  float* y;            // [N][Ho][Wo][Cout]
+  int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, relu;
+};
+struct LabelPropF32Args {
+  const float* fbank;  // [frames][H*W][C] L2-normalised fp32 features
+  const float* sbank;  // [frames][H*W][CO] fp32 value logits
+  float* out;          // [H*W][CO]
+  float* pval;         // workspace [LP_MAX_SPLIT][H*W][10] ...
+  int* pidx;           // ... partial top-k lists
+  int qframe, nkeys;
+  int kslot[LP_MAX_KEYS];
+  int H, W, C, CO, radius, topk;
+  int non_mask_len;    // leading key frames WITHOUT the spatial mask (with_first_neighbor=False: 1)
+  float temperature;
+};
+int vfs_conv_f32_launch(const ConvF32Args& a, hipStream_t s);
+int vfs_imgs_to_nhwc4_f32_launch(const float* imgs, float* out, int B, int V, int T, int H, int W, hipStream_t s);
+int vfs_maxpool_f32_launch(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+int vfs_l2norm_rows_f32_launch(const float* x, float* y, long long P, int C, hipStream_t s);
+int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s);
+int vfs_bilinear_resize_f32_launch(const float* src, float* dst, int C, int H, int W, int Ho, int Wo, int src_nhwc, int dst_nhwc,
+                                   hipStream_t s);
+int vfs_seg_postprocess_exact_launch(const float* seg, float* partial, uint8_t* label, int H, int W, int CO, int Ho, int Wo,
+                                     hipStream_t s);
 
 // DAVIS J&F ingredients (davis.hip)
 struct DavisArgs {

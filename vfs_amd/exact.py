@@ -1,0 +1,108 @@
+"""The fp32 ("exact") evaluation executor: ResNet in eval mode on the bit-defined fp32 kernels of
+csrc/exact_f32.hip (v_mfma_f32_32x32x2_f32: every dot product one ascending fma chain).
+
+The reference evaluates in fp32 (no fp16 key in any config; mmaction/apis/train.py:83-90) and
+VanillaTracker.forward_test returns INTEGER label maps, so this is the default precision of the
+evaluation path; `test_cfg.precision='bf16'` / `ResNet.eval_precision='bf16'` selects the bf16 kernels
+of the training path instead (about 3x faster, labels equal except near-ties).
+
+Layer semantics restated: mmcv ConvModule in eval mode = conv(bias=False) -> BatchNorm(running
+statistics) -> ReLU (resnet.py:51-73,163-191), BasicBlock / Bottleneck joins relu(out + identity)
+(resnet.py:102-111,221-230), downsample = 1x1 conv + BN (resnet.py:267-277), ResNet.forward
+(resnet.py:555-575; stops after the last requested stage instead of computing and discarding the rest)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+F32 = torch.float32
+
+
+def bn_eval_affine(bn):
+    """BatchNorm in eval mode as y = fma(x, scale, shift); every step ONE fp32 operation on the host so the
+    coefficients are defined exactly: scale = gamma / sqrt(var + eps), shift = beta - mean * scale"""
+    gamma = bn.weight.detach().cpu().numpy().astype(np.float32)
+    beta = bn.bias.detach().cpu().numpy().astype(np.float32)
+    mean = bn.running_mean.detach().cpu().numpy().astype(np.float32)
+    var = bn.running_var.detach().cpu().numpy().astype(np.float32)
+    scale = gamma / np.sqrt(var + np.float32(bn.eps))
+    shift = beta - mean * scale
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+class ExactResNet:
+    """fp32 execution state of one vfs_amd.ResNet: weights repacked to [Cout][KH][KW][Cin4] fp32 (a layout change, no
+    arithmetic), BatchNorm folded to (scale, shift); rebuilt when a parameter or buffer changes."""
+
+    def __init__(self, backbone):
+        self.bb = backbone
+        self.key = None
+        self.units = {}
+
+    def prepare(self, dev):
+        bb = self.bb
+        tensors = list(bb.parameters()) + list(bb.buffers())
+        key = (str(dev),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if key == self.key:
+            return
+        self.units = {}
+        for name, m in bb.conv_modules():
+            w = m.conv.weight.detach().to(dev, F32)
+            cout, cin, kh, kw = w.shape
+            wp = w.permute(0, 2, 3, 1)
+            if cin % 4:
+                wp = F.pad(wp, (0, 4 - cin % 4))
+            scale, shift = bn_eval_affine(m.bn)
+            self.units[name] = dict(w=wp.contiguous(), scale=torch.from_numpy(scale).to(dev), shift=torch.from_numpy(shift).to(dev),
+                                    k=kh, stride=m.conv.stride[0], pad=m.conv.padding[0], dil=m.conv.dilation[0],
+                                    cin=wp.shape[-1], cout=cout)
+        self.key = key
+
+    def conv(self, eng, name, x, N, H, W, relu, res=None, tag=''):
+        u = self.units[name]
+        span = u['dil'] * (u['k'] - 1) + 1
+        Ho, Wo = (H + 2 * u['pad'] - span) // u['stride'] + 1, (W + 2 * u['pad'] - span) // u['stride'] + 1
+        y = eng.buf(f'exact.{name}{tag}', (N, Ho, Wo, u['cout']), F32, x.device)
+        M = N * Ho * Wo
+        eng.timed('conv_f32', (2.0 * M * u['cout'] * u['k'] * u['k'] * u['cin'],
+                               4.0 * (N * H * W * u['cin'] + M * u['cout'] * (2 if res is not None else 1) + u['w'].numel())), x.device,
+                  eng.lib.conv_f32_fwd, x, u['w'], u['scale'], u['shift'], res, y, N, H, W, u['cin'], Ho, Wo, u['cout'], u['k'], u['k'],
+                  u['stride'], u['pad'], u['dil'], 1 if relu else 0, eng.stream(x.device))
+        return y, Ho, Wo
+
+    def forward(self, eng, x4, N, H, W, stop_after_out=True):
+        """x4: fp32 NHWC4 [N,H,W,4] -> ({stage: (act, h, w, C)}, [(block output, h, w, C, stage), ...])"""
+        bb = self.bb
+        dev = x4.device
+        self.prepare(dev)
+        s = eng.stream(dev)
+        x, h, w = self.conv(eng, 'conv1', x4, N, H, W, True)
+        hp, wp = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        pooled = eng.buf('exact.pool', (N, hp, wp, 64), F32, dev)
+        eng.lib.maxpool_f32(x, pooled, N, h, w, 64, hp, wp, s)
+        x, h, w = pooled, hp, wp
+        outs, blocks = {}, []
+        for si, lname in enumerate(bb.res_layers):
+            for bi, blk in enumerate(getattr(bb, lname)):
+                pre = f'{lname}.{bi}'
+                identity = x
+                if blk.downsample is not None:
+                    identity, _, _ = self.conv(eng, pre + '.downsample', x, N, h, w, False)
+                a, ah, aw = x, h, w
+                nconv = blk.nconv
+                for ci in range(nconv):
+                    last = ci == nconv - 1
+                    a, ah, aw = self.conv(eng, f'{pre}.conv{ci + 1}', a, N, ah, aw, True, res=identity if last else None)
+                x, h, w = a, ah, aw
+                blocks.append((x, h, w, x.shape[-1], si))
+            if si in bb.out_indices:
+                outs[si] = (x, h, w, x.shape[-1])
+            if stop_after_out and si >= bb.last_stage():
+                break
+        return outs, blocks
+
+
+def exact_state(backbone):
+    st = getattr(backbone, '_exact_state', None)
+    if st is None:
+        st = backbone._exact_state = ExactResNet(backbone)
+    return st

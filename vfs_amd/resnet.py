@@ -127,7 +127,15 @@ class ResNet(nn.Module):
     def init_weights(self):
         """resnet.py:525-553: checkpoint, or kaiming + BN(1,0) + zero-init of each block's last BN."""
         if isinstance(self.pretrained, str):
-            self.load_torchvision_checkpoint(torch.load(self.pretrained, map_location='cpu'))
+            ckpt = torch.load(self.pretrained, map_location='cpu')
+            if self.torchvision_pretrain:
+                self.load_torchvision_checkpoint(ckpt)
+            else:
+                # "ours" (resnet.py:536-539): mmcv load_checkpoint(self, path, strict=False) - the module's own key
+                # names, an optional 'state_dict' wrapper and a 'module.' prefix left by (MM)DistributedDataParallel
+                sd = ckpt.get('state_dict', ckpt)
+                sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+                self.load_state_dict(sd, strict=False)
         elif self.pretrained is None:
             for m in self.modules():
                 if isinstance(m, nn.Conv2d):
@@ -400,9 +408,18 @@ class ResNet(nn.Module):
         if x.requires_grad:
             raise RuntimeError('ResNet.forward is the inference entry point; use SimSiamBaseTracker.forward_train')
         eng = shared_engine(x.device)
+        N, _, H, W = x.shape
+        precision = getattr(self, 'eval_precision', None) or os.environ.get('VFS_EVAL_PRECISION', 'fp32')
+        if not self.training and precision == 'fp32':
+            # eval mode: the reference's fp32 arithmetic, bit-defined (vfs_amd/exact.py, csrc/exact_f32.hip)
+            from .exact import exact_state
+            x4 = eng.buf('exact.x4', (N, H, W, 4), torch.float32, x.device)
+            eng.lib.imgs_to_nhwc4_f32(x.contiguous().float(), x4, N, 1, 1, H, W, eng.stream(x.device))
+            outs, _ = exact_state(self).forward(eng, x4, N, H, W, stop_after_out=True)
+            res = [outs[i][0].permute(0, 3, 1, 2).contiguous() for i in sorted(outs)]
+            return res[0] if len(res) == 1 else tuple(res)
         self.attach(eng)
         eng.pack_weights()
-        N, _, H, W = x.shape
         Wp = W + (W & 1)
         x4 = eng.buf('backbone.x4', (N, H, Wp, 4), BF16, x.device)
         eng.lib.imgs_to_nhwc4(x.contiguous().float(), x4, N, 1, 1, H, W, Wp, eng.stream(x.device))
