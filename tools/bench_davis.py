@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--model', default='r18', choices=['r18', 'r50'])
     ap.add_argument('--frames', type=int, default=30)
     ap.add_argument('--parity-frames', type=int, default=3)
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'])
     args = ap.parse_args()
     import vfs_amd
     from oracle import vfs_oracle as O
@@ -32,6 +33,7 @@ def main():
     dev = torch.device('cuda:0')
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
     tc = vfs_amd.ConfigDict(cfg.test_cfg)
+    tc['precision'] = args.precision
     bb = dict(cfg.model['backbone'])
     bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']
     model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
@@ -63,7 +65,7 @@ def main():
     # stage timing: features vs propagation
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    bank, h, w, C = extract_features(model, eng, imgs.reshape(1, 3, T, H, W), 10)
+    bank, h, w, C = extract_features(model, eng, imgs.reshape(1, 3, T, H, W), 10, precision=args.precision)
     torch.cuda.synchronize()
     t_feat = time.perf_counter() - t0
     radius = int(tc['neighbor_range']) // 2
@@ -75,11 +77,12 @@ def main():
     slots = [0] + list(range(max(0, f - 20), f))
     ks = (ctypes.c_int * len(slots))(*slots)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lp = eng.lib.labelprop_f32 if args.precision == 'fp32' else eng.lib.labelprop
     for _ in range(2):
-        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
+        lp(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
     e0.record()
     for _ in range(5):
-        eng.lib.labelprop(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
+        lp(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
     e1.record()
     torch.cuda.synchronize()
     t_lp = e0.elapsed_time(e1) / 5 * 1e-3
@@ -87,9 +90,13 @@ def main():
     alg_flop = 2.0 * float(mask.sum()) * len(slots) * C
     # label parity on the first frames against the oracle fed the same bf16 bank
     P = min(args.parity_frames + 1, T)
-    feats = bank[:P].float().cpu().permute(2, 0, 1).reshape(1, C, P, h, w)
-    lab = O.label_propagate(feats, seg, (H, W), precede_frames=20, topk=10, temperature=0.07,
-                            neighbor_range=int(tc['neighbor_range']), with_first=True, normalize=False)
+    if args.precision == 'fp32':      # the C oracle end to end (features included): must be 0
+        from oracle import exact_oracle as X
+        lab = X.forward_test(ref.state_dict(), depth, imgs[:, :, :, :P].cpu(), seg, (H, W, 3), tc)
+    else:
+        feats = bank[:P].float().cpu().permute(2, 0, 1).reshape(1, C, P, h, w)
+        lab = O.label_propagate(feats, seg, (H, W), precede_frames=20, topk=10, temperature=0.07,
+                                neighbor_range=int(tc['neighbor_range']), with_first=True, normalize=False)
     mism = float((out[0][:P] != lab).mean())
     # J&F of the propagated labels against a "ground truth" that keeps the first-frame masks (the clip is
     # a static scene + noise): exercises the evaluator on the real pipeline; oracle counts on 3 frames
@@ -111,7 +118,8 @@ def main():
     res = {'metric': 'DAVIS label propagation', 'model': f'R{depth}', 'frames': T, 'feature_hw': [h, w], 'C': C,
            'ms_per_frame_end_to_end': dt / (T - 1) * 1e3, 'ms_backbone_per_frame': t_feat / T * 1e3,
            'ms_labelprop_kernel_21_key_frames': t_lp * 1e3, 'key_frames': len(slots),
-           'labelprop_algorithmic_TFLOPs': alg_flop / t_lp / 1e12, 'labelprop_frac_of_mfma_peak': alg_flop / t_lp / 2.5e15,
+           'precision': args.precision, 'labelprop_algorithmic_TFLOPs': alg_flop / t_lp / 1e12,
+           'labelprop_frac_of_mfma_peak': alg_flop / t_lp / (157.3e12 if args.precision == 'fp32' else 2.5e15),
            'label_mismatch_vs_oracle_same_features': mism, 'parity_frames': P - 1,
            'labels_present': sorted(int(v) for v in np.unique(out[0])),
            'jf_eval': {'J&F-Mean': jf['J&F-Mean'], 'J-Mean': jf['J-Mean'], 'F-Mean': jf['F-Mean'],
