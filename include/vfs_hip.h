@@ -107,7 +107,9 @@ int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* 
                         int stride, int pad, int nsplit, int pix_per_split, vfs_stream_t stream);
 /* wgrad: grad[Cout][Cin][KH][KW] (fp32, reference OIHW layout) += sum_pixels dy * im2col(x).
  * partial: workspace float[nsplit][Cout][KH*KW*Cin]; pix_per_split % 64 == 0 and
- * nsplit*pix_per_split >= N*Ho*Wo.  Deterministic (fixed-order split-K reduction). */
+ * nsplit*pix_per_split >= N*Ho*Wo.  Deterministic (fixed-order split-K reduction).
+ * grad == NULL (here and in vfs_conv_wgrad_bnin / vfs_stem_wgrad / vfs_stem_wgrad_fused): only the partials are written;
+ * the caller keeps `partial` alive and reduces many layers at once with vfs_wgrad_reduce_table. */
 int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float* grad, int N, int H,
                    int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                    int nsplit, int pix_per_split, vfs_stream_t stream);
@@ -239,6 +241,13 @@ int vfs_seg_postprocess(const float* seg, float* partial, uint8_t* label, int H,
                         int Wo, vfs_stream_t stream);
 /* F.one_hot of the resized first-frame label map into the seg bank (vanilla_tracker.py:96-100) */
 int vfs_onehot(const uint8_t* labels, float* out, int P, int CO, vfs_stream_t stream);
+
+/* split-K partials of MANY layers -> their gradients in ONE launch.  desc: device array of nrecords 56-byte records
+ * {const float* partial; float* grad; int nsplit, Cout, Ktot, Cin, KH, KW, stem, block_start, nblocks, pad;} (stem = 1:
+ * the 7x7 stem's k-layout, Ktot 256 for vfs_stem_wgrad / 224 for vfs_stem_wgrad_fused with Cin = 3); a record is served
+ * by workgroups [block_start, block_start + nblocks), 128 elements each per pass; total_blocks = sum of nblocks.
+ * grad += sum over the splits in a fixed order (deterministic). */
+int vfs_wgrad_reduce_table(const void* desc, int nrecords, int total_blocks, vfs_stream_t stream);
 
 /* ---- fp32 evaluation path ("exact" precision; csrc/exact_f32.hip) ------------------------------------
  * The reference evaluates in fp32 and its outputs are INTEGER label maps, so the default forward_test path stores

@@ -195,6 +195,12 @@ def _clip():
     return imgs, g['ref_seg'], (H, W), g
 
 
+def _small_clip(T=3):
+    """a 48x64 crop of the golden clip (6x8 feature map): the option tests run on the CPU emulator as well"""
+    imgs, seg, _, _ = _clip()
+    return imgs[:, :, :, :T, 16:64, 24:88].contiguous(), np.ascontiguousarray(seg[16:64, 24:88]), (48, 64)
+
+
 def test_forward_test_fp32_equals_reference_labels_100pct(backend):
     """default precision (fp32): every pixel of every frame equals the label maps captured from the reference,
     features agree with the reference's to 1e-5, and everything equals the C oracle bit for bit"""
@@ -235,8 +241,7 @@ def test_forward_test_fp32_options_bit_exact_vs_oracle(backend, opts):
     """the option surface of test_cfg (vanilla_tracker.py:133-159): unmasked first frame, no feature normalisation,
     no first frame, no spatial mask, other top-k / window"""
     model, ref, tc = _davis_model(backend.dev, **opts)
-    imgs, seg, (H, W), _ = _clip()
-    imgs = imgs[:, :, :, :4]
+    imgs, seg, (H, W) = _small_clip(4)
     out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
                 img_meta=[dict(original_shape=(H, W, 3))])
     want = X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc)
@@ -250,8 +255,7 @@ def test_forward_test_fp32_options_bit_exact_vs_oracle(backend, opts):
 def test_forward_test_onehot_reference_map(backend):
     """4-D (one-hot / soft) ref_seg_map (vanilla_tracker.py:94-111): bilinear resizes, soft maps returned"""
     model, ref, tc = _davis_model(backend.dev)
-    imgs, seg, (H, W), _ = _clip()
-    imgs = imgs[:, :, :, :3]
+    imgs, seg, (H, W) = _small_clip(3)
     onehot = torch.nn.functional.one_hot(torch.from_numpy(seg).long(), 3).permute(2, 0, 1)[None].float()
     out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=onehot, img_meta=[dict(original_shape=(H, W, 3))])
     assert out[0].shape == (3, 3, H, W) and out[0].dtype == np.float32
@@ -278,8 +282,7 @@ def test_forward_test_onehot_reference_map(backend):
 
 def test_save_np(backend, tmp_path, monkeypatch):
     model, ref, tc = _davis_model(backend.dev, save_np=True)
-    imgs, seg, (H, W), _ = _clip()
-    imgs = imgs[:, :, :, :2]
+    imgs, seg, (H, W) = _small_clip(2)
     monkeypatch.chdir(tmp_path)
     out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
                 img_meta=[dict(original_shape=(H, W, 3))])

@@ -175,6 +175,10 @@ int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float*
     rc = vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
   }
   if (rc) return rc;
+  if (!grad) {      // the caller reduces the partials later (vfs_wgrad_reduce_table): its table needs the split count it offered
+    if (nsplit != a.nsplit) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: deferred reduction needs a split plan the kernel takes as offered");
+    return VFS_OK;
+  }
   return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
 }
 int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* in_bnp, int in_npg, float* partial, float* grad, int N,
@@ -189,6 +193,10 @@ int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* 
     return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
   int rc = vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);
   if (rc) return rc;
+  if (!grad) {
+    if (nsplit != a.nsplit) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_bnin: deferred reduction needs a split plan the kernel takes as offered");
+    return VFS_OK;
+  }
   return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
 }
 
@@ -198,8 +206,13 @@ int vfs_stem_wgrad(const vfs_bf16* dy, const vfs_bf16* x4, float* partial, float
   a.g = make_geom(N, H, Wp, 4, Ho, Wo, 7, 7, 2, 3, 256);
   a.dy = dy; a.x = x4; a.partial = partial; a.Cout = 64; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
   int rc = vfs_conv_wgrad_dispatch(a, GATHER_STEM, S(stream));
-  if (rc) return rc;
+  if (rc || !grad) return rc;
   return vfs_wgrad_reduce_launch(partial, grad, nsplit, 64, 256, 3, 7, 7, 1, S(stream));
+}
+
+int vfs_wgrad_reduce_table(const void* desc, int nrecords, int total_blocks, vfs_stream_t stream) {
+  if (nrecords > 0 && !desc) return vfs_set_error(VFS_ERR_ARG, "wgrad_reduce_table: null table");
+  return vfs_wgrad_reduce_table_launch((const WgradReduceDesc*)desc, nrecords, total_blocks, S(stream));
 }
 
 int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stream) {
@@ -321,7 +334,7 @@ int vfs_stem_wgrad_fused(const vfs_bf16* x4, const vfs_bf16* xraw, const vfs_bf1
   a.N = N; a.H = Ho; a.W = Wo; a.C = 64; a.Hp = Hp; a.Wp = Wp; a.npg = npg; a.count = count;
   if ((size_t)N * Hin * Win * 8 >= 0xFFFFFFF0ull) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: input >= 4 GiB");
   int rc = vfs_stem_wgrad_fused_launch(a, x4, Hin, Win, partial, nblocks, S(stream));
-  if (rc) return rc;
+  if (rc || !grad) return rc;
   return vfs_wgrad_reduce_launch(partial, grad, nblocks, 64, 224, 3, 7, 7, 1, S(stream));
 }
 int vfs_bn_param_grad(const double* sums, float* dgamma, float* dbeta, int G, int C, vfs_stream_t stream) {

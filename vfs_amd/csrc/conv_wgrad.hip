@@ -11,6 +11,7 @@
 // ranges; fp32 partials are summed in a fixed order by wgrad_reduce (deterministic), which also
 // scatters into the reference's OIHW parameter layout.
 #include "vfs_conv.h"
+#include "vfs_ops.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define WG_RS 72   // LDS row pitch of a [pixel][64 channels] tile: 144 B (see conv_wgrad_halo.hip)
@@ -194,18 +195,16 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
 // partial[nsplit][Cout][Ktot] -> grad (+=) in the reference's parameter layout (OIHW fp32):
 //   FWD  : k = (r*KW + s)*Cin + cin          -> grad[cout][cin][r][s]
 //   STEM : k = (r*8 + (s+1))*4 + c           -> grad[cout][c][r][s]   (r<7, 0<=s<7, c<3)
+// one pass of a workgroup over `total` elements starting at block `blk` of `nblk`: EL lanes x 4 consecutive elements (one
+// 16-byte load each) x SL split-slices; a lane walks its slice's splits four at a time (four independent 16-byte loads in
+// flight), the SL slice sums meet in LDS and are added in a fixed order (deterministic).  total % 4 == 0 (Ktot % 4 == 0).
 template <int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad,
-                                                           int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
-                                                           int stem) {
-  // workgroup = EL lanes x 4 consecutive elements (one 16-byte load each) x SL split-slices; a lane
-  // walks its slice's splits four at a time (four independent 16-byte loads in flight), the SL slice
-  // sums meet in LDS and are added in a fixed order (deterministic).  total % 4 == 0 (Ktot % 4 == 0).
+__device__ __forceinline__ void wgrad_reduce_body(float (*sh)[(256 / SL) * 4], const float* __restrict__ partial, float* __restrict__ grad,
+                                                  int nsplit, int Cout, int Ktot, int Cin, int KH, int KW, int stem, int blk, int nblk) {
   constexpr int EL = 256 / SL;
-  __shared__ __attribute__((aligned(16))) float sh[SL][EL * 4];
   const size_t total = (size_t)Cout * Ktot;
   const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
-  for (size_t base = (size_t)blockIdx.x * (EL * 4); base < total; base += (size_t)gridDim.x * (EL * 4)) {
+  for (size_t base = (size_t)blk * (EL * 4); base < total; base += (size_t)nblk * (EL * 4)) {
     const size_t i = base + (size_t)el * 4;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     if (i < total) {
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const int cout = (int)(ii / Ktot), k = (int)(ii - (size_t)cout * Ktot);
       int cin, r, s2;
       bool ok = true;
-      if (stem) {
+      if (stem == 1) {            // direct stem kernel / implicit-GEMM stem: k = (r*8 + (s+1))*4 + c
         cin = k & 3;
         const int si = (k >> 2) & 7;
         r = k >> 5; s2 = si - 1;
@@ -249,6 +248,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     __syncthreads();
   }
+}
+
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad,
+                                                           int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
+                                                           int stem) {
+  __shared__ __attribute__((aligned(16))) float sh[SL][(256 / SL) * 4];
+  wgrad_reduce_body<SL>(sh, partial, grad, nsplit, Cout, Ktot, Cin, KH, KW, stem, blockIdx.x, gridDim.x);
+}
+
+// Table-driven form: the split-K partials of MANY layers reduced by ONE launch (the per-layer reduction launches were
+// 58 of ResNet-50's ~430 launches per step and 0.95 ms of the weight-gradient stream).  Workgroup b serves the
+// descriptor d with d.block_start <= b < d.block_start + d.nblocks (binary search, uniform per workgroup).
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_table_kernel(const WgradReduceDesc* __restrict__ tab, int n) {
+  __shared__ __attribute__((aligned(16))) float sh[SL][(256 / SL) * 4];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradReduceDesc d = tab[lo];
+  wgrad_reduce_body<SL>(sh, d.partial, d.grad, d.nsplit, d.Cout, d.Ktot, d.Cin, d.KH, d.KW, d.stem, (int)blockIdx.x - d.block_start,
+                        d.nblocks);
+}
+
+int vfs_wgrad_reduce_table_launch(const WgradReduceDesc* tab, int n, int total_blocks, hipStream_t stream) {
+  if (n < 1 || total_blocks < 1) return VFS_OK;
+  hipLaunchKernelGGL((wgrad_reduce_table_kernel<8>), dim3(total_blocks), dim3(256), 0, stream, tab, n);
+  return vfs_check_launch("wgrad_reduce_table");
 }
 
 template <int SL>

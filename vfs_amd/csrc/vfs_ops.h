@@ -112,6 +112,17 @@ int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s);
 int vfs_bn_param_grad_launch(const double* sums, float* dgamma, float* dbeta, int G, int C, hipStream_t s);
 int vfs_wgrad_reduce_launch(const float* partial, float* grad, int nsplit, int Cout, int Ktot, int Cin, int KH, int KW,
                             int stem, hipStream_t stream);
+// one record per layer of the table-driven split-K reduction (conv_wgrad.hip; 56 bytes, mirrored by vfs_amd/packing.py)
+struct WgradReduceDesc {
+  const float* partial;   // [nsplit][Cout][Ktot]
+  float* grad;            // OIHW fp32 gradient (+=)
+  int nsplit, Cout, Ktot, Cin, KH, KW;
+  int stem;               // 1: 7x7 stem k-layout ((r*8 + s+1)*4 + c)
+  int block_start;        // first workgroup of this record (128 elements per workgroup)
+  int nblocks;            // workgroups serving this record
+  int pad_;
+};
+int vfs_wgrad_reduce_table_launch(const WgradReduceDesc* tab, int n, int total_blocks, hipStream_t stream);
 
 // ---- misc.hip ------------------------------------------------------------------------------
 // imgs fp32 [B][V][3][T][H][W] (reference layout, FormatShape 'NCTHW') -> bf16 NHWC4

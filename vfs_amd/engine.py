@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import Tape, TapeLib, get_lib
-from .packing import (igemm_ksplit, bn_fold_eligible, build_pack_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible,
+from .packing import (igemm_ksplit, bn_fold_eligible, build_pack_table, build_reduce_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible,
                       wgrad_splits)
 
 BF16 = torch.bfloat16
@@ -53,6 +53,12 @@ class Engine:
         self._side_dirty = False
         self.prof = None     # list collecting (kind, flops, start_event, end_event) when profiling
         self.tape = None
+        # weight-gradient split-K partials: reduced per layer right after the kernel (default), or - inside the trackers'
+        # backward chain (defer_wgrad) - kept in per-layer buffers and reduced by ONE table-driven launch per flush
+        self.defer_wgrad = False
+        self._wpending = []
+        self._wtables = {}
+        self.generation = 0  # bumped whenever a persistent buffer is (re)allocated: recorded launch chains hold raw pointers
         for kv in filter(None, os.environ.get('VFS_OPTS', '').split(',')):      # kernel A/B knobs: "name=value,..."
             name, value = kv.split('=')
             self.lib.set_option(name.strip().encode(), int(value))
@@ -93,8 +99,11 @@ class Engine:
         t = self.bufs.get(key)
         shape = tuple(int(s) for s in shape)
         if t is None or t.shape != shape or t.dtype != dtype or t.device != dev:
+            if t is not None and dev.type == 'cuda':
+                torch.cuda.synchronize(dev)     # a recorded chain may still be reading the old block
             t = torch.empty(shape, dtype=dtype, device=dev)
             self.bufs[key] = t
+            self.generation += 1
         return t
 
     def ws(self, key, numel, dtype, dev):
@@ -105,6 +114,7 @@ class Engine:
                 torch.cuda.synchronize(dev)     # the old block may still be in use on the side stream
             t = torch.empty(int(numel), dtype=dtype, device=dev)
             self.bufs[key] = t
+            self.generation += 1
         return t
 
     @staticmethod
@@ -152,6 +162,7 @@ class Engine:
     def register(self, unit):
         self.units.append(unit)
         self._pack = None
+        self.generation += 1      # the pack table (and its bf16 weight copies) will be rebuilt
         return unit
 
     def pack_weights(self):
@@ -170,8 +181,11 @@ class Engine:
                     u.wf = torch.empty(u.cout, u.k, u.k, u.cin, dtype=BF16, device=dev)
                     u.wd = torch.empty(u.cin, u.k, u.k, u.cout, dtype=BF16, device=dev) if u.need_wd else None
                 entries.append((u.weight.data, u.wf, u.wd, 1 if u.kind == 'stem' else 0))
+            if dev.type == 'cuda':
+                torch.cuda.synchronize(dev)     # the previous packed copies may still be in use
             self._pack = build_pack_table(entries, dev)
             self._pack_key = key
+            self.generation += 1
         tab, n, total = self._pack
         self.lib.pack_weights(tab, n, total, self.stream(dev))
 
@@ -292,6 +306,7 @@ class Engine:
                 torch.cuda.synchronize(dev)
             t = torch.zeros(int(need), dtype=torch.float32, device=dev)
             self.bufs['ws.ksplit'] = t
+            self.generation += 1
         return t
 
     def bn_scratch(self, G, C, dev):
@@ -302,6 +317,7 @@ class Engine:
         if t is None or t.numel() < need or t.device != dev:
             t = torch.zeros(need, dtype=torch.float64, device=dev)
             self.bufs['ws.bnred'] = t
+            self.generation += 1
         return t
 
     def bn_act(self, u, raw, M, G, train, relu, res=None, rres=None, rbnp=None, tag=''):
@@ -419,13 +435,42 @@ class Engine:
         ntiles = N * ((H + 7) // 8) * ((W + 15) // 16)
         tpb = (ntiles + 1535) // 1536        # ~6 workgroups per CU: the operand gather is latency-bound
         nblocks = (ntiles + tpb - 1) // tpb
-        partial = self.ws('ws.wgrad', nblocks * 64 * 224, torch.float32, dev)
+        partial = self.wgrad_partial(u, nblocks, 64, 224, dev)
         with self.on_side_stream(dev):      # ws.wgrad belongs to the side stream
-            self.timed('stem_wgrad', (2.0 * N * H * W * 64 * 147,
-                                      2.0 * N * (Hin * Win * 4 + H * W * 64) + 5.0 * N * Hp * Wp * 64 + 8.0 * nblocks * 64 * 224),
+            self.timed('stem_wgrad', (2.0 * N * H * W * 64 * 147, 2.0 * N * (Hin * Win * 4 + H * W * 64) + 5.0 * N * Hp * Wp * 64),
                        dev, self.lib.stem_wgrad_fused,
-                       x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, u.weight.grad, N, Hin, Win, H, W, Hp, Wp,
-                       N // G, count, nblocks, self.stream(dev))
+                       x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, self.wgrad_target(u, partial, nblocks, 64, 224, 3, 7, 1),
+                       N, Hin, Win, H, W, Hp, Wp, N // G, count, nblocks, self.stream(dev))
+
+    def wgrad_partial(self, u, nsplit, cout, ktot, dev):
+        """split-K workspace of unit u's weight gradient: the shared scratch (reduced right after the kernel) or, when the
+        reduction is deferred, a per-unit buffer that lives until flush_wgrad"""
+        if self.defer_wgrad:
+            return self.buf(f'{u.name}.wpart', (nsplit * cout * ktot,), torch.float32, dev)
+        return self.ws('ws.wgrad', nsplit * cout * ktot, torch.float32, dev)
+
+    def wgrad_target(self, u, partial, nsplit, cout, ktot, cin, k, stem):
+        """the `grad` argument of the weight-gradient entry points: the gradient itself, or None (= reduce later)"""
+        if not self.defer_wgrad:
+            return u.weight.grad
+        self._wpending.append((partial, u.weight.grad, nsplit, cout, ktot, cin, k, k, stem))
+        return None
+
+    def flush_wgrad(self, dev):
+        """ONE table-driven launch reduces the split-K partials of every weight gradient issued since the last flush
+        (side stream, after the kernels that wrote them)"""
+        if not self._wpending:
+            return
+        pend, self._wpending = self._wpending, []
+        key = tuple((p.data_ptr(), g.data_ptr(), ns) for p, g, ns, *_ in pend)
+        tab = self._wtables.get(key)
+        if tab is None:
+            if len(self._wtables) > 64:
+                self._wtables.clear()
+            tab = self._wtables[key] = build_reduce_table(pend, dev)
+            self.generation += 1
+        with self.on_side_stream(dev):
+            self.lib.wgrad_reduce_table(tab[0], tab[1], tab[2], self.stream(dev))
 
     def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None, bn_next=None, x_in_bn=None):
         """weight (and bias) gradients accumulate into .grad; returns the input gradient or None.
@@ -441,18 +486,22 @@ class Engine:
                                       'dilated backbone: frozen_stages=4, norm_eval=True)')
         if u.kind == 'stem':
             nsplit, pps = wgrad_splits(M, 64, 256)
-            partial = self.ws('ws.wgrad', nsplit * 64 * 256, torch.float32, dev)
+            partial = self.wgrad_partial(u, nsplit, 64, 256, dev)
             with self.on_side_stream(dev):
-                self.timed('stem_wgrad', (2.0 * M * 64 * 147, 2.0 * (M * 64 + N * H * W * 4) + 8.0 * nsplit * 64 * 256), dev, lib.stem_wgrad,
-                           dx, x_in, partial, u.weight.grad, N, H, W, Ho, Wo, nsplit, pps, self.stream(dev))
+                self.timed('stem_wgrad', (2.0 * M * 64 * 147, 2.0 * (M * 64 + N * H * W * 4)), dev, lib.stem_wgrad,
+                           dx, x_in, partial, self.wgrad_target(u, partial, nsplit, 64, 256, 3, 7, 1), N, H, W, Ho, Wo, nsplit, pps,
+                           self.stream(dev))
             return None
         ktot = u.k * u.k * u.cin
         halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
-        partial = self.ws('ws.wgrad', nsplit * u.cout * ktot, torch.float32, dev)
+        partial = self.wgrad_partial(u, nsplit, u.cout, ktot, dev)
         flops = 2.0 * M * u.cout * ktot
-        # dY + x once, fp32 split-K partials written and re-read by the reduction, fp32 gradient read-modify-write
-        wbytes = 2.0 * (M * u.cout + N * H * W * u.cin) + 8.0 * nsplit * u.cout * ktot + 8.0 * u.cout * ktot
+        # ALGORITHMIC bytes: dY + x once, the fp32 gradient read-modify-write.  (The fp32 split-K partials - written by the
+        # kernel, re-read by the reduction: 8 * nsplit * Cout * Ktot bytes - are implementation traffic; they show up in the
+        # PMC 'traffic' figure, not here.)
+        wbytes = 2.0 * (M * u.cout + N * H * W * u.cin) + 8.0 * u.cout * ktot
+        wtarget = self.wgrad_target(u, partial, nsplit, u.cout, ktot, u.cin, u.k, 0)
         # dgrad: dY + weights in, dx out (+ residual gradient / fused BatchNorm operands when present)
         dbytes = 2.0 * (M * u.cout + N * H * W * u.cin + u.cout * ktot)
         # the weight gradient only feeds the optimizer: it runs on the side stream, concurrently
@@ -461,9 +510,9 @@ class Engine:
             ss = self.stream(dev)
             if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
                 self.timed('conv3x3_wgrad_halo', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
-                           u.weight.grad, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+                           wtarget, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             else:
-                self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, u.weight.grad, N, H, W, u.cin, Ho,
+                self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, wtarget, N, H, W, u.cin, Ho,
                            Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
             if u.bias is not None:
                 lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)

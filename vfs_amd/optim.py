@@ -1,5 +1,8 @@
-"""Fused SGD over the tracker's flat parameter arena: one HIP launch per step
-(torch.optim.SGD semantics of configs/r*_*.py:134: lr, momentum, weight_decay; dampening 0)."""
+"""Fused SGD over the tracker's flat parameter arena (torch.optim.SGD semantics of configs/r*_*.py:134: lr, momentum,
+weight_decay; dampening 0): one HIP launch per contiguous range of TRAINABLE parameters (one launch for the shipped
+configs).  Parameters with requires_grad=False are never touched - the reference's optimizer does not hold them, so
+they get neither weight decay nor momentum.  The momentum arena is exposed through `state[p]['momentum_buffer']`
+(views), so `state_dict()` / `load_state_dict()` - what mmcv's checkpoint hook and `--resume-from` use - carry it."""
 import torch
 
 from .engine import shared_engine
@@ -11,21 +14,62 @@ class SGD(torch.optim.Optimizer):
         params = [p for p in model.parameters() if p.requires_grad]
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._buf = None
+        self._segments = None
 
     def zero_grad(self, set_to_none=False):
         f = self.model._ensure_arena()
         f['grads'].zero_()
 
+    def _arena(self):
+        """momentum arena + the contiguous arena ranges that hold trainable parameters"""
+        f = self.model._ensure_arena()
+        flat = f['params']
+        if self._buf is None or self._buf.shape != flat.shape or self._buf.device != flat.device:
+            old = {id(p): st.get('momentum_buffer') for p, st in self.state.items()}
+            self._buf = torch.zeros_like(flat)
+            self._segments = None
+            for p, o in zip(f['plist'], f['offsets']):
+                if not p.requires_grad:
+                    continue
+                view = self._buf[o:o + p.numel()].view(p.shape)
+                prev = old.get(id(p))
+                if prev is not None:              # a state restored before the arena existed
+                    view.copy_(prev)
+                self.state[p]['momentum_buffer'] = view
+        key = tuple(p.requires_grad for p in f['plist'])
+        if self._segments is None or self._segments[0] != key:
+            segs = []
+            for p, o in zip(f['plist'], f['offsets']):
+                if not p.requires_grad:
+                    continue
+                end = o + (p.numel() + 3) // 4 * 4
+                if segs and segs[-1][1] == o:
+                    segs[-1][1] = end
+                else:
+                    segs.append([o, end])
+            self._segments = (key, segs)
+        return f, self._segments[1]
+
     @torch.no_grad()
     def step(self, closure=None):
-        f = self.model._ensure_arena()
+        f, segs = self._arena()
         flat, g = f['params'], f['grads']
-        if self._buf is None or self._buf.shape != flat.shape or self._buf.device != flat.device:
-            self._buf = torch.zeros_like(flat)
         grp = self.param_groups[0]
         eng = shared_engine()
-        eng.lib.sgd_step(flat, g, self._buf, flat.numel(), float(grp['lr']), float(grp['momentum']),
-                         float(grp['weight_decay']), eng.stream(flat.device))
+        for lo, hi in segs:
+            eng.lib.sgd_step(flat[lo:hi], g[lo:hi], self._buf[lo:hi], hi - lo, float(grp['lr']), float(grp['momentum']),
+                             float(grp['weight_decay']), eng.stream(flat.device))
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the state tensors by copies: put them back into the momentum arena"""
+        super().load_state_dict(state_dict)
+        loaded = {id(p): st.get('momentum_buffer') for p, st in self.state.items()}
+        self._buf = None
+        f, _ = self._arena()
+        for p in f['plist']:
+            buf = loaded.get(id(p))
+            if buf is not None and p.requires_grad:
+                self.state[p]['momentum_buffer'].copy_(buf)
 
 
 def build_optimizer(model, cfg):

@@ -27,6 +27,23 @@ def build_pack_table(entries, device):
     return t, len(entries), tiles
 
 
+REDUCE_DTYPE = np.dtype([('partial', '<u8'), ('grad', '<u8'), ('nsplit', '<i4'), ('Cout', '<i4'), ('Ktot', '<i4'), ('Cin', '<i4'),
+                         ('KH', '<i4'), ('KW', '<i4'), ('stem', '<i4'), ('block_start', '<i4'), ('nblocks', '<i4'), ('pad', '<i4')])
+assert REDUCE_DTYPE.itemsize == 56
+
+
+def build_reduce_table(entries, device, max_blocks_per_record=2048):
+    """entries: list of (partial tensor, grad tensor, nsplit, Cout, Ktot, Cin, KH, KW, stem) -> (table uint8 tensor on the
+    device, nrecords, total_blocks) for vfs_wgrad_reduce_table (csrc/conv_wgrad.hip: 128 elements per workgroup and pass)."""
+    arr = np.zeros(len(entries), REDUCE_DTYPE)
+    start = 0
+    for i, (partial, grad, nsplit, cout, ktot, cin, kh, kw, stem) in enumerate(entries):
+        nb = min(max_blocks_per_record, (cout * ktot + 127) // 128)
+        arr[i] = (partial.data_ptr(), grad.data_ptr(), nsplit, cout, ktot, cin, kh, kw, stem, start, nb, 0)
+        start += nb
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(entries), start
+
+
 def small_map(H, W):
     """mirror of vfs_small_map (csrc/vfs_conv.h): whole images of <= 8x8 pixels, two per halo tile"""
     return H <= 8 and W <= 8 and H * W * 100 >= 64 * HALO_MIN_FILL
@@ -108,7 +125,7 @@ def igemm_ksplit(M, Cout, Ktot, target_blocks=256):
     return ks, 1024 + tiles * ks * 128 * bc
 
 
-def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
+def wgrad_splits(M, Cout, Ktot, target_blocks=256, halo_geom=None):
     """Split-K plan for the wgrad kernels: (nsplit, pix_per_split).  halo_geom = (N, H, W, Cin)
     selects the plan of the 3x3 halo kernel (workgroup = 64 cin x 64 cout x 9 taps, split over
     128-pixel spatial tiles)."""
@@ -118,7 +135,7 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=1024, halo_geom=None):
         colblocks = (Cin // 64) * (Cout // 64)
         # every workgroup writes a 9x64x64 fp32 partial (147 KB): keep ~2 workgroups per CU so
         # the split-K traffic (blocks x 147 KB, written then re-read) stays well below the MFMA time
-        tb = int(os.environ.get('VFS_WGRAD_TB', 512))   # measured on all four layer shapes: 512 > 256 > 768 > 1024
+        tb = int(os.environ.get('VFS_WGRAD_TB', 256))   # whole-step A/B on MI355X (the kernels run beside the dgrad chain): 256 > 128 > 512 (R50 9.86 -> 9.51 ms with TBG 256)
         nsplit = max(1, min(ntiles, (tb + colblocks - 1) // colblocks))
         tps = (ntiles + nsplit - 1) // nsplit
         nsplit = (ntiles + tps - 1) // tps

@@ -259,7 +259,9 @@ class SimSiamBaseTracker(BaseTracker):
             self._gs = None
             return self._hip_forward_train(imgs)
         f = self._ensure_arena()              # recorded chains hold raw pointers into the parameter / gradient arenas
-        key = (tuple(imgs.shape), imgs.dtype, dev, self.training, id(shared_engine()), mode,
+        # recorded chains hold raw pointers into the engine's buffers: any (re)allocation there - another model attached
+        # to the shared engine, a larger workspace, repacked weights - bumps eng.generation and forces a re-record
+        key = (tuple(imgs.shape), imgs.dtype, dev, self.training, id(shared_engine()), shared_engine().generation, mode,
                f['params'].data_ptr(), f['grads'].data_ptr())
         gs = getattr(self, '_gs', None)
         if gs is None or gs.key != key:
@@ -336,9 +338,22 @@ class SimSiamBaseTracker(BaseTracker):
         gs.bwd.replay()
         self._ctx = None
 
+    def _check_trainable(self):
+        """the fused step implements batch-statistics BatchNorm and gradients for EVERY parameter; frozen stages /
+        norm_eval / partial_bn (resnet.py:577-654) would need the eval-mode BatchNorm backward (dx = g * scale, no
+        statistics) and skipped weight gradients - refuse instead of returning wrong gradients"""
+        for name, m in self.named_modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and not m.training:
+                raise NotImplementedError(f'{name}: BatchNorm in eval mode inside forward_train (frozen_stages / norm_eval / '
+                                          'partial_bn) is not on the HIP training path')
+        for name, p in self.named_parameters():
+            if not p.requires_grad:
+                raise NotImplementedError(f'{name}: requires_grad=False inside forward_train is not on the HIP training path')
+
     def _hip_forward_train(self, imgs):
         eng = shared_engine()
         dev = imgs.device
+        self._check_trainable()
         self.backbone.attach(eng)
         self.img_head.attach(eng)
         self._ensure_arena()
@@ -376,16 +391,25 @@ class SimSiamBaseTracker(BaseTracker):
         gl = gl.contiguous().float()
         eng.lib.cosine_loss_bwd(p[:Nv], z[:Nv], p[Nv:], z[Nv:], gl, dp[:Nv], dp[Nv:], Nv, p.shape[1], c['T'],
                                 c['K'], c['neg'], c['weight'], s)
-        gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
-        if eng.collectives_on:
-            eng.wgrad_join(dev)
-        self._allreduce_range(self._head_range())
-
-        def stage_done(module):      # gradients of `module` are final: reduce them while earlier stages run
+        # split-K partials of the weight gradients are reduced by one table-driven launch per stage (data parallel: the
+        # stage's gradients must be final before their all-reduce) or one for the whole step (single process)
+        eng.defer_wgrad = os.environ.get('VFS_WGRAD_BATCH', '1') == '1'
+        try:
+            gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
             if eng.collectives_on:
+                eng.flush_wgrad(dev)
                 eng.wgrad_join(dev)
-                self._allreduce_range(self._param_range(module))
-        self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat}, on_stage_done=stage_done)
+            self._allreduce_range(self._head_range())
+
+            def stage_done(module):      # gradients of `module` are final: reduce them while earlier stages run
+                if eng.collectives_on:
+                    eng.flush_wgrad(dev)
+                    eng.wgrad_join(dev)
+                    self._allreduce_range(self._param_range(module))
+            self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat}, on_stage_done=stage_done)
+            eng.flush_wgrad(dev)
+        finally:
+            eng.defer_wgrad = False
         eng.wgrad_join(dev)
         eng.record(self._wait_works)
         self._ctx = None
