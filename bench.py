@@ -8,7 +8,14 @@ One "step" = one pass of the hot path over one per-GPU batch: imgs [32, 2, 3, T,
 Default = the configuration BASELINE.json's metric is quoted on ("frame-pairs/sec (train) R50 256^2 at
 1/2/4/8 GPUs": configs[2], ResNet-50 r5_1xNx2, T=1 -> 32 frame-pairs per GPU per step; it fits one GPU);
 --model r18: configs[1], ResNet-18 r2_1xNx8, T=4 -> 128 frame-pairs.  Inputs are resident in HBM before
-the timed region.  Prints ONE JSON line on rank 0."""
+the timed region.  Prints ONE JSON line on rank 0.
+
+  python bench.py --workload davis [--model r50|r18] [--precision fp32|bf16] --steps K --warmup W
+
+BASELINE.json configs[3] (the second headline metric's workload): DAVIS label propagation on a synthetic
+480x854 clip with the reference's test-time settings; one "step" = one propagated frame (backbone of the frame,
+L2 normalisation, masked attention over first + 20 preceding frames, upsample / min-max / argmax).  Same JSON
+schema (`roofline` on the in-mask affinity FLOP, `cpu_baseline` = the C oracle per frame).  N > 1: replicas."""
 import argparse
 import json
 import os
@@ -22,7 +29,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector peak, same guide
 PEAK_HBM_GBS = 8000.0       # HBM3E, same guide
+# algorithmic work per frame-pair (3 x forward FLOP; ideal-fusion activation traffic, bf16)
+WORK_PER_PAIR = {(50, 256): (64.2e9, 232e6), (50, 224): (49.2e9, 178e6), (50, 512): (256.4e9, 929e6),
+                 (18, 256): (28.4e9, 52e6), (18, 224): (21.8e9, 40e6)}
 
 
 def log(*a):
@@ -75,6 +86,151 @@ def cpu_baseline(depth, size, threads):
                        f'1 warm-up + {n} timed steps, {dt * 1e3:.0f} ms/step')
 
 
+def davis_cpu_baseline(depth, threads):
+    """The C oracle (oracle/exact_oracle.c: the reference's fp32 evaluation arithmetic) on the host cores, one frame of the
+    same workload: ResNet stem..res4 of ONE 480x854 frame + ONE propagation step over 21 key frames + post-processing."""
+    import numpy as np
+    os.environ['OMP_NUM_THREADS'] = str(threads)
+    from oracle import exact_oracle as X
+    from oracle import vfs_oracle as O
+    ref = O.ResNet(depth, strides=(1, 2, 1, 1), out_indices=(2,))
+    O.fill_state_dict_(ref, seed=5)
+    sd = ref.state_dict()
+    H, W, h, w = 480, 854, 60, 107
+    C = 256 if depth == 18 else 1024
+    radius = 12 if depth == 18 else 18
+    frame = np.random.RandomState(0).randn(1, 3, H, W).astype(np.float32)
+    t0 = time.perf_counter()
+    X.resnet_eval(sd, depth, frame, strides=(1, 2, 1, 1), out_indices=(2,))
+    t_bb = time.perf_counter() - t0
+    rs = np.random.RandomState(1)
+    bank = X.l2norm_rows(rs.randn(22 * h * w, C).astype(np.float32)).reshape(22, h * w, C)
+    sbank = rs.rand(22, h * w, 4).astype(np.float32)
+    t0 = time.perf_counter()
+    out = X.labelprop(bank, sbank, 21, [0] + list(range(1, 21)), h, w, radius, 10, 0.07)
+    t_lp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    X.seg_postprocess(out, h, w, H, W)
+    t_pp = time.perf_counter() - t0
+    tot = t_bb + t_lp + t_pp
+    return dict(value=1.0 / tot, unit='frames/s', cores=threads, kind='port',
+                sample=f'C oracle (fp32, gcc -O3 + OpenMP, {threads} threads), ONE 480x854 frame of the same workload: R{depth} stem..res4 '
+                       f'{t_bb:.2f} s + propagation over 21 key frames {t_lp:.2f} s + post-processing {t_pp:.2f} s')
+
+
+def bench_davis(args, depth, dev, world, rank):
+    """BASELINE.json configs[3]: DAVIS-2017 label propagation, synthetic 480x854 clip, the reference's test-time config"""
+    import numpy as np
+    import vfs_amd
+    from oracle import vfs_oracle as O      # deterministic weight filler only (no checkpoint on the box)
+    from vfs_amd.engine import shared_engine
+    from vfs_amd.labelprop import mask_pairs
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    tc = vfs_amd.ConfigDict(cfg.test_cfg)
+    tc['precision'] = args.precision
+    bb = dict(cfg.model['backbone'])
+    bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']          # tools/test.py:129-133
+    model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
+    ref = O.VanillaTracker(depth, dict(tc))
+    O.fill_state_dict_(ref, seed=5)
+    model.load_state_dict(ref.state_dict(), strict=False)
+    model.to(dev).eval()
+    K, Wm = args.steps, max(1, args.warmup)
+    H, W = 480, 854
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    base = torch.randn(1, 1, 3, 1, H, W, device=dev, generator=g)           # a slowly drifting scene: propagation is not pure noise
+    imgs = base + 0.15 * torch.randn(1, 1, 3, K + 1, H, W, device=dev, generator=g)
+    yy, xx = np.mgrid[0:H, 0:W]
+    seg = np.zeros((H, W), np.uint8)
+    seg[(yy > 100) & (yy < 300) & (xx > 150) & (xx < 400)] = 1
+    seg[(yy > 250) & (yy < 420) & (xx > 500) & (xx < 760)] = 2
+    seg[(yy - 120) ** 2 + (xx - 650) ** 2 < 80 ** 2] = 3
+    seg_t, meta = torch.from_numpy(seg)[None], [dict(original_shape=(H, W, 3))]
+    eng = shared_engine()
+
+    def run(clip):
+        return model(clip, return_loss=False, ref_seg_map=seg_t, img_meta=meta)
+    run(imgs[:, :, :, :Wm + 1])            # W untimed propagated frames (allocations, weight repack)
+    torch.cuda.synchronize()
+    log(f'{Wm} warm-up frames done')
+
+    def timed():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(imgs)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        tm = torch.tensor([d], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item()), out
+    dt, out = timed()
+    log(f'{K} propagated frames: {dt / K * 1e3:.3f} ms/frame')
+    C = 256 if depth == 18 else 1024
+    radius = int(tc['neighbor_range']) // 2
+    res = {'metric': f'DAVIS label propagation frames/sec (R{depth} res4, 480x854, first + 20 preceding key frames)',
+           'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': dt / K * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16',
+           'data': 'synthetic',
+           'config': {'workload': f'VanillaTracker.forward_test (BASELINE configs[3]): ResNet-{depth} stem..res4 at stride 8 + masked '
+                                  f'attention (top-10, tau 0.07, radius {radius}, first + 20 preceding frames) + upsample/min-max/argmax, '
+                                  f'one {K + 1}-frame 480x854 clip per GPU, {args.precision} evaluation path',
+                      'frames_per_clip': K + 1, 'parallelism': f'replicas x{world}'},
+           'labels_present': sorted(int(v) for v in np.unique(out[0][-1]))}
+    if rank == 0 and not args.no_roofline:
+        eng.prof = []
+        run(imgs)
+        torch.cuda.synchronize()
+        prof, eng.prof = eng.prof, None
+        agg = {}
+        for kind, flops, e0, e1, nbytes in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+            a[3] += nbytes
+        tot = sum(v[1] for v in agg.values())
+        peak = PEAK_F32_TFLOPS if args.precision == 'fp32' else PEAK_BF16_TFLOPS
+
+        def family(kind):
+            fl, tm, cnt, nb = agg[kind]
+            hbm_bound = nb / (PEAK_HBM_GBS * 1e9) >= fl / (peak * 1e12)
+            ach, pk, unit = (nb / tm / 1e9, PEAK_HBM_GBS, 'GB/s') if hbm_bound else (fl / tm / 1e12, peak, 'TFLOP/s')
+            return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': pk, 'unit': unit, 'frac': ach / pk,
+                    'traffic': None, 'launches': cnt, 'avg_launch_ms': tm / cnt * 1e3, 'time_share_of_kernels': tm / tot,
+                    'algorithmic_flop_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
+        kind = max(agg, key=lambda k: agg[k][1])
+        res['roofline'] = family(kind)
+        res['roofline']['note'] = ('FLOP = the affinity INSIDE the circular mask only (2 * C * in-mask (query, key) pairs per key frame; the '
+                                   'dense T*HW x HW product the reference executes is not counted); peak = dense '
+                                   + ('fp32-input MFMA (157.3 TFLOP/s)' if args.precision == 'fp32' else 'bf16 MFMA (2.5 PFLOP/s)'))
+        res['roofline']['families'] = [family(k) for k in sorted(agg, key=lambda k: -agg[k][1]) if k != kind and agg[k][1] / tot >= 0.03]
+        res['roofline']['in_mask_pairs_per_key_frame'] = mask_pairs(60, 107, radius)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('timing the C oracle on one frame ...')
+        import subprocess
+        threads = min(os.cpu_count() or 1, 64)
+        code = (f'import sys, json; sys.path.insert(0, {REPO!r}); import bench; '
+                f'print("CPUBASE " + json.dumps(bench.davis_cpu_baseline({depth}, {threads})))')
+        try:
+            o = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=400)
+            line = [ln for ln in o.stdout.splitlines() if ln.startswith('CPUBASE ')]
+            res['cpu_baseline'] = json.loads(line[0][8:]) if line else dict(value=None, unit='frames/s', cores=threads, kind='port',
+                                                                            sample='failed: ' + o.stderr[-300:])
+        except subprocess.TimeoutExpired:
+            res['cpu_baseline'] = dict(value=None, unit='frames/s', cores=threads, kind='port', sample='timed out after 400 s')
+    if rank == 0:
+        print(json.dumps(res))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -83,6 +239,8 @@ def main():
     ap.add_argument('--model', default='r50', choices=['r18', 'r50'])
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--batch', type=int, default=32, help='videos per GPU (configs: videos_per_gpu=32)')
+    ap.add_argument('--workload', default='train', choices=['train', 'davis'])
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='davis workload: evaluation precision')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -103,6 +261,8 @@ def main():
     import vfs_amd
     from vfs_amd.engine import shared_engine
     depth = 18 if args.model == 'r18' else 50
+    if args.workload == 'davis':
+        return bench_davis(args, depth, dev, world, rank)
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
     torch.manual_seed(0)
     model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev).train()
@@ -204,33 +364,43 @@ def main():
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
             a[3] += nbytes
+        # HBM bytes per launch of every family from the committed PMC passes (tools/gpu_pmc.sh + make_traffic_json.py:
+        # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as the guide prescribes for gfx950)
+        tclasses, tsource = {}, None
+        for tag in ('r02', 'r01'):
+            tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_{args.model}.json')
+            if os.path.exists(tpath):
+                tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
+                break
+
+        def family(kind):
+            """roofline entry of one kernel family: which roof binds (time at the dense MFMA peak for its algorithmic FLOP vs
+            time at the HBM peak for its algorithmic bytes - every operand of a launch once), achieved / peak"""
+            fl, tm, cnt, nb = agg[kind]
+            tr = tclasses.get(kind, {}).get('hbm_bytes_per_launch')
+            hbm_bound = nb / (PEAK_HBM_GBS * 1e9) >= fl / (PEAK_BF16_TFLOPS * 1e12)
+            ach, peak, unit = (nb / tm / 1e9, PEAK_HBM_GBS, 'GB/s') if hbm_bound else (fl / tm / 1e12, PEAK_BF16_TFLOPS, 'TFLOP/s')
+            return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': peak, 'unit': unit,
+                    'frac': ach / peak, 'traffic': tr, 'launches_per_step': cnt / args.steps, 'avg_launch_ms': tm / cnt * 1e3,
+                    'time_share_of_step': tm / dt_prof, 'algorithmic_bytes_per_launch': nb / cnt,
+                    'algorithmic_flop_per_launch': fl / cnt, 'GB/s': nb / tm / 1e9, 'TFLOP/s': fl / tm / 1e12}
         kind = max(agg, key=lambda k: agg[k][1])
-        fl, tm, cnt, nb = agg[kind]
-        ach = fl / tm / 1e12
-        traffic = None   # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh), if present
-        tpath = os.path.join(REPO, 'profiles', f'r01_traffic_{args.model}.json')
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('classes', {}).get(kind, {}).get('hbm_bytes_per_launch')
-        # which roof binds the class: time at the dense bf16 MFMA peak for the algorithmic FLOP vs time at the
-        # HBM peak for the algorithmic bytes (every operand of a launch once; Engine.timed) - peaks from
-        # MI355X_MICROARCH.md: 2.5 PFLOP/s, 8 TB/s.  `traffic` is what the PMC passes actually counted.
-        t_launch = tm / cnt
-        t_mfma = fl / cnt / (PEAK_BF16_TFLOPS * 1e12)
-        t_hbm = nb / cnt / (PEAK_HBM_GBS * 1e9)
-        extra = {'algorithmic_flop_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt, 'launches': cnt,
-                 'avg_launch_ms': t_launch * 1e3, 'time_share_of_step': tm / dt_prof,
-                 'mfma': {'achieved_TFLOP/s': ach, 'frac': ach / PEAK_BF16_TFLOPS},
-                 'hbm': {'achieved_GB/s': nb / tm / 1e9, 'frac': nb / tm / 1e9 / PEAK_HBM_GBS,
-                         'measured_traffic_GB/s': (traffic or 0.0) / t_launch / 1e9},
-                 'measured_over': f'{args.steps} eager single-stream steps right after the timed region, {dt_prof / args.steps * 1e3:.2f} ms/step',
-                 'others': {k: {'TFLOP/s': v[0] / v[1] / 1e12, 'GB/s': v[3] / v[1] / 1e9, 'time_share_of_step': v[1] / dt_prof}
-                            for k, v in agg.items() if k != kind}}
-        if t_hbm > t_mfma:
-            res['roofline'] = {'kernel': kind, 'bound': 'hbm', 'achieved': extra['hbm']['achieved_GB/s'], 'peak': PEAK_HBM_GBS,
-                               'unit': 'GB/s', 'frac': extra['hbm']['frac'], 'traffic': traffic, **extra}
-        else:
-            res['roofline'] = {'kernel': kind, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic, **extra}
+        res['roofline'] = family(kind)
+        res['roofline']['traffic_source'] = tsource
+        res['roofline']['measured_over'] = (f'{args.steps} eager single-stream steps right after the timed region, '
+                                            f'{dt_prof / args.steps * 1e3:.2f} ms/step (HIP events around every launch)')
+        # every other family that takes >= 3 % of the step (BatchNorm / streaming kernels included), and what is left
+        fams = sorted((k for k in agg if k != kind), key=lambda k: -agg[k][1])
+        res['roofline']['families'] = [family(k) for k in fams if agg[k][1] / dt_prof >= 0.03]
+        res['roofline']['small_families_time_share'] = sum(agg[k][1] for k in fams if agg[k][1] / dt_prof < 0.03) / dt_prof
+        res['roofline']['unlabelled_time_share'] = max(0.0, 1.0 - sum(v[1] for v in agg.values()) / dt_prof)
+    work = WORK_PER_PAIR.get((depth, args.size))
+    if rank == 0 and work:
+        # step level (SURVEY.md section 8d): algorithmic FLOP (3 x forward) and ideal-fusion bytes per frame-pair
+        pps = pairs_per_step / world / (dt / args.steps)       # per GPU
+        res['step_roofline'] = {'flop_per_pair': work[0], 'ideal_bytes_per_pair': work[1], 'TFLOP/s_per_gpu': pps * work[0] / 1e12,
+                                'frac_of_mfma_peak': pps * work[0] / 1e12 / PEAK_BF16_TFLOPS, 'GB/s_per_gpu': pps * work[1] / 1e9,
+                                'frac_of_hbm_peak': pps * work[1] / 1e9 / PEAK_HBM_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample) ...')
         res['cpu_baseline'] = cpu_baseline_subprocess(depth, args.size, min(os.cpu_count() or 1, 64))

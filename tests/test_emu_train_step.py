@@ -455,6 +455,10 @@ def test_rccl_one_rank_group_equals_no_collectives(gpu_backend, monkeypatch):
         torch.cuda.synchronize()
         return losses, {k: v.clone() for k, v in m.state_dict().items()}, eng
 
+    # the single-process step normally takes shortcuts a SyncBN step cannot (statistics finished in the consumer's prologue,
+    # statistics from the stored output for tiny groups): switch them off so that both runs execute the same reduction kernels
+    monkeypatch.setattr(engine, 'FIN_FUSE', False)
+    monkeypatch.setenv('VFS_RAW_STATS', '0')
     base_losses, base_sd, _ = run()
     monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
     monkeypatch.setenv('MASTER_PORT', '29533')

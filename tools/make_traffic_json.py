@@ -12,9 +12,17 @@ CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels
     'conv_igemm': ('conv_igemm_kernel',),
     'conv3x3_halo': ('conv3x3_halo_kernel',),
     'stem_fwd': ('stem_fwd_direct_kernel',),
-    'conv_wgrad': ('conv_wgrad_kernel',),          # (the wgrad_reduce launch that follows every weight gradient is not attributed)
+    'conv_wgrad': ('conv_wgrad_kernel',),          # (the table-driven reduction of the partials is its own class)
     'conv3x3_wgrad_halo': ('conv3x3_wgrad_halo_kernel',),
     'stem_wgrad': ('stem_wgrad_fused_kernel',),
+    'wgrad_reduce': ('wgrad_reduce_',),
+    'bn_act': ('bn_act_kernel',),
+    'bn_bwd_apply': ('bn_bwd_apply_kernel',),
+    'bn_bwd_reduce': ('bn_bwd_reduce_kernel', 'stem_pool_bn_bwd_reduce'),
+    'bn_stats': ('bn_reduce_', 'bn_stats_raw', 'bn_finalize'),
+    'bn_relu_maxpool': ('bn_relu_maxpool_kernel',),
+    'pack_weights': ('pack_weights_kernel',),
+    'sgd': ('sgd_kernel',),
 }
 NOT_A_LAUNCH = ()
 
@@ -40,7 +48,7 @@ def main():
             json.dump(d, open(path, 'w'), indent=1)
             print(path, json.dumps(d['classes']))
         return
-    model, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'r01')
+    model, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'r02')
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     raw = json.load(open(os.path.join(repo, 'gpurun_out', f'pmc_{model}.json')))
     kernels = {}

@@ -27,6 +27,7 @@
 #include "vfs_conv.h"
 
 #define OOB_OFFSET 0xFFFFFFF0u   // >= any num_records: the load returns zeros
+#define XCD_SWIZZLE 1
 
 // ONEK ("single buffer"): ONE operand buffer instead of two - the arena shrinks from 64 to 37 KB and, with the
 // smaller register budget, three to four workgroups share a CU instead of two.  The 1x1 convolutions are HBM-bound
@@ -66,7 +67,16 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
   const int lane = t & 63, wave = t >> 6;
   const int wc = wave >> 1, wp = wave & 1;
   const int ncb = (a.Cout + BC - 1) / BC;
-  const int pb = blockIdx.x / ncb, cb = blockIdx.x - pb * ncb;
+  // XCD-aware tile order: hardware workgroup b runs on XCD b % 8 (observed dispatch; a speed matter only), each XCD with its
+  // own L2.  Give every XCD a CONTIGUOUS range of logical tiles so that the ncb channel tiles of a pixel block - which read
+  // the same 128 input rows - and neighbouring pixel blocks of a 3x3 gather meet in one L2 instead of eight (bijective
+  // remap for any grid size, cdna_hip_programming.md T1).
+  int bx = blockIdx.x;
+  if (XCD_SWIZZLE && a.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
+  }
+  const int pb = bx / ncb, cb = bx - pb * ncb;
   const int m0 = pb * BP, c0 = cb * BC;
   const int j = t & 7, row0 = t >> 3;
 
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
   // depend on the arrival order - and goes on to the epilogue.  Tickets return to zero for the next launch.
   if (ksplit > 1) {
     __shared__ unsigned s_ticket;
-    const int tile = blockIdx.x;
+    const int tile = bx;
     unsigned* tickets = reinterpret_cast<unsigned*>(a.ks_ws);
     float* parts = a.ks_ws + KS_TICKETS + (size_t)tile * ksplit * (TM * TN * 1024);
     float* mine = parts + (size_t)kslice * (TM * TN * 1024);
@@ -422,6 +432,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
 
 // ------------------------------------------------------------------ host launcher
 int vfs_option_igemm_bc = 0;     // 64: force the 64-channel tile (A/B knob)
+int vfs_option_igemm_xcd = 1;    // XCD-aware tile order (A/B knob)
 int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a K-step before its MFMAs (prepared, not yet measured)
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
 int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
@@ -445,7 +456,9 @@ static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
   return vfs_check_launch("conv_igemm");
 }
 
-int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
+int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.xcd_swizzle = vfs_option_igemm_xcd;
   if (a.g.Ktot % 64 != 0 || a.Cout % 8 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: K%64 or Cout%8");
   if (vfs_option_halo && a.g.C % 64 == 0 && (size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 < 0xFFFFFFF0ull &&
       vfs_conv_halo_eligible(a, mode))

@@ -61,6 +61,7 @@ struct ConvArgs {
   // partials in slice order (deterministic) and runs the epilogue.
   float* ks_ws = nullptr;
   int ksplit = 1;
+  int xcd_swizzle = 0;   // implicit-GEMM kernel: XCD-aware logical tile order (set by the dispatcher)
 };
 #define KS_TICKETS 1024
 

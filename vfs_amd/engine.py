@@ -187,7 +187,9 @@ class Engine:
             self._pack_key = key
             self.generation += 1
         tab, n, total = self._pack
-        self.lib.pack_weights(tab, n, total, self.stream(dev))
+        nel = sum(u.weight.numel() for u in self.units)
+        self.timed('pack_weights', (0.0, 4.0 * nel + 2.0 * sum(u.weight.numel() * (2 if u.wd is not None else 1) for u in self.units)), dev,
+                   self.lib.pack_weights, tab, n, total, self.stream(dev))
 
     # ------------------------------------------------------------------ forward primitives
     def conv_fwd(self, u, x, N, H, W, G, train, tag='', in_bn=None, defer_fin=False):
@@ -261,10 +263,11 @@ class Engine:
                     # the caller's next launch is bn_act on this output: it finishes the statistics in its prologue
                     self._pending_fin = (u, partial, nblk_g, float(mpg))
                 elif raw_stats:
-                    lib.bn_stats_raw_finalize(y, u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var,
+                    self.timed('bn_stats', (0.0, 2.0 * M * u.cout), dev, lib.bn_stats_raw_finalize, y, u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var,
                                               G, mpg, u.cout, float(mpg), float(bn.eps), float(bn.momentum), s)
                 elif self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
-                    lib.bn_reduce_partials(partial, u.sums, self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
+                    self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_reduce_partials, partial, u.sums,
+                               self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
                     self.allreduce(u.sums)
                     if defer_fin and FIN_FUSE and u.kind != 'stem':
                         # the bn_act that follows turns the all-reduced sums into scale / shift itself (any size)
@@ -273,7 +276,8 @@ class Engine:
                         lib.bn_finalize(u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var, G,
                                         u.cout, float(mpg * self.world), float(bn.eps), float(bn.momentum), s)
                 else:
-                    lib.bn_stats_finalize(partial, u.sums, self.bn_scratch(G, u.cout, dev), bn.weight.data, bn.bias.data,
+                    self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_stats_finalize, partial, u.sums,
+                               self.bn_scratch(G, u.cout, dev), bn.weight.data, bn.bias.data,
                                           u.bnp, bn.running_mean, bn.running_var, G, nblk_g, u.cout, float(mpg),
                                           float(bn.eps), float(bn.momentum), s)
                 u.nbt_pending = getattr(u, 'nbt_pending', 0) + G   # num_batches_tracked, flushed lazily
@@ -324,16 +328,18 @@ class Engine:
         dev = raw.device
         y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
         mpg = M // G if train else M
+        nbytes = 2.0 * M * u.cout * (2 + (res is not None) + (rres is not None))      # raw in, activation out, identity in
         fin = getattr(self, '_pending_fin', None)
         if fin is not None:
             assert fin[0] is u, 'deferred BatchNorm finalisation belongs to another unit'
             self._pending_fin = None
             bn = u.bn
-            self.lib.bn_act_fin(raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean, bn.running_var,
+            self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act_fin, raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean, bn.running_var,
                                 res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0, fin[3], float(bn.eps), float(bn.momentum),
                                 self.stream(dev))
             return y
-        self.lib.bn_act(raw, u.bnp, res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0, self.stream(dev))
+        self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act, raw, u.bnp, res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0,
+                   self.stream(dev))
         return y
 
     # ------------------------------------------------------------------ backward primitives
@@ -358,28 +364,31 @@ class Engine:
         if fused is not None and fused[0] is u:     # the producing dgrad already emitted the statistics rows
             partial, nblk = fused[1], fused[2]
         else:
-            lib.bn_bwd_reduce(g, ymask, raw, u.bnp, partial, M, C, mpg, ppb, rl, s)
+            self.timed('bn_bwd_reduce', (0.0, 2.0 * M * C * (2 + (ymask is not None))), dev, lib.bn_bwd_reduce, g, ymask, raw, u.bnp,
+                       partial, M, C, mpg, ppb, rl, s)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
+        abytes = 2.0 * M * C * (3 + (ymask is not None) + want_gm)      # g, raw in; dx out; activation (mask) in; masked gradient out
         if FIN_FUSE and not self.collectives_on and nblk // G <= FIN_MAX_ROWS:
             # few statistics rows: the apply pass sums them in its prologue (and writes bsums, dgamma, dbeta)
-            lib.bn_bwd_apply_fin(g, ymask, raw, u.bnp, partial, nblk // G, u.bsums, u.bn.weight.grad, u.bn.bias.grad, dx, gm, M, C,
+            self.timed('bn_bwd_apply', (0.0, abytes), dev, lib.bn_bwd_apply_fin, g, ymask, raw, u.bnp, partial, nblk // G, u.bsums, u.bn.weight.grad, u.bn.bias.grad, dx, gm, M, C,
                                  mpg, float(mpg), rl, s)
             return dx, gm
         self._bwd_sums(u, partial, G, nblk // G, C, dev)
-        lib.bn_bwd_apply(g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg, float(mpg * self.world), rl, s)
+        self.timed('bn_bwd_apply', (0.0, abytes), dev, lib.bn_bwd_apply, g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg,
+                   float(mpg * self.world), rl, s)
         return dx, gm
 
     def _bwd_sums(self, u, partial, G, bpg, C, dev):
         """partial (S1, S2) rows -> u.bsums (all-reduced for SyncBN) and dgamma / dbeta (local sums)"""
         s = self.stream(dev)
         if self.collectives_on:     # local sums + local dgamma / dbeta in one launch, then the SyncBN all-reduce of the sums
-            self.lib.bn_bwd_sums_paramgrad(partial, u.bsums, self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad,
-                                           G, bpg, C, s)
+            self.timed('bn_stats', (0.0, 8.0 * G * bpg * C), dev, self.lib.bn_bwd_sums_paramgrad, partial, u.bsums,
+                       self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad, G, bpg, C, s)
             self.allreduce(u.bsums)
         else:
-            self.lib.bn_bwd_sums_paramgrad(partial, u.bsums, self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad,
-                                           G, bpg, C, s)
+            self.timed('bn_stats', (0.0, 8.0 * G * bpg * C), dev, self.lib.bn_bwd_sums_paramgrad, partial, u.bsums,
+                       self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad, G, bpg, C, s)
 
     def flush_counters(self):
         """materialise the lazily counted BatchNorm.num_batches_tracked buffers"""
@@ -403,7 +412,8 @@ class Engine:
         nblk = (N * Hp * Wp) // ppb
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
-        lib.stem_pool_bn_bwd_reduce(gp, yp, idx, raw, xpool, u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
+        self.timed('bn_bwd_reduce', (0.0, (2.0 * 3 + 1.0) * N * Hp * Wp * C), dev, lib.stem_pool_bn_bwd_reduce, gp, yp, idx, raw, xpool,
+                   u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
         self._bwd_sums(u, partial, G, nblk // G, C, dev)
         return float(npg * H * W * self.world)
 

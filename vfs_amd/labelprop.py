@@ -50,6 +50,19 @@ def torch_nearest_resize(label, out_h, out_w):
     return label[ys][:, xs]
 
 
+def mask_pairs(h, w, radius):
+    """number of (query, key) pairs of one key frame inside the circular mask (affinity_utils.py:144-156: distance < radius);
+    radius <= 0: no mask -> (h*w)^2.  The ALGORITHMIC affinity work of a propagation step is 2 * C * pairs per key frame."""
+    if radius <= 0:
+        return float(h * w) ** 2
+    n = 0
+    for dy in range(-(radius - 1), radius):
+        for dx in range(-(radius - 1), radius):
+            if dy * dy + dx * dx < radius * radius:
+                n += max(0, h - abs(dy)) * max(0, w - abs(dx))
+    return float(n)
+
+
 def _block_feats(bb, ctx_blocks, stages):
     """(block index range) of every residual block of the listed stages, in network order"""
     sel, bi = [], 0
@@ -171,6 +184,7 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
             preds[0] = torch.from_numpy(ref).to(dev)
         if CO > 256:
             raise NotImplementedError('label propagation kernels: at most 256 classes')
+        pairs = mask_pairs(h, w, radius)
         partial = eng.ws('ws.segpost', 64 * CO * 2, F32, dev)
         lpws = eng.ws('ws.labelprop', 24 * h * w * 10 * 2, F32, dev)
         for f in range(1, clip_len):
@@ -180,11 +194,16 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
                 slots = [0] + slots                                 # frame 0 twice while f <= precede (as the reference)
             assert 0 <= non_mask_len < len(slots)                   # local_attention.py:272
             ks = (ctypes.c_int * len(slots))(*slots)
-            lp(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, non_mask_len, topk, temp, s)
+            nmask = len(slots) - non_mask_len
+            work = (2.0 * C * (nmask * pairs + non_mask_len * float(h * w) ** 2),          # in-mask affinity FLOP
+                    float(bank.element_size()) * (len(set(slots)) + 1) * h * w * C)         # every key / query row once
+            eng.timed('labelprop_f32' if exact else 'labelprop', work, dev, lp, bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w,
+                      C, CO, radius, non_mask_len, topk, temp, s)
             if input_onehot:
                 eng.lib.bilinear_resize_f32(sbank[f], preds[f], CO, h, w, out_h, out_w, 1, 0, s)
             else:
-                post(sbank[f], partial, preds[f], h, w, CO, out_h, out_w, s)
+                eng.timed('seg_postprocess', (0.0, 4.0 * h * w * CO + float(out_h * out_w)), dev, post, sbank[f], partial, preds[f],
+                          h, w, CO, out_h, out_w, s)
         arr = preds.cpu().numpy()
         if tracker.save_np:                                         # vanilla_tracker.py:184-193
             os.makedirs('.eval', exist_ok=True)

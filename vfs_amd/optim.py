@@ -57,8 +57,8 @@ class SGD(torch.optim.Optimizer):
         grp = self.param_groups[0]
         eng = shared_engine()
         for lo, hi in segs:
-            eng.lib.sgd_step(flat[lo:hi], g[lo:hi], self._buf[lo:hi], hi - lo, float(grp['lr']), float(grp['momentum']),
-                             float(grp['weight_decay']), eng.stream(flat.device))
+            eng.timed('sgd', (0.0, 20.0 * (hi - lo)), flat.device, eng.lib.sgd_step, flat[lo:hi], g[lo:hi], self._buf[lo:hi], hi - lo,
+                      float(grp['lr']), float(grp['momentum']), float(grp['weight_decay']), eng.stream(flat.device))
 
     def load_state_dict(self, state_dict):
         """torch's loader replaces the state tensors by copies: put them back into the momentum arena"""

@@ -257,7 +257,8 @@ class ResNet(nn.Module):
         # raw conv output at each argmax: the stem's BatchNorm backward reads it instead of gathering from raw
         xpool = eng.buf('backbone.pool_x', (N, Hp, Wp, 64), BF16, dev) if train else None
         npg = N // G if stem_train else N
-        eng.lib.bn_relu_maxpool(raw, stem.bnp, pooled, idx, xpool, N, Hs, Ws, 64, Hp, Wp, npg, eng.stream(dev))
+        eng.timed('bn_relu_maxpool', (0.0, 2.0 * N * Hs * Ws * 64 + N * Hp * Wp * 64 * (2.0 + (3.0 if train else 0.0))), dev,
+                  eng.lib.bn_relu_maxpool, raw, stem.bnp, pooled, idx, xpool, N, Hs, Ws, 64, Hp, Wp, npg, eng.stream(dev))
         ctx.update(stem_raw=raw, Hs=Hs, Ws=Ws, pooled=pooled, idx=idx, xpool=xpool, Hp=Hp, Wp2=Wp)
         x, h, w = pooled, Hp, Wp
         outs = {}

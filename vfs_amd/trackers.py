@@ -393,7 +393,7 @@ class SimSiamBaseTracker(BaseTracker):
                                 c['K'], c['neg'], c['weight'], s)
         # split-K partials of the weight gradients are reduced by one table-driven launch per stage (data parallel: the
         # stage's gradients must be final before their all-reduce) or one for the whole step (single process)
-        eng.defer_wgrad = os.environ.get('VFS_WGRAD_BATCH', '1') == '1'
+        eng.defer_wgrad = os.environ.get('VFS_WGRAD_BATCH', '0') == '1'
         try:
             gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
             if eng.collectives_on:
