@@ -42,7 +42,7 @@
 // Lane l of a DMA piece lands at piece_base + 16*l, so each lane FETCHES the (row, chunk) whose swizzled slot
 // that is.  Rows past the ragged end re-fetch a valid row (their outputs are masked by the epilogue).
 template <int BC, int MODE, int PIPE, bool FBN>
-__global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool ONEK = (PIPE == 1);
   constexpr int BP = 128;
   constexpr int WC = BC / 2;   // channels per wave
@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? 1 : (PIPE == 1 ? 3 : 2)) void conv
 // ------------------------------------------------------------------ host launcher
 int vfs_option_igemm_bc = 0;     // 64: force the 64-channel tile (A/B knob)
 int vfs_option_igemm_xcd = 1;    // XCD-aware tile order (A/B knob)
+int vfs_option_igemm_narrow_below = 513;   // 64-channel tiles when the 128-channel tiling has fewer tiles than this (0: never); whole-step A/B: R50 9.45 -> 9.32 ms
 int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a K-step before its MFMAs (prepared, not yet measured)
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
 int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
@@ -470,7 +471,10 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   if (a.g.dil != 1 && mode != GATHER_FWD) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: dilation is forward-only");
   if (a.bn.partial && (mode != GATHER_DGRAD || a.g.stride != 1))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: fused BatchNorm-backward statistics need a stride-1 dgrad");
-  const bool wide = (a.Cout % 128 == 0) && vfs_option_igemm_bc != 64;
+  // 128-channel tiles, unless that leaves the chip under-filled (deep stages: 16x16 / 8x8 maps, the head): with fewer than
+  // igemm_narrow_below tiles the 64-channel tile doubles the workgroups - two latency-bound K chains per CU instead of one
+  const long long tiles128 = (long long)((a.g.M + 127) / 128) * ((a.Cout + 127) / 128);
+  const bool wide = (a.Cout % 128 == 0) && vfs_option_igemm_bc != 64 && tiles128 >= vfs_option_igemm_narrow_below;
   const bool onek = vfs_option_igemm_onek >= 3 || (vfs_option_igemm_onek == 2 && a.g.KH * a.g.KW == 1) ||
                     (vfs_option_igemm_onek == 1 && a.g.Ktot == 64);
   // DMA ring: pure GEMM (1x1, stride 1, no padding), at least 4 K-steps, at most vfs_option_igemm_ring_tiles tiles

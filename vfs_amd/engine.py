@@ -22,6 +22,9 @@ BF16 = torch.bfloat16
 
 FIN_FUSE = os.environ.get('VFS_FIN_FUSE', '1') == '1'      # BatchNorm statistics finished in the apply kernels' prologue
 FIN_MAX_ROWS = int(os.environ.get('VFS_FIN_MAX_ROWS', '128'))   # ... for at most this many statistics rows per group
+# timing experiments only: kernel families (Engine.timed labels) whose launches are dropped - results are garbage, the step
+# time shows what the family costs on the critical path (no kernel here has data-dependent control flow)
+SKIP = frozenset(filter(None, os.environ.get('VFS_DEBUG_SKIP', '').split(',')))
 KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's Linear layers (slower as measured)
 
 
@@ -130,6 +133,8 @@ class Engine:
         """launch through `fn`; with profiling on, bracket it with events on the launch stream.
         work = algorithmic FLOP of the launch, or (FLOP, algorithmic HBM bytes: every operand once)"""
         flops, nbytes = work if isinstance(work, tuple) else (work, 0.0)
+        if SKIP and kind in SKIP:      # what-if measurement (VFS_DEBUG_SKIP=family,...): the step WITHOUT this family's launches
+            return 0
         if self.prof is None or dev.type != 'cuda':
             return fn(*args)
         pool = getattr(self, 'prof_pool', None)
