@@ -310,6 +310,20 @@ int vfs_crop_resize_flip_norm(const uint8_t* src, const int* boxes, const uint8_
 int vfs_xcorr_fwd(const vfs_bf16* z, const vfs_bf16* x, float* out, int nz, int nx, int Hz, int Wz, int H, int W, int C,
                   float scale, vfs_stream_t stream);
 
+/* training the probe (siamfc_tracker_base.py:364-387 `train_step`): backward of the cross-correlation.  g fp32
+ * [nx][H-Hz+1][W-Wz+1] = dL/d(responses); dz bf16 [nz][Hz][Wz][C] (summed over the search features that share an exemplar),
+ * dx bf16 [nx][H][W][C]; either may be NULL.  The gradients feed vfs_conv_wgrad / vfs_bias_grad of the 1x1 convs. */
+int vfs_xcorr_bwd(const vfs_bf16* z, const vfs_bf16* x, const float* g, vfs_bf16* dz, vfs_bf16* dx, int nz, int nx, int Hz, int Wz,
+                  int H, int W, int C, float scale, vfs_stream_t stream);
+/* the probe's losses on n response values (projects/siamfc-pytorch/siamfc/losses.py): mode 0 BalancedLoss (:24-41, param =
+ * neg_weight), mode 1 FocalLoss (:44-65, param = gamma; the normaliser mean(avg_weight) is differentiated through, as autograd
+ * does).  loss[0] = value; grad (may be NULL) = scale * dL/d(responses). */
+int vfs_siamfc_loss(const float* responses, const float* labels, float* loss, float* grad, int n, int mode, float param, float scale,
+                    vfs_stream_t stream);
+/* torch.optim.Adam (amsgrad off; default_config_base.py:33, siamfc_tracker_base.py:139-145) on flat fp32 arrays, step >= 1 */
+int vfs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, vfs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

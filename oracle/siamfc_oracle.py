@@ -38,3 +38,40 @@ class SiamConvFC(nn.Module):
 
     def forward(self, z, x):
         return fast_xcorr(self.z_convs(z), self.x_convs(x)) * self.out_scale
+
+
+# ---------------------------------------------------------------------------------------------
+# training the probe (siamfc_tracker_base.py:364-387, 456-500; losses.py) - pinned by tests/golden/siamfc_train.npz
+# ---------------------------------------------------------------------------------------------
+def create_labels(size, r_pos, r_neg, total_stride):
+    """siamfc_tracker_base.py:456-500: 1 within block distance r_pos / stride of the centre, 0.5 inside r_neg / stride, else 0"""
+    import numpy as np
+    n, c, h, w = size
+    x = np.arange(w) - (w - 1) / 2
+    y = np.arange(h) - (h - 1) / 2
+    x, y = np.meshgrid(x, y)
+    dist = np.abs(x) + np.abs(y)
+    rp, rn = r_pos / total_stride, r_neg / total_stride
+    lab = np.where(dist <= rp, np.ones_like(x), np.where(dist < rn, np.ones_like(x) * 0.5, np.zeros_like(x)))
+    return torch.from_numpy(np.tile(lab.reshape(1, 1, h, w), (n, c, 1, 1))).float()
+
+
+def balanced_loss(x, target, neg_weight=1.0):
+    """losses.py:24-41"""
+    pos, neg = target == 1, target == 0
+    w = torch.zeros_like(target)
+    w[pos] = 1 / pos.sum().float()
+    w[neg] = 1 / neg.sum().float() * neg_weight
+    w = w / w.sum()
+    return F.binary_cross_entropy_with_logits(x, target, w, reduction='sum')
+
+
+def focal_loss(x, target, gamma=2):
+    """losses.py:44-65 (the normaliser avg_weight.mean() stays in the graph)"""
+    ls = torch.clamp(x, max=0) - torch.log(1 + torch.exp(-torch.abs(x)))
+    lms = torch.clamp(-x, max=0) - torch.log(1 + torch.exp(-torch.abs(x)))
+    p = torch.sigmoid(x)
+    pw, nw = torch.pow(1 - p, gamma), torch.pow(p, gamma)
+    loss = -(target * pw * ls + (1 - target) * nw * lms)
+    avg = target * pw + (1 - target) * nw
+    return (loss / avg.mean()).mean()

@@ -15,3 +15,4 @@ from .optim import SGD, build_optimizer  # noqa: F401
 from .davis_eval import DavisEvaluator, evaluate_sequences  # noqa: F401
 from .checkpoint import from_pretrained_keys, to_pretrained_keys  # noqa: F401
 from .siamfc_heads import SiamConvFC, SiamFC  # noqa: F401
+from .siamfc import SiamFCProbe  # noqa: F401

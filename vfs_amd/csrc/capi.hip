@@ -367,6 +367,23 @@ int vfs_xcorr_fwd(const vfs_bf16* z, const vfs_bf16* x, float* out, int nz, int 
   a.z = z; a.x = x; a.out = out; a.nz = nz; a.nx = nx; a.Hz = Hz; a.Wz = Wz; a.H = H; a.W = W; a.C = C; a.scale = scale;
   return vfs_xcorr_fwd_launch(a, S(stream));
 }
+int vfs_xcorr_bwd(const vfs_bf16* z, const vfs_bf16* x, const float* g, vfs_bf16* dz, vfs_bf16* dx, int nz, int nx, int Hz, int Wz, int H, int W,
+                  int C, float scale, vfs_stream_t stream) {
+  if (!z || !x || !g || (!dz && !dx)) return vfs_set_error(VFS_ERR_ARG, "xcorr_bwd: null buffer");
+  XcorrBwdArgs a;
+  a.z = z; a.x = x; a.g = g; a.dz = dz; a.dx = dx; a.nz = nz; a.nx = nx; a.Hz = Hz; a.Wz = Wz; a.H = H; a.W = W; a.C = C; a.scale = scale;
+  return vfs_xcorr_bwd_launch(a, S(stream));
+}
+int vfs_siamfc_loss(const float* responses, const float* labels, float* loss, float* grad, int n, int mode, float param, float scale,
+                    vfs_stream_t stream) {
+  if (!responses || !labels || !loss) return vfs_set_error(VFS_ERR_ARG, "siamfc_loss: null buffer");
+  return vfs_siamfc_loss_launch(responses, labels, loss, grad, n, mode, param, scale, S(stream));
+}
+int vfs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, vfs_stream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq) return vfs_set_error(VFS_ERR_ARG, "adam_step: null buffer");
+  return vfs_adam_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
 int vfs_loss_means(const float* loss, float* means, int K, int N, vfs_stream_t stream) {
   if (!loss || !means) return vfs_set_error(VFS_ERR_ARG, "loss_means: null buffer");
   return vfs_loss_means_launch(loss, means, K, N, S(stream));

@@ -166,6 +166,20 @@ struct XcorrArgs {
   float scale;
 };
 int vfs_xcorr_fwd_launch(const XcorrArgs& a, hipStream_t s);
+struct XcorrBwdArgs {
+  const bf16_t* z;   // [nz][Hz][Wz][C]
+  const bf16_t* x;   // [nx][H][W][C]
+  const float* g;    // [nx][H-Hz+1][W-Wz+1] gradient wrt the responses
+  bf16_t* dz;        // [nz][Hz][Wz][C] or null
+  bf16_t* dx;        // [nx][H][W][C] or null
+  int nz, nx, Hz, Wz, H, W, C;
+  float scale;
+};
+int vfs_xcorr_bwd_launch(const XcorrBwdArgs& a, hipStream_t s);
+int vfs_siamfc_loss_launch(const float* x, const float* tgt, float* loss_out, float* grad, int n, int mode, float param, float scale,
+                           hipStream_t s);
+int vfs_adam_launch(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step,
+                    hipStream_t s);
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
 int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s);
 int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s);
