@@ -220,6 +220,10 @@ int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
 int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
                  float momentum, float weight_decay, vfs_stream_t stream);
 int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream);
+/* bf16 gradient buckets for the data-parallel all-reduce (opt-in, VFS_GRAD_BF16=1; the reference's DDP - apis/train.py:62-66 -
+ * reduces fp32): dst = bf16(src * scale) before the collective, dst = float(src) after it; buffers 16-byte aligned */
+int vfs_f32_to_bf16(const float* src, vfs_bf16* dst, long long n, float scale, vfs_stream_t stream);
+int vfs_bf16_to_f32(const vfs_bf16* src, float* dst, long long n, vfs_stream_t stream);
 
 /* ---- DAVIS label propagation (VanillaTracker.forward_test, vanilla_tracker.py:80-206) -------
  * F.normalize(dim=channel) of NHWC rows, once per frame when it enters the bank

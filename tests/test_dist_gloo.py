@@ -80,3 +80,21 @@ def test_command_tape_replay_equals_eager_with_collectives(tmp_path):
         assert np.array_equal(tape[0][k], eager[0][k]), k
         if k.startswith(('param/', 'grad/', 'buf/')):
             assert np.array_equal(tape[0][k], tape[1][k]), k
+
+
+def test_bf16_gradient_buckets(tmp_path):
+    """VFS_GRAD_BF16=1 (opt-in): the gradient arena is reduced in bf16 buckets - the mean gradient both ranks end up with equals the
+    fp32-bucket result to bf16 rounding, and the replicas still hold identical bits"""
+    from tests.emu_util import emu_lib
+    emu_lib()
+    f32 = _run_ranks(tmp_path, 'f32', dict(VFS_TEST_STEPS='1'))
+    b16 = _run_ranks(tmp_path, 'b16', dict(VFS_TEST_STEPS='1', VFS_GRAD_BF16='1'))
+    n = 0
+    for k in f32[0].files:
+        if k.startswith('grad/'):
+            assert np.array_equal(b16[0][k], b16[1][k]), k
+            a, b = b16[0][k].astype(np.float64), f32[0][k].astype(np.float64)
+            if np.abs(b).max() > 0:
+                assert np.abs(a - b).max() <= 2 ** -6 * np.abs(b).max(), k       # bf16 roundings of each rank's share (which may cancel) and of the sum
+                n += 1
+    assert n > 10

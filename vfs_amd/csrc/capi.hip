@@ -404,6 +404,10 @@ int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long lo
   return vfs_sgd_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, S(stream));
 }
 int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream) { return vfs_scale_launch(x, n, scale, S(stream)); }
+int vfs_f32_to_bf16(const float* src, vfs_bf16* dst, long long n, float scale, vfs_stream_t stream) {
+  return vfs_f32_to_bf16_launch(src, dst, n, scale, S(stream));
+}
+int vfs_bf16_to_f32(const vfs_bf16* src, float* dst, long long n, vfs_stream_t stream) { return vfs_bf16_to_f32_launch(src, dst, n, S(stream)); }
 
 int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stream_t stream) {
   return vfs_l2norm_rows_launch(x, y, P, C, S(stream));

@@ -344,3 +344,39 @@ int vfs_scale_launch(float* p, long long n, float scale, hipStream_t s) {
   hipLaunchKernelGGL(scale_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, p, n, scale);
   return vfs_check_launch("scale");
 }
+
+// bf16 gradient buckets for the data-parallel all-reduce (opt-in: halves the xGMI traffic of the 152.8 MB ResNet-50 gradient;
+// the reference's DDP reduces fp32): dst = bf16(src * scale) before the collective, dst = float(src) after it
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n, float scale) {
+  const long long n8 = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+    const float f[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale, b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
+    st16(dst + i * 8, pack8(f));
+  }
+  if (blockIdx.x == 0)
+    for (long long i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = f2bf(src[i] * scale);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n) {
+  const long long n8 = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float f[8];
+    unpack8(ld16(src + i * 8), f);
+    *reinterpret_cast<f32x4*>(dst + i * 8) = (f32x4){f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(dst + i * 8 + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+  }
+  if (blockIdx.x == 0)
+    for (long long i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = bf2f(src[i]);
+}
+int vfs_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, float scale, hipStream_t s) {
+  if (((size_t)src & 15) || ((size_t)dst & 15)) return vfs_set_error(VFS_ERR_ARG, "f32_to_bf16: 16-byte aligned buffers");
+  long long b = ((n >> 3) + 255) / 256;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, src, dst, n, scale);
+  return vfs_check_launch("f32_to_bf16");
+}
+int vfs_bf16_to_f32_launch(const bf16_t* src, float* dst, long long n, hipStream_t s) {
+  if (((size_t)src & 15) || ((size_t)dst & 15)) return vfs_set_error(VFS_ERR_ARG, "bf16_to_f32: 16-byte aligned buffers");
+  long long b = ((n >> 3) + 255) / 256;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, src, dst, n);
+  return vfs_check_launch("bf16_to_f32");
+}
