@@ -94,7 +94,7 @@ def test_bf16_gradient_buckets(tmp_path):
         if k.startswith('grad/'):
             assert np.array_equal(b16[0][k], b16[1][k]), k
             a, b = b16[0][k].astype(np.float64), f32[0][k].astype(np.float64)
-            if np.abs(b).max() > 0:
-                assert np.abs(a - b).max() <= 2 ** -6 * np.abs(b).max(), k       # bf16 roundings of each rank's share (which may cancel) and of the sum
+            if np.linalg.norm(b) > 1e-3:      # (the per-rank shares of some gradients cancel: compare norms, as the fp32 test does)
+                assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b), (k, np.linalg.norm(a - b) / np.linalg.norm(b))
                 n += 1
     assert n > 10
