@@ -244,6 +244,8 @@ __device__ __forceinline__ float vexp(float x) {
 }
 
 #define LPX_TOPK 10
+#define LPX_QCAP 8
+typedef __attribute__((ext_vector_type(2))) unsigned int vfs_u32x2q;
 #define LPX_NONE 0x7fffffff
 // total order of the top-k: larger score first, equal scores: smaller candidate id first
 __device__ __forceinline__ bool lpx_better(float s, int id, float ts, int tid) { return s > ts || (s == ts && id < tid); }
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a) 
   __shared__ int sKC[BKEY];
   __shared__ float sMV[BQ * 4 * LPX_TOPK];
   __shared__ int sMI[BQ * 4 * LPX_TOPK];
+  __shared__ __attribute__((aligned(16))) vfs_u32x2q sQue[LPX_QCAP * 256];   // per-lane candidate queues, slot-major
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int H = a.H, W = a.W, C = a.C, HW = H * W;
   const int tiles_x = (W + 7) >> 3;
@@ -291,6 +294,23 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a) 
   int ti[LPX_TOPK];
 #pragma unroll
   for (int i = 0; i < LPX_TOPK; ++i) { tv[i] = -INFINITY; ti[i] = LPX_NONE; }
+  // two-stage streaming top-k (as labelprop.hip): a candidate STRICTLY below thr - the best 10th-best score of the four
+  // lanes that share its query - has ten better candidates and cannot be in the query's top 10 under any tie rule; the
+  // others are queued in LDS and drained through the sorted insertion once per key block.  Exactness is untouched: the
+  // set that survives still contains the true top 10, and the insertion keeps the total order.
+  float thr = -INFINITY;
+  int qn = 0;
+  auto drain = [&]() {
+    for (int i = 0; __any(i < qn); ++i) {
+      const vfs_u32x2q e = sQue[i * 256 + t];
+      const bool on = i < qn;
+      lpx_insert(tv, ti, on ? __builtin_bit_cast(float, e[0]) : -INFINITY, on ? (int)e[1] : LPX_NONE);
+    }
+    qn = 0;
+    // lanes l and l+32 of this wave and the same lanes of the partner wave share a query; only the in-wave pair is cheap to reach
+    const float m = tv[LPX_TOPK - 1];
+    thr = fmaxf(m, __shfl_xor(m, 32));
+  };
 
   const int fpb = (a.nkeys + (int)gridDim.y - 1) / (int)gridDim.y;
   const int f_begin = (int)blockIdx.y * fpb, f_end = min(a.nkeys, f_begin + fpb);
@@ -355,8 +375,13 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a) 
         }
         const float sc = ok ? acc[rg] / a.temperature : -INFINITY;
         const int id = ok ? f * HW + cy * W + cx : LPX_NONE;
-        if (__any(lpx_better(sc, id, tv[LPX_TOPK - 1], ti[LPX_TOPK - 1]))) lpx_insert(tv, ti, sc, id);
+        if ((rg & 3) == 0 && __any(qn > LPX_QCAP - 4)) drain();
+        if (ok && sc >= thr) {
+          sQue[qn * 256 + t] = (vfs_u32x2q){__builtin_bit_cast(unsigned, sc), (unsigned)id};
+          ++qn;
+        }
       }
+      drain();
       __syncthreads();   // sKC is rewritten by the next key block
     }
   }
