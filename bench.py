@@ -260,6 +260,9 @@ def main():
 
     import vfs_amd
     from vfs_amd.engine import shared_engine
+    if os.environ.get('VFS_TAPE_PROFILE') == '1':
+        from vfs_amd._lib import Tape
+        Tape.slowest = {}
     depth = 18 if args.model == 'r18' else 50
     if args.workload == 'davis':
         return bench_davis(args, depth, dev, world, rank)
@@ -277,11 +280,24 @@ def main():
     batch = dict(imgs=imgs, label=torch.zeros(B, 1, device=dev))
     eng = shared_engine()
 
+    phases = [0.0] * 5 if os.environ.get('VFS_BENCH_PHASES') == '1' else None      # diagnostics: host wall time per call of a step
+
     def step():
+        if phases is not None:
+            t = [time.perf_counter()]
+            out = model.train_step(batch, opt); t.append(time.perf_counter())
+            opt.zero_grad(); t.append(time.perf_counter())
+            out['loss'].backward(); t.append(time.perf_counter())
+            opt.step(); t.append(time.perf_counter())
+            out['log_vars']['loss']; t.append(time.perf_counter())
+            for i in range(5):
+                phases[i] += t[i + 1] - t[i]
+            return out
         out = model.train_step(batch, opt)
         opt.zero_grad()
         out['loss'].backward()
         opt.step()
+        out['log_vars']['loss']      # the host reads the step's log values once per iteration, as mmcv's runner does (log_buffer.update)
         return out
 
     # initialisation (the analogue of a graph capture): one eager pass settles buffers / workspaces / packed weights, the
@@ -318,8 +334,22 @@ def main():
         return float(tm.item()), o
 
     # ---- the timed region: EXACTLY args.steps steps (single process: hipGraph replay of the step)
+    if phases is not None:
+        phases[:] = [0.0] * 5
+    import gc
+    gc.collect()           # benchmark hygiene: no full collection of the warm-up's garbage inside the timed region
+    gc.freeze()
     dt, out = timed(args.steps)
     log(f'{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step')
+    if phases is not None:
+        log('host ms per step in train_step / zero_grad / backward / opt.step / log read (timed steps): ' +
+            ' / '.join(f'{p / args.steps * 1e3:.2f}' for p in phases))
+    from vfs_amd._lib import Tape
+    log(f'launch chains were (re)recorded {getattr(model, "chain_resets", 0)} times, engine generation {eng.generation}, '
+        f'host time in tape replay {Tape.host_seconds * 1e3:.1f} ms over the whole run')
+    if Tape.slowest:
+        top = sorted(Tape.slowest.items(), key=lambda kv: -kv[1][0])[:8]
+        log('slowest tape ops (host ms total / calls): ' + ', '.join(f'{k}: {v[0] * 1e3:.1f}/{v[1]}' for k, v in top))
     # ---- roofline: per-kernel HIP events need eager launches (a graph replay is one launch), so the
     # same number of steps is repeated eagerly right after the timed region with an event pair around
     # every conv launch (events pre-created; only hipEventRecord is added)

@@ -112,12 +112,30 @@ class Tape:
         self.lib = lib
         self.ops = []
 
+    host_seconds = 0.0      # diagnostics: host time spent replaying tapes (all tapes of the process)
+    slowest = None
+
     def replay(self):
+        import time
         check = self.lib.check
-        for name, fn, args in self.ops:
-            rc = fn(*args)
-            if name is not None and rc:
-                check(name, rc)
+        t0 = time.perf_counter()
+        if Tape.slowest is not None:          # VFS_TAPE_PROFILE=1: per-op host time, to find a call that blocks
+            for name, fn, args in self.ops:
+                t1 = time.perf_counter()
+                rc = fn(*args)
+                d = time.perf_counter() - t1
+                key = name or getattr(fn, '__qualname__', repr(fn))
+                a = Tape.slowest.setdefault(key, [0.0, 0])
+                a[0] += d
+                a[1] += 1
+                if name is not None and rc:
+                    check(name, rc)
+        else:
+            for name, fn, args in self.ops:
+                rc = fn(*args)
+                if name is not None and rc:
+                    check(name, rc)
+        Tape.host_seconds += time.perf_counter() - t0
 
 
 class TapeLib:

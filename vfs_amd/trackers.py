@@ -88,6 +88,69 @@ class _ReduceLossFn(torch.autograd.Function):
         return (g * (1.0 / N)).expand(K, N), None
 
 
+class LazyLogVars(OrderedDict):
+    """log_vars of the fused train_step: same keys, same python floats as _parse_losses returns (base.py:103-108), but read
+    from the device on FIRST ACCESS instead of inside train_step.  The reference's per-variable .item() stalls the host in
+    the middle of the step; here the host goes on to enqueue zero_grad / backward / the optimizer while the forward still
+    runs (0.2 ms of GPU idle time per ResNet-50 step otherwise), and whoever consumes the values - mmcv's log buffer, a
+    print - pays the synchronisation when it actually looks."""
+
+    def __init__(self, keys, snapshot):
+        super().__init__((k, None) for k in keys)
+        self._snap = snapshot
+
+    def _load(self):
+        snap = self.__dict__.pop('_snap', None)
+        if snap is not None:
+            for k, v in zip(list(super().keys()), snap.tolist()):
+                super().__setitem__(k, v)
+
+    def __getitem__(self, k):
+        self._load()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._load()
+        return super().get(k, default)
+
+    def items(self):
+        self._load()
+        return super().items()
+
+    def values(self):
+        self._load()
+        return super().values()
+
+    def __repr__(self):
+        self._load()
+        return super().__repr__()
+
+    def __eq__(self, other):
+        self._load()
+        return dict(self) == dict(other)
+
+    def __reduce__(self):
+        self._load()
+        return (OrderedDict, (list(self.items()),))
+
+
+_GC_FROZEN = [False]
+
+
+def _freeze_gc_once():
+    """Once the launch chains are recorded, move everything alive (torch, the model, the engine's buffers, the tapes: hundreds
+    of thousands of long-lived container objects) out of the cyclic collector's working set.  A full (generation-2) collection
+    over them takes tens of milliseconds - measured on the MI355X host: one such pause inside 20 ResNet-18 steps showed up as
+    +3.5 ms per step although the GPU never waited for the host otherwise.  The objects stay alive anyway; young garbage is
+    still collected.  VFS_GC_FREEZE=0 leaves the collector alone."""
+    if _GC_FROZEN[0] or os.environ.get('VFS_GC_FREEZE', '1') != '1':
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _GC_FROZEN[0] = True
+
+
 class _GraphState:
     """Replay state of the fused step: after one eager step with a given input signature the forward chain and
     the backward chain are each recorded once - as a host-side command tape (default) or captured into a hipGraph
@@ -267,6 +330,7 @@ class SimSiamBaseTracker(BaseTracker):
         gs = getattr(self, '_gs', None)
         if gs is None or gs.key != key:
             gs = self._gs = _GraphState(key)
+            self.chain_resets = getattr(self, 'chain_resets', 0) + 1      # diagnostics: how often the recorded chains were dropped
         if gs.warm < 1:                       # first step eager: buffers, workspaces, packed weights settle
             gs.warm += 1
             return self._hip_forward_train(imgs)
@@ -334,6 +398,7 @@ class SimSiamBaseTracker(BaseTracker):
                 finally:
                     eng.end_tape()
                 gs.bwd = tape
+                _freeze_gc_once()
                 return
         gs.gl.copy_(gl)
         gs.bwd.replay()
@@ -495,11 +560,13 @@ class SimSiamBaseTracker(BaseTracker):
         if dist.is_available() and dist.is_initialized():      # log vars are averaged over the ranks (base.py:103-108)
             packed = self._loss_means / dist.get_world_size()
             dist.all_reduce(packed)
-            vals = packed.tolist()
         else:
-            vals = self._loss_means.tolist()
-        log_vars = OrderedDict((f'img_head.{i}.loss_feat', vals[i]) for i in range(rows.shape[0]))
-        log_vars['loss'] = vals[-1]
+            packed = self._loss_means.clone()                  # the engine buffer is rewritten by the next step
+        keys = [f'img_head.{i}.loss_feat' for i in range(rows.shape[0])] + ['loss']
+        if os.environ.get('VFS_LAZY_LOG', '1') == '1':
+            log_vars = LazyLogVars(keys, packed)
+        else:
+            log_vars = OrderedDict(zip(keys, packed.tolist()))
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['imgs']))
 
     def forward_train(self, imgs, grids=None, label=None):
