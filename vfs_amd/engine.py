@@ -297,9 +297,9 @@ class Engine:
         if os.environ.get('VFS_BNACT_FUSE', '1') != '1' or u.kind == 'stem' or u.dil != 1:
             return False
         # pays only where the saved activation pass is large: the fold costs VALU work in the staging of
-        # the consumer's forward and weight-gradient kernels (measured: + on ResNet-18's wide early layers,
-        # - on ResNet-50's 33 MB-and-smaller bottleneck tensors)
-        if N * H * W * u.cin * 2 < float(os.environ.get('VFS_BNACT_FUSE_MB', '48')) * (1 << 20):
+        # the consumer's forward and weight-gradient kernels (round-2 whole-step A/B on MI355X, threshold 48 / 32 / 16 MB:
+        # ResNet-50 9.36 / 9.30 / 9.24 ms, ResNet-18 unchanged - its folded tensors are all >= 48 MB)
+        if N * H * W * u.cin * 2 < float(os.environ.get('VFS_BNACT_FUSE_MB', '16')) * (1 << 20):
             return False
         Ng = N // G
         mpg = Ng * H * W
