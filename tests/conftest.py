@@ -68,6 +68,18 @@ def backend(request):
 
 
 @pytest.fixture()
+def emu_backend():
+    """CPU-only tests of the kernels (the GPU runs a full-size counterpart of the same properties)"""
+    import torch
+    from vfs_amd import engine
+    from tests.emu_util import emu_lib
+    eng = engine.Engine(lib=emu_lib())
+    engine.set_shared_engine(eng)
+    yield Backend('emu', eng.lib, torch.device('cpu'), eng)
+    engine._ENGINES.clear()
+
+
+@pytest.fixture()
 def gpu_backend():
     import torch
     from vfs_amd import engine

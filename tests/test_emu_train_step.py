@@ -400,11 +400,10 @@ def _full_size_properties(dev, cfg_name, shape, nsteps=2, check_replay=True, sha
     return l1
 
 
-def test_train_step_properties_toy_size(backend):
-    if backend.name == 'gpu':
-        pytest.skip('the GPU runs the BASELINE size (test_train_step_properties_at_baseline_size)')
+def test_train_step_properties_toy_size(emu_backend):
+    """the emulator's share of the size-independent properties; the GPU runs them at the BASELINE sizes (below)"""
     # (replay == eager is covered on the emulator by the 2-rank tape test and on the GPU by test_graph_replay_equals_eager)
-    _full_size_properties(backend.dev, 'vfs_r18.py', [2, 2, 3, 1, 32, 32], nsteps=1, check_replay=False, shallow=True)
+    _full_size_properties(emu_backend.dev, 'vfs_r18.py', [2, 2, 3, 1, 32, 32], nsteps=1, check_replay=False, shallow=True)
 
 
 @pytest.mark.gpu
