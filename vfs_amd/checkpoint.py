@@ -9,45 +9,52 @@
   (models/backbones/resnet.py:488-523) does while loading; `vfs_amd.resnet.ResNet.
   load_torchvision_checkpoint` applies it module by module.
 """
+import re
 from collections import OrderedDict
 
 import torch
 
-_NORMS = {'bn': 'bn', 'gn': 'gn'}
+# One rewrite table, read in both directions.  Each row: (ConvModule-style pattern, torchvision-style template,
+# torchvision-style pattern, ConvModule-style template); `n` is bn|gn, `t` the tensor name (weight, running_mean, ...).
+_BLK = r'(?P<blk>layer\d+\.\d+)'
+_T = r'(?P<t>[^.]+)$'
+_RULES = (
+    (r'^conv1\.conv\.' + _T, 'conv1.{t}',
+     r'^conv1\.' + _T, 'conv1.conv.{t}'),
+    (r'^conv1\.(?P<n>bn|gn)\.' + _T, '{n}1.{t}',
+     r'^(?P<n>bn|gn)1\.' + _T, 'conv1.{n}.{t}'),
+    (r'^' + _BLK + r'\.downsample\.conv\.' + _T, '{blk}.downsample.0.{t}',
+     r'^' + _BLK + r'\.downsample\.0\.' + _T, '{blk}.downsample.conv.{t}'),
+    (r'^' + _BLK + r'\.downsample\.(?P<n>bn|gn)\.' + _T, '{blk}.downsample.1.{t}',
+     r'^' + _BLK + r'\.downsample\.1\.' + _T, '{blk}.downsample.bn.{t}'),
+    (r'^' + _BLK + r'\.conv(?P<i>\d)\.conv\.' + _T, '{blk}.conv{i}.{t}',
+     r'^' + _BLK + r'\.conv(?P<i>\d)\.' + _T, '{blk}.conv{i}.conv.{t}'),
+    (r'^' + _BLK + r'\.conv(?P<i>\d)\.(?P<n>bn|gn)\.' + _T, '{blk}.{n}{i}.{t}',
+     r'^' + _BLK + r'\.(?P<n>bn|gn)(?P<i>\d)\.' + _T, '{blk}.conv{i}.{n}.{t}'),
+)
+_TO_TV = [(re.compile(a), b) for a, b, _, _ in _RULES]
+_FROM_TV = [(re.compile(c), d) for _, _, c, d in _RULES]
+
+
+def _rewrite(table, key):
+    for pat, template in table:
+        m = pat.match(key)
+        if m:
+            return template.format(**m.groupdict())
+    return None
 
 
 def to_pretrained_keys(state_dict, verbose=False):
+    """`backbone.*` entries renamed to torchvision keys; everything else is dropped; a backbone entry no row of the
+    table covers raises RuntimeError (convert_to_pretrained.py raises on unknown sub-modules too)"""
     out = OrderedDict()
     for k, v in state_dict.items():
         if not k.startswith('backbone'):
             continue
-        b_k = k.replace('backbone.', '')
-        parts = b_k.split('.')
-        tail = parts[-1]
-        if b_k.startswith('conv1'):
-            if parts[1] == 'conv':
-                name = f'conv1.{tail}'
-            elif parts[1] in _NORMS:
-                name = f'{_NORMS[parts[1]]}1.{tail}'
-            else:
-                raise RuntimeError(b_k)
-        elif b_k.startswith('layer'):
-            layer, block = int(parts[0][-1]), int(parts[1])
-            if parts[2] == 'downsample':
-                if parts[3] == 'conv':
-                    name = f'layer{layer}.{block}.downsample.0.{tail}'
-                elif parts[3] in _NORMS:
-                    name = f'layer{layer}.{block}.downsample.1.{tail}'
-                else:
-                    raise RuntimeError(b_k)
-            elif parts[3] == 'conv':
-                name = f'layer{layer}.{block}.conv{int(parts[2][-1])}.{tail}'
-            elif parts[3] in _NORMS:
-                name = f'layer{layer}.{block}.{_NORMS[parts[3]]}{int(parts[2][-1])}.{tail}'
-            else:
-                raise RuntimeError(b_k)
-        else:
-            raise RuntimeError(f'{b_k}')
+        inner = k.replace('backbone.', '')
+        name = _rewrite(_TO_TV, inner)
+        if name is None:
+            raise RuntimeError(inner)
         out[name] = v
         if verbose:
             print(f'{k} --> {name}')
@@ -58,25 +65,9 @@ def from_pretrained_keys(state_dict, prefix='backbone.'):
     """torchvision-style ResNet keys -> ConvModule-style keys (fc.* and unknown entries are skipped)"""
     out = OrderedDict()
     for k, v in state_dict.items():
-        parts = k.split('.')
-        tail = parts[-1]
-        if parts[0] == 'conv1':
-            name = f'conv1.conv.{tail}'
-        elif parts[0] in ('bn1', 'gn1'):
-            name = f'conv1.{parts[0][:2]}.{tail}'
-        elif parts[0].startswith('layer') and len(parts) >= 4:
-            head = f'{parts[0]}.{parts[1]}'
-            if parts[2] == 'downsample':
-                name = f'{head}.downsample.{"conv" if parts[3] == "0" else "bn"}.{tail}'
-            elif parts[2].startswith('conv'):
-                name = f'{head}.{parts[2]}.conv.{tail}'
-            elif parts[2][:2] in ('bn', 'gn'):
-                name = f'{head}.conv{parts[2][2:]}.{parts[2][:2]}.{tail}'
-            else:
-                continue
-        else:
-            continue
-        out[prefix + name] = v
+        name = _rewrite(_FROM_TV, k)
+        if name is not None:
+            out[prefix + name] = v
     return out
 
 
