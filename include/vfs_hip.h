@@ -164,6 +164,19 @@ int vfs_bn_eval_params(const float* gamma, const float* beta, const float* runni
 int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres,
                const float* rbnp, vfs_bf16* y, long long M, int C, int mpg, int relu,
                vfs_stream_t stream);
+/* vfs_bn_act / vfs_bn_act_fin with a second output: mask_bits, M*C/8 bytes, bit i of the byte of (pixel m, channels c..c+7) =
+ * (y[m][c+i] > 0); bytes are stored SLAB-major, uint8 [C/64][M][8] ([M][C/8] when C < 64), so that a kernel that owns <= 64
+ * channels of a pixel range reads contiguous bytes.
+ * The BatchNorm backward of a residual unit (resnet.py:102-111,221-230: out = relu(bn(x) + identity)) needs y only as
+ * that mask, in two passes (statistics, apply): pass the mask as `y` with relu = 2 to vfs_bn_bwd_reduce / vfs_bn_bwd_apply /
+ * vfs_bn_bwd_apply_fin / vfs_conv_dgrad_bn (bn_relu = 2) and they read 1/16 of the bytes - bit-identical gradients. */
+int vfs_bn_act_mask(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres,
+                    const float* rbnp, vfs_bf16* y, uint8_t* mask_bits, long long M, int C, int mpg, int relu,
+                    vfs_stream_t stream);
+int vfs_bn_act_fin_mask(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp,
+                        double* sums, float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres,
+                        const float* rbnp, vfs_bf16* y, uint8_t* mask_bits, long long M, int C, int mpg, int relu,
+                        double count, float eps, float momentum, vfs_stream_t stream);
 /* stem: y = maxpool3x3/2/1(relu(bn(x)))  (resnet.py:435), idx = argmax code per element; xpool
  * (optional) = the RAW x at each argmax: the BatchNorm backward of the stem then never re-reads x */
 int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, vfs_bf16* xpool,

@@ -36,3 +36,16 @@ def rb(x):  # round to bf16, keep fp32
 def relerr(a, b):
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def pack_relu_mask(y):
+    """the bit-packed ReLU mask of a [M][C] activation as the kernels lay it out (csrc/vfs_common.h mask8_index):
+    bit i of a byte <-> channel c + i positive; bytes slab-major, uint8 [C/64][M][8] ([M][C/8] when C < 64)"""
+    import numpy as np
+    import torch
+    y = y.float().reshape(-1, y.shape[-1])
+    M, C = y.shape
+    bits = np.packbits((y > 0).numpy().reshape(M, C // 8, 8), axis=2, bitorder='little').reshape(M, C // 8)
+    if C >= 64:
+        bits = bits.reshape(M, C // 64, 8).transpose(1, 0, 2)
+    return torch.from_numpy(np.ascontiguousarray(bits).reshape(-1))

@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import vfs_oracle as O
-from tests.emu_util import nchw, nhwc, rb, relerr
+from tests.emu_util import nchw, nhwc, pack_relu_mask, rb, relerr
 
 
 def bn_forward_chain(lib, x_nhwc, gamma, beta, G, rm, rv):
@@ -393,6 +393,60 @@ def test_bn_apply_with_inkernel_finalisation(backend, G, rows, C, ppr):
     assert torch.allclose(dga, dgb, rtol=1e-6, atol=1e-6) and torch.allclose(dba, dbb2, rtol=1e-6, atol=1e-6)
     assert torch.equal(ga, gb)
     assert (da - dbb).abs().max() <= 2 ** -7 * dbb.abs().max()
+
+
+@pytest.mark.parametrize('G,rows,C,ppr', [(2, 6, 128, 32), (1, 33, 64, 16), (2, 3, 32, 64), (2, 40, 256, 16)])
+def test_bit_packed_relu_mask(backend, G, rows, C, ppr):
+    """vfs_bn_act_mask / vfs_bn_act_fin_mask write y AND the bit-packed mask y > 0 (layout: tests/emu_util.pack_relu_mask);
+    vfs_bn_bwd_reduce / _apply / _apply_fin with relu = 2 read that mask in place of y:
+    every output is BIT-identical to the 16-byte mask operand."""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(rows * 11 + C)
+    mpg = rows * ppr
+    M = G * mpg
+    x = rb(torch.randn(M, C, generator=g) * 1.3 - 0.1)
+    xb = x.to(torch.bfloat16)
+    part = torch.stack([x.view(G * rows, ppr, C).sum(1), (x * x).view(G * rows, ppr, C).sum(1)], dim=1).contiguous()
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    res = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    rm, rv = torch.full((C,), 0.25), torch.full((C,), 1.5)
+    sums, bnp = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(G, 4, C)
+    y0 = torch.empty(M, C, dtype=torch.bfloat16)
+    lib.bn_act_fin(xb, part, rows, gamma, beta, bnp, sums, rm.clone(), rv.clone(), res, None, None, y0, M, C, mpg, 1, float(mpg), 1e-5, 0.1, None)
+    want = pack_relu_mask(y0)
+    assert 0.2 < (y0.float() > 0).float().mean() < 0.8
+    # the two writers
+    y1, m1 = torch.empty(M, C, dtype=torch.bfloat16), torch.full((M * C // 8,), 0xAA, dtype=torch.uint8)
+    lib.bn_act_fin_mask(xb, part, rows, gamma, beta, torch.zeros(G, 4, C), torch.zeros(G, 2, C, dtype=torch.float64), rm.clone(), rv.clone(),
+                        res, None, None, y1, m1, M, C, mpg, 1, float(mpg), 1e-5, 0.1, None)
+    assert torch.equal(y1, y0) and torch.equal(m1, want)
+    y2, m2 = torch.empty(M, C, dtype=torch.bfloat16), torch.full((M * C // 8,), 0x55, dtype=torch.uint8)
+    lib.bn_act_mask(xb, bnp, res, None, None, y2, m2, M, C, mpg, 1, None)
+    assert torch.equal(y2, y0) and torch.equal(m2, want)
+    # without ReLU the mask still is y > 0 (negative values, zeros)
+    y3, m3 = torch.empty(M, C, dtype=torch.bfloat16), torch.zeros(M * C // 8, dtype=torch.uint8)
+    lib.bn_act_mask(xb, bnp, None, None, None, y3, m3, M, C, mpg, 0, None)
+    assert torch.equal(m3, pack_relu_mask(y3))
+    # the three readers
+    gy = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    ppb = ppr
+    pa, pb = torch.full((M // ppb, 2, C), float('nan')), torch.full((M // ppb, 2, C), float('nan'))
+    lib.bn_bwd_reduce(gy, y0, xb, bnp, pa, M, C, mpg, ppb, 0, None)
+    lib.bn_bwd_reduce(gy, m1, xb, bnp, pb, M, C, mpg, ppb, 2, None)
+    assert torch.equal(pa, pb)
+    bs = torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_reduce_partials(pa, bs, torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64), G, (M // ppb) // G, C, None)
+    outs = []
+    for ym, rl in ((y0, 0), (m1, 2)):
+        dx, gm = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+        lib.bn_bwd_apply(gy, ym, xb, bnp, bs, dx, gm, M, C, mpg, float(mpg), rl, None)
+        dx2, gm2 = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+        bs2, dg, db = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(C), torch.zeros(C)
+        lib.bn_bwd_apply_fin(gy, ym, xb, bnp, pa, (M // ppb) // G, bs2, dg, db, dx2, gm2, M, C, mpg, float(mpg), rl, None)
+        outs.append((dx, gm, dx2, gm2, bs2, dg, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][1].float(), torch.where(y0.float() > 0, gy.float(), torch.zeros(())))
 
 
 def _bn_sweep(n, seed):

@@ -1,11 +1,12 @@
 """Conv kernels (forward / dgrad / wgrad / stem) against torch conv2d (CPU, fp32) on the same
 bf16-rounded operands.  backend=emu: host build through the fiber emulator (CPU);
 backend=gpu: libvfs_hip.so on the MI355X."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.emu_util import nchw, nhwc, rb, relerr
+from tests.emu_util import pack_relu_mask, nchw, nhwc, rb, relerr
 from vfs_amd.packing import build_pack_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible, wgrad_splits
 
 
@@ -93,6 +94,26 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
 ]
 
 
+@pytest.mark.parametrize('M_img,nsplit,pps', [(8, 1, 64), (16, 1, 128), (24, 1, 192), (40, 1, 320), (40, 2, 192), (72, 3, 192), (33, 1, 320)])
+def test_wgrad_pixel_step_counts(backend, M_img, nsplit, pps):
+    """the generic weight-gradient kernel loads pixel steps in PAIRS (two register stages): 1, 2, 3 (odd) and 5 steps per
+    split, splits whose last steps run past M, against autograd"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    N, H, W, Cin, Cout = 1, M_img, 8, 128, 64
+    M = N * H * W
+    assert nsplit * pps >= M
+    g = torch.Generator().manual_seed(M + nsplit)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1)
+    dy = rb(torch.randn(N, Cout, H, W, generator=g))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, 1, 0).backward(dy)
+    partial = torch.full((nsplit, Cout, Cin), float('nan'), device=dev)
+    grad = torch.zeros(Cout, Cin, 1, 1, device=dev)
+    lib.conv_wgrad(d(nhwc(dy)), d(nhwc(x)), partial, grad, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, nsplit, pps, None)
+    assert relerr(grad.cpu(), wr.grad) < 3e-4
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', CASES)
 def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
@@ -139,8 +160,10 @@ def test_pack_weights_ragged(backend, shape):
     (3, 7, 7, 128, 64, 1, 1),       # generic kernel, ragged M = 147
     (2, 8, 8, 64, 128, 1, 1),       # generic kernel, 64 output channels (32-channel waves)
     (2, 8, 8, 64, 64, 1, 1),        # generic kernel, one K-step
+    (3, 7, 7, 64, 512, 1, 1),       # DMA-ring variant with fused statistics: 8 K-steps, 64-channel tile, ragged M = 147
+    (4, 8, 8, 256, 320, 1, 2),      # DMA-ring variant with fused statistics: 5 K-steps (odd), four 64-channel tiles, two groups
 ])
-@pytest.mark.parametrize('mask', ['y', 'relu', 'none'])
+@pytest.mark.parametrize('mask', ['y', 'bits', 'relu', 'none'])
 def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, mask):
     """vfs_conv_dgrad_bn: the input gradient is bit-identical to vfs_conv_dgrad, and the partial rows
     {sum g*mask, sum g*mask*xhat} summed per group equal what bn_bwd_reduce computes from the stored
@@ -169,12 +192,20 @@ def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, m
     nblk = conv_stats_rows(N, G, H, W, Cout, Cin, k, 1, pad, H, W) * G     # the dgrad as a conv producing [N,H,W,Cin]
     partial = torch.full((nblk, 2, Cin), float('nan'), device=dev)
     dx1 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
-    lib.conv_dgrad_bn(dy, wd, dx1, add, d(x.to(torch.bfloat16)), d(y.to(torch.bfloat16)) if mask == 'y' else None, d(bnp), partial, mpg, 1 if mask == 'relu' else 0,
+    ymask = d(y.to(torch.bfloat16)) if mask == 'y' else None
+    if mask == 'bits':     # the bit-packed form of the same mask (bn_relu = 2)
+        ymask = d(pack_relu_mask(y))
+    lib.conv_dgrad_bn(dy, wd, dx1, add, d(x.to(torch.bfloat16)), ymask, d(bnp), partial, mpg, {'relu': 1, 'bits': 2}.get(mask, 0),
                       N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
     assert torch.equal(dx1.cpu(), dx0.cpu())
+    if mask == 'bits':     # bit-identical to the 16-byte mask operand
+        p2 = torch.full((nblk, 2, Cin), float('nan'), device=dev)
+        lib.conv_dgrad_bn(dy, wd, dx1, add, d(x.to(torch.bfloat16)), d(y.to(torch.bfloat16)), d(bnp), p2, mpg, 0,
+                          N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+        assert torch.equal(partial.cpu(), p2.cpu())
     gq = dx0.float().cpu().reshape(G, mpg, Cin).double()
     xq = x.float().reshape(G, mpg, Cin).double()
-    if mask == 'y':
+    if mask in ('y', 'bits'):
         gq = gq * (y.float().reshape(G, mpg, Cin) > 0)
     elif mask == 'relu':
         act = x.float().reshape(G, mpg, Cin) * scale[:, None] + (beta - mean * scale)[:, None]

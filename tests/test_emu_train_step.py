@@ -578,6 +578,44 @@ def test_sgd_skips_frozen_parameters_and_checkpoints_momentum(backend):
         assert torch.equal(p.detach(), want[n]), n
 
 
+@pytest.mark.parametrize('depth,shape', [(18, [4, 2, 3, 2, 32, 32]), (50, [4, 2, 3, 1, 32, 32])])
+def test_bit_packed_relu_mask_step_is_bit_identical(backend, depth, shape, monkeypatch):
+    """residual joins write a bit-packed ReLU mask and their BatchNorm backward reads it instead of the activation
+    (engine.MASK_BITS, VFS_MASK_BITS): losses and every parameter after two steps equal the run that reads y, bit for bit"""
+    import vfs_amd
+    from vfs_amd import engine as E
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    mcfg = dict(cfg.model)
+    mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE)
+    mcfg['img_head'] = dict(mcfg['img_head'], **dict(SHALLOW_HEAD, in_channels=128 if depth == 18 else 512))
+    dev = backend.dev
+    batches = [O.fill_tensor(shape, seed=70 + i, scale=2.0).to(dev) for i in range(2)]
+
+    def run(bits):
+        monkeypatch.setattr(E, 'MASK_BITS', bits)
+        torch.manual_seed(0)
+        model = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev).train()
+        opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+        losses = []
+        for b in batches:
+            out = model.train_step(dict(imgs=b, label=torch.zeros(shape[0], 1)), opt)
+            opt.zero_grad()
+            out['loss'].backward()
+            opt.step()
+            losses.append(out['log_vars']['loss'])
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
+        wrote = any(getattr(getattr(m, 'unit', None), 'mask_bits', None) is not None for m in model.modules())
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, wrote
+
+    la, sda, wa = run(True)
+    lb, sdb, wb = run(False)
+    assert wa and not wb
+    assert la == lb, (la, lb)
+    for k in sda:
+        assert torch.equal(sda[k], sdb[k]), k
+
+
 def test_frozen_or_eval_batchnorm_in_train_step_is_refused(backend):
     """frozen_stages / norm_eval need the eval-mode BatchNorm backward, which the fused step does not have: it must
     refuse loudly instead of producing wrong gradients"""

@@ -509,7 +509,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = fmaxf(x[i], 0.f);
       }
-      st16(a.y + (size_t)(r + (long long)u * s.rows) * a.C + s.c, pack8(x));
+      const size_t o = (size_t)(r + (long long)u * s.rows) * a.C + s.c;
+      const u32x4 pk = pack8(x);
+      st16(a.y + o, pk);
+      if (a.mbits) a.mbits[mask8_index(r + (long long)u * s.rows, s.c, a.M, a.C)] = (unsigned char)mask8_of(pk);
     }
   }
 }
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   const long long m0 = (long long)blockIdx.x * a.ppb;
   const int gi = (int)(m0 / a.mpg);
   const int c = blockIdx.y * cslab + ct * 8;
+  const bool bits = a.relu == VFS_MASK_BITS;
   float s1[8], s2[8], mean[8], inv[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -629,7 +633,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         const size_t o = (size_t)(ok[u] ? m : m0) * a.C + c;
         gv[u] = ld16(a.g + o);
         xv[u] = ld16(a.x + o);
-        if (a.y) yv[u] = ld16(a.y + o);
+        if (a.y) {
+          if (bits) yv[u].x = mask8_load(a.y, ok[u] ? m : m0, c, a.M, a.C); else yv[u] = ld16(a.y + o);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -637,7 +643,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         float g[8], x[8];
         unpack8(gv[u], g);
         unpack8(xv[u], x);
-        if (a.y) {
+        if (a.y && bits) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g[i] = ((yv[u].x >> i) & 1u) ? g[i] : 0.f;
+        } else if (a.y) {
           float y[8];
           unpack8(yv[u], y);
 #pragma unroll
@@ -706,6 +715,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1d[i] = sp[i]; s2d[i] = sp[a.C + i]; }
   }
+  const bool bits = a.relu == VFS_MASK_BITS;
   float A[8], B[8], D[8], sh[8];
   {
     float mean[8], inv[8];
@@ -732,7 +742,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
       const size_t o = (size_t)(ok[u] ? m : s.m0) * a.C + s.c;
       gv[u] = ld16(a.g + o);
       xv[u] = ld16(a.x + o);
-      if (a.y) yv[u] = ld16(a.y + o);
+      if (a.y) {
+        if (bits) yv[u].x = mask8_load(a.y, ok[u] ? m : s.m0, s.c, a.M, a.C); else yv[u] = ld16(a.y + o);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -740,7 +752,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
       float g[8], x[8], d[8];
       unpack8(gv[u], g);
       unpack8(xv[u], x);
-      if (a.y) {
+      if (a.y && bits) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = ((yv[u].x >> i) & 1u) ? g[i] : 0.f;
+      } else if (a.y) {
         float y[8];
         unpack8(yv[u], y);
 #pragma unroll

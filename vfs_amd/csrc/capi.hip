@@ -29,7 +29,7 @@ int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
-extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront;
+extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -55,6 +55,8 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "igemm_narrow_below")) { vfs_option_igemm_narrow_below = value; return VFS_OK; }
   if (!strcmp(name, "igemm_onek")) { vfs_option_igemm_onek = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_tiles")) { vfs_option_igemm_ring_tiles = value; return VFS_OK; }
+  if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
+  if (!strcmp(name, "igemm_ring_fbn")) { vfs_option_igemm_ring_fbn = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_upfront")) { vfs_option_igemm_ring_upfront = value; return VFS_OK; }
   return vfs_set_error(VFS_ERR_ARG, "vfs_set_option: unknown option");
 }
@@ -251,22 +253,35 @@ int vfs_bn_eval_params(const float* gamma, const float* beta, const float* runni
                        int C, float eps, vfs_stream_t stream) {
   return vfs_bn_eval_params_launch(gamma, beta, running_mean, running_var, bnp, C, eps, S(stream));
 }
-int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
-               long long M, int C, int mpg, int relu, vfs_stream_t stream) {
+int vfs_bn_act_mask(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+                    uint8_t* mask_bits, long long M, int C, int mpg, int relu, vfs_stream_t stream) {
   BnActArgs a;
   a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
+  a.mbits = mask_bits;
   return vfs_bn_act_launch(a, S(stream));
 }
-int vfs_bn_act_fin(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp, double* sums,
-                   float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
-                   long long M, int C, int mpg, int relu, double count, float eps, float momentum, vfs_stream_t stream) {
+int vfs_bn_act(const vfs_bf16* x, const float* bnp, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+               long long M, int C, int mpg, int relu, vfs_stream_t stream) {
+  return vfs_bn_act_mask(x, bnp, res, rres, rbnp, y, nullptr, M, C, mpg, relu, stream);
+}
+int vfs_bn_act_fin_mask(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp, double* sums,
+                        float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+                        uint8_t* mask_bits, long long M, int C, int mpg, int relu, double count, float eps, float momentum,
+                        vfs_stream_t stream) {
   if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: M % mpg");
   BnActArgs a;
   a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
+  a.mbits = mask_bits;
   BnFin f;
   f.partial = partial; f.bpg = bpg; f.G = (int)(M / mpg); f.gamma = gamma; f.beta = beta; f.bnp = bnp; f.sums = sums;
   f.running_mean = running_mean; f.running_var = running_var; f.count = count; f.eps = eps; f.momentum = momentum;
   return vfs_bn_act_fin_launch(a, f, S(stream));
+}
+int vfs_bn_act_fin(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp, double* sums,
+                   float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+                   long long M, int C, int mpg, int relu, double count, float eps, float momentum, vfs_stream_t stream) {
+  return vfs_bn_act_fin_mask(x, partial, bpg, gamma, beta, bnp, sums, running_mean, running_var, res, rres, rbnp, y, nullptr, M, C, mpg,
+                             relu, count, eps, momentum, stream);
 }
 int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, vfs_bf16* xpool, int N, int H, int W, int C,
                         int Hp, int Wp, int npg, vfs_stream_t stream) {

@@ -101,10 +101,12 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
       const int p = i * 8 + (lane >> 3);
       int ti, py, px;
       halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
-      const size_t o = (((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px)) * a.Cout + c0 + wc * 64 + (lane & 7) * 8;
+      const size_t mrow = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
+      const int cch = c0 + wc * 64 + (lane & 7) * 8;
+      const size_t o = mrow * a.Cout + cch;
       const bool ok = (oki >> i) & 1u;
       bxv[i] = ok ? ld16(a.bn.x + o) : zero16();
-      byv[i] = (ok && a.bn.y) ? ld16(a.bn.y + o) : zero16();
+      byv[i] = (ok && a.bn.y) ? bnfuse_load_mask(a.bn, (long long)mrow, cch, (long long)g.N * g.H * g.W, a.Cout) : zero16();
     }
     __builtin_amdgcn_sched_barrier(0);
   }

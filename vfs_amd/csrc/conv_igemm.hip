@@ -332,9 +332,10 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
 #pragma unroll
     for (int i = 0; i < CPR; ++i) {
       const int m = m0 + wp * 64 + i * PPI + lane / CPR;
-      const size_t o = (size_t)(m < Mc ? m : m0) * a.Cout + c0 + wc * WC + (lane % CPR) * 8;
+      const int mm = m < Mc ? m : m0, cch = c0 + wc * WC + (lane % CPR) * 8;
+      const size_t o = (size_t)mm * a.Cout + cch;
       bxv[i] = ld16(a.bn.x + o);
-      if (a.bn.y) byv[i] = ld16(a.bn.y + o);
+      if (a.bn.y) byv[i] = bnfuse_load_mask(a.bn, mm, cch, Mc, a.Cout);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -435,6 +436,7 @@ int vfs_option_igemm_bc = 0;     // 64: force the 64-channel tile (A/B knob)
 int vfs_option_igemm_xcd = 1;    // XCD-aware tile order (A/B knob)
 int vfs_option_igemm_narrow_below = 513;   // 64-channel tiles when the 128-channel tiling has fewer tiles than this (0: never); whole-step A/B: R50 9.45 -> 9.32 ms
 int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a K-step before its MFMAs (prepared, not yet measured)
+int vfs_option_igemm_ring_fbn = 1;      // the DMA ring also for dgrads with fused BatchNorm-backward statistics (A/B knob)
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
 int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
 
@@ -481,12 +483,14 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   const int bc = wide ? 128 : 64;
   const long long tiles = (long long)((a.g.M + 127) / 128) * ((a.Cout + bc - 1) / bc);
   const bool ring = vfs_option_igemm_ring_tiles > 0 && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
-                    a.g.Ktot >= 256 && tiles <= vfs_option_igemm_ring_tiles && !a.bn.partial &&
+                    a.g.Ktot >= 256 && tiles <= vfs_option_igemm_ring_tiles && (!a.bn.partial || vfs_option_igemm_ring_fbn) &&
                     (mode == GATHER_FWD || mode == GATHER_DGRAD);
-  if (ring && vfs_option_igemm_ring_upfront) {
+  if (ring && vfs_option_igemm_ring_upfront && !a.bn.partial) {
     if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 4>(a, stream) : launch_igemm<64, GATHER_FWD, 4>(a, stream);
     return wide ? launch_igemm<128, GATHER_DGRAD, 4>(a, stream) : launch_igemm<64, GATHER_DGRAD, 4>(a, stream);
   }
+  if (ring && a.bn.partial)   // the deep-stage dgrads that also emit BatchNorm-backward statistics (round 2: they had been left on the register pipeline)
+    return wide ? launch_igemm<128, GATHER_DGRAD, 3, true>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3, true>(a, stream);
   if (ring) {
     if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(a, stream) : launch_igemm<64, GATHER_FWD, 3>(a, stream);
     return wide ? launch_igemm<128, GATHER_DGRAD, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3>(a, stream);

@@ -25,7 +25,12 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const bf16_t* tile, int lo_off, int
   return f;
 }
 
-template <int BCW, int MODE>
+#define WG_OOB 0xFFFFFFF0u   // >= any num_records: the buffer load returns zeros
+// LIN: 1x1, stride 1, no padding - the gather is the identity, pixel m of the input is row m of [M][C].  The generic
+// path re-derives (n, h, w) -> address for every 16-byte load (~230 VALU instructions per 64-pixel step, more than twice
+// the issue time of the step's 32 MFMAs, and with ONE wave per SIMD nothing hides them: SQ counters of the 2048 -> 512
+// layer: VALU busy 30 %, MFMA busy 14 %, the rest waits); here a load is `buffer_load voffset` with voffset += one step.
+template <int BCW, int MODE, bool LIN = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BKC = 128;        // k-columns per workgroup (two forward K-steps)
   constexpr int TM = 4;           // 64 k-columns per wave
@@ -94,7 +99,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   };
 
   u32x4 av[4], dv[4];
+  // LIN: per-lane byte offsets of the four rows this lane fetches; rows past M are past num_records (zero fill); lanes
+  // without work (k-columns past Ktot, the idle half of the dY loaders) stay at WG_OOB (their step is 0)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, LIN ? (unsigned)((size_t)g.M * g.C * 2) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, LIN ? (unsigned)((size_t)g.M * a.Cout * 2) : 0u, 0x00020000);
+  unsigned xvo[4], dvo[4];
+  const unsigned xstep = (LIN && a_ok) ? 64u * (unsigned)g.C * 2u : 0u, dstep = (LIN && d_active) ? 64u * (unsigned)a.Cout * 2u : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xvo[i] = (LIN && a_ok) ? (unsigned)((((size_t)pix_begin + a_pg * 4 + i) * g.C + a_kt * 64 + a_j * 8) * 2) : WG_OOB;
+    dvo[i] = (LIN && d_active) ? (unsigned)((((size_t)pix_begin + d_pg * 4 + i) * a.Cout + cb * BCW + d_cj * 8) * 2) : WG_OOB;
+  }
   auto load_tiles = [&](int it) {   // must be called with it = 0, 1, 2, ... in order
+    if (LIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[i], 0, 0); xvo[i] += xstep; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dv[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, dvo[i], 0, 0); dvo[i] += dstep; }
+      return;
+    }
     const int p0 = pix_begin + it * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -173,11 +196,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-template <int BCW, int MODE>
+int vfs_option_wgrad_lin = 1;   // the linear-address path for 1x1 / stride-1 problems (A/B knob)
+
+template <int BCW, int MODE, bool LIN = false>
 static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
   int nkb = (a.g.Ktot + 127) / 128;
   int ncb = a.Cout / BCW;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BCW, MODE>), dim3(nkb * ncb * a.nsplit), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BCW, MODE, LIN>), dim3(nkb * ncb * a.nsplit), dim3(256), 0, stream, a);
   return vfs_check_launch("conv_wgrad");
 }
 
@@ -186,6 +211,11 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
     return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: K%64, Cout%64, pix_per_split%64");
   if ((long long)a.pix_per_split * a.nsplit < a.g.M) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: splits do not cover M");
   const bool wide = (a.Cout % 128 == 0);
+  // 1x1 / stride 1 / no padding with 32-bit row offsets (the last split may run past M by less than pix_per_split rows)
+  const size_t rows = (size_t)a.g.M + a.pix_per_split, widest = (size_t)(a.g.C > a.Cout ? a.g.C : a.Cout);
+  const bool lin = vfs_option_wgrad_lin && mode == GATHER_FWD && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
+                   a.g.H == a.g.Ho && a.g.W == a.g.Wo && rows * widest * 2 < 0xFFF00000ull;
+  if (lin) return wide ? launch_wgrad<128, GATHER_FWD, true>(a, stream) : launch_wgrad<64, GATHER_FWD, true>(a, stream);
   if (mode == GATHER_FWD) return wide ? launch_wgrad<128, GATHER_FWD>(a, stream) : launch_wgrad<64, GATHER_FWD>(a, stream);
   if (mode == GATHER_STEM) return launch_wgrad<64, GATHER_STEM>(a, stream);
   return vfs_set_error(VFS_ERR_ARG, "conv_wgrad: bad mode");

@@ -153,6 +153,31 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
+// Bit-packed ReLU mask of 8 consecutive bf16 values (bit i <-> value i > 0, exactly the test `float(v) > 0.f`: positive
+// zero, negative values and NaNs give 0).  A residual unit's output y is only needed as `y > 0` by its BatchNorm backward:
+// two passes read it (statistics, apply); the mask is 1/16 of the bytes.
+__device__ __forceinline__ unsigned mask8_of(u32x4 v) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  unsigned bits = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bits |= (((w[i] & 0xffffu) - 1u) < 0x7f80u ? 1u : 0u) << (2 * i);
+    bits |= (((w[i] >> 16) - 1u) < 0x7f80u ? 1u : 0u) << (2 * i + 1);
+  }
+  return bits;
+}
+// Layout: SLAB-major, uint8 [C/64][M][8] (one slab [M][C/8] when C < 64): the byte of pixel m, channels c..c+7 (c % 8 == 0).
+// Every kernel that touches the mask owns <= 64 channels of a range of pixels, so its bytes are contiguous; with a plain
+// [M][C/8] layout a workgroup used 8 bytes of every 64-byte line it fetched and the mask cost as much as the activation.
+__device__ __forceinline__ size_t mask8_index(long long m, int c, long long M, int C) {
+  if (C < 64) return (size_t)m * (C >> 3) + (c >> 3);
+  return ((size_t)(c >> 6) * M + m) * 8 + ((c & 63) >> 3);
+}
+__device__ __forceinline__ unsigned mask8_load(const void* bits, long long m, int c, long long M, int C) {
+  return reinterpret_cast<const unsigned char*>(bits)[mask8_index(m, c, M, C)];
+}
+#define VFS_MASK_BITS 2     // value of the `relu` argument of the BatchNorm-backward entry points: `y` is a bit-packed mask
+
 // error codes of the C ABI (include/vfs_hip.h)
 #define VFS_OK 0
 #define VFS_ERR_SHAPE (-1)

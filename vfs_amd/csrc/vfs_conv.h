@@ -33,7 +33,7 @@ struct ConvGeom {
 // x*scale+shift > 0 (plain conv-BN-ReLU units, relu = 1), or none.  partial == nullptr: disabled.
 struct BnBwdFuse {
   const bf16_t* x;     // [M][Cout] raw conv output of that unit
-  const bf16_t* y;     // [M][Cout] its activation (mask) or null
+  const bf16_t* y;     // [M][Cout] its activation (mask) or null; relu == VFS_MASK_BITS: bit-packed mask, slab-major uint8 [Cout/64][M][8] (vfs_common.h mask8_index)
   const float* bnp;    // [G][4][Cout] scale, shift, mean, invstd
   float* partial;      // [ceil(M/128)][2][Cout]
   int mpg;             // pixels per statistics group (selects the bnp row; blocks never straddle groups)
@@ -217,11 +217,23 @@ __device__ __forceinline__ void bnfuse_init(BnFuseLane& L, const BnBwdFuse& bn, 
 // gv: the 8 gradient values just stored for one pixel; xv / yv: the unit's raw output / activation at the
 // same place (loaded by the caller EARLY: issued next to the use, each load costs a full HBM round trip
 // per tile and the fusion is no faster than the separate reduction pass)
+// the mask operand of pixel m, channels c..c+7 of the [M][Cout] output: 16 bytes of the activation, or (bit mode) one byte in .x
+__device__ __forceinline__ u32x4 bnfuse_load_mask(const BnBwdFuse& bn, long long m, int c, long long M, int Cout) {
+  if (bn.relu == VFS_MASK_BITS) {
+    u32x4 v;
+    v.x = mask8_load(bn.y, m, c, M, Cout); v.y = 0u; v.z = 0u; v.w = 0u;
+    return v;
+  }
+  return *reinterpret_cast<const u32x4*>(bn.y + (size_t)m * Cout + c);
+}
 __device__ __forceinline__ void bnfuse_accum(BnFuseLane& L, const BnBwdFuse& bn, u32x4 gv, u32x4 xv, u32x4 yv) {
   float g[8], x[8];
   unpack8(gv, g);
   unpack8(xv, x);
-  if (bn.y) {
+  if (bn.y && bn.relu == VFS_MASK_BITS) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = ((yv.x >> i) & 1u) ? g[i] : 0.f;
+  } else if (bn.y) {
     float y[8];
     unpack8(yv, y);
 #pragma unroll

@@ -12,6 +12,7 @@ struct BnActArgs {
   bf16_t* y;            // [M][C]
   long long M;
   int C, mpg, relu;     // mpg = pixels per group
+  unsigned char* mbits = nullptr;   // optional second output: the bit-packed mask y > 0, [M][C/8] (vfs_common.h mask8_of)
 };
 
 // Optional in-kernel statistics finalisation for the apply passes (bn_act / bn_bwd_apply, SMALL row counts): the
@@ -62,7 +63,7 @@ struct PoolBwdArgs {
 // one partial[2][C] per workgroup (PIX_PER_BLOCK pixels of one group)
 struct BnBwdArgs {
   const bf16_t* g;     // [M][C] gradient wrt the unit's output
-  const bf16_t* y;     // [M][C] unit output for the ReLU mask, or null (mask from x when relu, else none)
+  const bf16_t* y;     // [M][C] unit output for the ReLU mask, or null (mask from x when relu, else none); relu == VFS_MASK_BITS: uint8 [M][C/8] bit mask
   const bf16_t* x;     // [M][C] raw conv output
   const float* bnp;    // [G][4][C]
   const double* sums;  // pass 2: [G][2][C] (S1,S2), all-reduced for SyncBN
@@ -71,7 +72,7 @@ struct BnBwdArgs {
   bf16_t* gm;          // pass 2 optional output: masked gradient (identity branch)
   long long M;
   int C, mpg, ppb;     // pixels per group, pixels per block (pass 1; mpg % ppb == 0)
-  int relu;            // with y == null: recompute the ReLU mask as x*scale+shift > 0
+  int relu;            // with y == null: recompute the ReLU mask as x*scale+shift > 0; VFS_MASK_BITS (2): y is the bit-packed mask
   double count;        // pass 2: elements per channel per group (global for SyncBN)
 };
 

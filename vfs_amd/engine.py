@@ -24,6 +24,8 @@ FIN_FUSE = os.environ.get('VFS_FIN_FUSE', '1') == '1'      # BatchNorm statistic
 FIN_MAX_ROWS = int(os.environ.get('VFS_FIN_MAX_ROWS', '128'))   # ... for at most this many statistics rows per group
 # timing experiments only: kernel families (Engine.timed labels) whose launches are dropped - results are garbage, the step
 # time shows what the family costs on the critical path (no kernel here has data-dependent control flow)
+MASK_BITS = os.environ.get('VFS_MASK_BITS', '1') == '1'   # residual joins also write a bit-packed ReLU mask; their BatchNorm backward reads it instead of y (R50 -0.3 ms)
+NOMASK = os.environ.get('VFS_DEBUG_NOMASK') == '1'     # what-if timing: BatchNorm backward without reading the activation as ReLU mask
 SKIP = frozenset(filter(None, os.environ.get('VFS_DEBUG_SKIP', '').split(',')))
 KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's Linear layers (slower as measured)
 
@@ -329,21 +331,24 @@ class Engine:
             self.generation += 1
         return t
 
-    def bn_act(self, u, raw, M, G, train, relu, res=None, rres=None, rbnp=None, tag=''):
+    def bn_act(self, u, raw, M, G, train, relu, res=None, rres=None, rbnp=None, tag='', want_mask=False):
+        """y = [relu](bn(raw) [+ res] [+ bn(rres)]).  want_mask (the join of a residual block, training): also write the
+        bit-packed mask y > 0 (uint8 [M][C/8], left in u.mask_bits) - the unit's BatchNorm backward reads it instead of y"""
         dev = raw.device
         y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
+        u.mask_bits = self.buf(f'{u.name}{tag}.mbits', (M * u.cout // 8,), torch.uint8, dev) if (want_mask and MASK_BITS and u.cout % 8 == 0) else None
         mpg = M // G if train else M
-        nbytes = 2.0 * M * u.cout * (2 + (res is not None) + (rres is not None))      # raw in, activation out, identity in
+        nbytes = 2.0 * M * u.cout * (2 + (res is not None) + (rres is not None)) + (M * u.cout / 8.0 if u.mask_bits is not None else 0.0)      # raw in, activation out, identity in (+ mask bits out)
         fin = getattr(self, '_pending_fin', None)
         if fin is not None:
             assert fin[0] is u, 'deferred BatchNorm finalisation belongs to another unit'
             self._pending_fin = None
             bn = u.bn
-            self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act_fin, raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean, bn.running_var,
-                                res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0, fin[3], float(bn.eps), float(bn.momentum),
+            self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act_fin_mask, raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean, bn.running_var,
+                                res, rres, rbnp, y, u.mask_bits, M, u.cout, mpg, 1 if relu else 0, fin[3], float(bn.eps), float(bn.momentum),
                                 self.stream(dev))
             return y
-        self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act, raw, u.bnp, res, rres, rbnp, y, M, u.cout, mpg, 1 if relu else 0,
+        self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act_mask, raw, u.bnp, res, rres, rbnp, y, u.mask_bits, M, u.cout, mpg, 1 if relu else 0,
                    self.stream(dev))
         return y
 
@@ -352,6 +357,8 @@ class Engine:
         """gradient wrt the raw conv output (and optionally the ReLU-masked incoming gradient).
         ymask: the unit's output (residual units); relu=True without ymask: conv->BN->ReLU unit,
         the mask is recomputed from raw inside the kernels."""
+        if NOMASK:
+            ymask = None       # what-if only (WRONG gradients): the step without the mask operand reads
         dev = raw.device
         s = self.stream(dev)
         lib = self.lib
@@ -363,17 +370,19 @@ class Engine:
         nblk = M // ppb
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
-        rl = 1 if relu else 0
+        bits = ymask is not None and ymask.dtype == torch.uint8      # bit-packed mask from bn_act(want_mask=True)
+        rl = 2 if bits else (1 if relu else 0)
+        mask_bytes = 0.0 if ymask is None else (M * C / 8.0 if bits else 2.0 * M * C)
         fused = getattr(self, '_fused_bn', None)
         self._fused_bn = None
         if fused is not None and fused[0] is u:     # the producing dgrad already emitted the statistics rows
             partial, nblk = fused[1], fused[2]
         else:
-            self.timed('bn_bwd_reduce', (0.0, 2.0 * M * C * (2 + (ymask is not None))), dev, lib.bn_bwd_reduce, g, ymask, raw, u.bnp,
+            self.timed('bn_bwd_reduce', (0.0, 2.0 * M * C * 2 + mask_bytes), dev, lib.bn_bwd_reduce, g, ymask, raw, u.bnp,
                        partial, M, C, mpg, ppb, rl, s)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
-        abytes = 2.0 * M * C * (3 + (ymask is not None) + want_gm)      # g, raw in; dx out; activation (mask) in; masked gradient out
+        abytes = 2.0 * M * C * (3 + want_gm) + mask_bytes      # g, raw in; dx out; activation (or its bit mask) in; masked gradient out
         if FIN_FUSE and not self.collectives_on and nblk // G <= FIN_MAX_ROWS:
             # few statistics rows: the apply pass sums them in its prologue (and writes bsums, dgamma, dbeta)
             self.timed('bn_bwd_apply', (0.0, abytes), dev, lib.bn_bwd_apply_fin, g, ymask, raw, u.bnp, partial, nblk // G, u.bsums, u.bn.weight.grad, u.bn.bias.grad, dx, gm, M, C,
@@ -538,6 +547,8 @@ class Engine:
         ks, ksws = igemm_ksplit(N * H * W, u.cin, ktot // u.cin * u.cout) if (u.k == 1 and u.stride == 1 and KSPLIT) else (1, 0)
         if ks == 1 and bn_next is not None and u.stride == 1 and os.environ.get('VFS_BN_FUSE', '1') == '1':
             pu, praw, pymask, prelu, G = bn_next
+            if NOMASK:
+                pymask = None
             Min = N * H * W
             mpg = Min // G
             # the dgrad as a conv [N,Ho,Wo,cout] -> [N,H,W,cin]: its statistics rows (tiles or linear blocks)
@@ -545,9 +556,11 @@ class Engine:
             if rows is not None:
                 nblk = rows * G
                 partial = self.ws('ws.bnbwd_fused', nblk * 2 * u.cin, torch.float32, dev)
-                self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + (1 if pymask is not None else 0))),
+                pbits = pymask is not None and pymask.dtype == torch.uint8
+                mask_units = 0.0 if pymask is None else (1.0 / 16 if pbits else 1.0)
+                self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + mask_units)),
                            dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,
-                           mpg, 1 if (prelu and pymask is None) else 0, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k,
+                           mpg, 2 if pbits else (1 if (prelu and pymask is None) else 0), N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k,
                            u.stride, u.pad, s)
                 self._fused_bn = (pu, partial, nblk)
                 return gin

@@ -311,10 +311,12 @@ class ResNet(nn.Module):
                     draw, dh, dw = eng.conv_fwd(d.unit, x, N, h, w, G, dtr)
                     assert (dh, dw) == (oh, ow)
                     bctx['draw'] = draw
-                    a = eng.bn_act(c.unit, raw, M, G, tr, True, rres=draw, rbnp=d.unit.bnp)
+                    a = eng.bn_act(c.unit, raw, M, G, tr, True, rres=draw, rbnp=d.unit.bnp, want_mask=train)
                 else:
-                    a = eng.bn_act(c.unit, raw, M, G, tr, True, res=x)
+                    a = eng.bn_act(c.unit, raw, M, G, tr, True, res=x, want_mask=train)
                 bctx['out'] = a
+                # what the backward needs of the block output: its ReLU mask (bit-packed when the engine wrote one)
+                bctx['mask'] = c.unit.mask_bits if c.unit.mask_bits is not None else a
                 ah, aw = oh, ow
         return a, ah, aw, bctx
 
@@ -343,7 +345,7 @@ class ResNet(nn.Module):
                 continue
             # the BatchNorm unit that consumes this block's INPUT gradient: the join unit of the block before
             prev = blocks[i - 1] if i > 0 else None
-            next_bn = None if prev is None else (prev['blk'].convs[-1].unit, prev['raws'][-1], prev['out'])
+            next_bn = None if prev is None else (prev['blk'].convs[-1].unit, prev['raws'][-1], prev['mask'])
             g = self._block_bwd(eng, blocks[i], g, N, G, next_bn)
             if on_stage_done is not None and i in stage_start:
                 on_stage_done(getattr(self, self.res_layers[stage_start[i]]))
@@ -374,7 +376,7 @@ class ResNet(nn.Module):
         ih, iw, oh, ow = bctx['dims'][last]
         M = N * oh * ow
         # join: y = relu(bn_last(raw) + identity)
-        dx, gm = eng.bn_bwd(convs[last].unit, g, bctx['out'], bctx['raws'][last], M, G, want_gm=True)
+        dx, gm = eng.bn_bwd(convs[last].unit, g, bctx['mask'], bctx['raws'][last], M, G, want_gm=True)
         if blk.downsample is not None:
             ddx, _ = eng.bn_bwd(blk.downsample.unit, gm, None, bctx['draw'], M, G)
         for ci in range(last, -1, -1):
