@@ -75,6 +75,17 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
                       const vfs_bf16* bn_x, const vfs_bf16* bn_y, const float* bnp, float* bn_partial,
                       int bn_mpg, int bn_relu, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
                       int KW, int stride, int pad, vfs_stream_t stream);
+/* vfs_conv_dgrad / vfs_conv_dgrad_bn whose `add` operand is gated by the bit-packed ReLU mask of its own tensor (add_mask: the
+ * mask_bits of vfs_bn_act_mask for the [N,H,W,Cin] block output; NULL = plain add; Cin % 64 == 0): dx = dgrad + add * (y > 0).
+ * The identity branch of a residual block (resnet.py:105-111,224-230: out = relu(bn(x) + identity)) then adds the
+ * block-output gradient itself; the masked copy g * (y > 0) that vfs_bn_bwd_apply can emit (gm) is never written or read. */
+int vfs_conv_dgrad_maskadd(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const uint8_t* add_mask,
+                           int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                           vfs_stream_t stream);
+int vfs_conv_dgrad_bn_maskadd(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const uint8_t* add_mask,
+                              const vfs_bf16* bn_x, const vfs_bf16* bn_y, const float* bnp, float* bn_partial,
+                              int bn_mpg, int bn_relu, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                              int KW, int stride, int pad, vfs_stream_t stream);
 /* Split-K variants for problems with few output pixels and a long reduction - the SimSiam head's Linear
  * layers (sim_siam_head.py:78-111: 2048x2048 on 64 rows fill 16 workgroups otherwise): the K loop is cut into
  * ksplit slices that run as separate workgroups; the last slice to finish adds the fp32 partial tiles in

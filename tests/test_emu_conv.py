@@ -217,6 +217,47 @@ def test_dgrad_fused_bn_backward_statistics(backend, N, H, W, Cin, Cout, k, G, m
     assert torch.allclose(st[:, 1], want2, rtol=1e-4, atol=2e-2), (st[:, 1] - want2).abs().max()
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k', [
+    (2, 8, 16, 128, 64, 1),      # implicit-GEMM dgrad, one 128-channel tile (64-channel waves)
+    (3, 7, 7, 64, 256, 1),       # implicit-GEMM dgrad, 64-channel tile (32-channel waves), DMA ring, ragged M
+    (2, 16, 32, 128, 64, 3),     # halo dgrad, 128 output channels
+    (2, 32, 32, 64, 64, 3),      # halo dgrad, 64 output channels (16x16 tiles)
+    (4, 7, 7, 128, 128, 3),      # halo dgrad on whole 7x7 images
+])
+def test_dgrad_add_gated_by_bit_packed_mask(backend, N, H, W, Cin, Cout, k):
+    """vfs_conv_dgrad_maskadd(add = g, add_mask = bits(y > 0)) == vfs_conv_dgrad(add = g * (y > 0)), bit for bit; the same for
+    the statistics-fused entry point"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    gen = torch.Generator().manual_seed(N * 13 + Cin + k)
+    pad = k // 2
+    w = rb(torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5)
+    _, wd = pack(backend, w)
+    dy = d(nhwc(rb(torch.randn(N, Cout, H, W, generator=gen))))
+    g = rb(torch.randn(N, H, W, Cin, generator=gen))
+    y = rb(torch.relu(torch.randn(N, H, W, Cin, generator=gen)))
+    gm = torch.where(y > 0, g, torch.zeros(()))
+    bits = d(pack_relu_mask(y))
+    dx0 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+    dx1 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+    lib.conv_dgrad(dy, wd, dx0, d(gm.to(torch.bfloat16)), N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+    lib.conv_dgrad_maskadd(dy, wd, dx1, d(g.to(torch.bfloat16)), bits, N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+    assert torch.equal(dx0.cpu(), dx1.cpu())
+    # with fused BatchNorm-backward statistics
+    M = N * H * W
+    nblk = conv_stats_rows(N, 1, H, W, Cout, Cin, k, 1, pad, H, W)
+    x = rb(torch.randn(N, H, W, Cin, generator=gen))
+    bnp = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen), torch.randn(Cin, generator=gen) * 0.1,
+                       torch.rand(Cin, generator=gen) + 0.5], 0).reshape(1, 4, Cin).contiguous()
+    pa, pb = torch.full((nblk, 2, Cin), float('nan'), device=dev), torch.full((nblk, 2, Cin), float('nan'), device=dev)
+    dx2 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+    dx3 = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+    lib.conv_dgrad_bn(dy, wd, dx2, d(gm.to(torch.bfloat16)), d(x.to(torch.bfloat16)), None, d(bnp), pa, M, 1, N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+    lib.conv_dgrad_bn_maskadd(dy, wd, dx3, d(g.to(torch.bfloat16)), bits, d(x.to(torch.bfloat16)), None, d(bnp), pb, M, 1, N, H, W, Cin, H, W, Cout, k, k,
+                              1, pad, None)
+    assert torch.equal(dx2.cpu(), dx0.cpu()) and torch.equal(dx3.cpu(), dx0.cpu())
+    assert torch.equal(pa.cpu(), pb.cpu())
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,G', [
     (2, 16, 32, 128, 128, 2),     # 8x16 tiles, two channel chunks, two groups
     (2, 32, 32, 64, 64, 2),       # 16x16 tiles (64 output channels)

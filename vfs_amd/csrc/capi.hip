@@ -139,18 +139,30 @@ int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* sta
   return vfs_conv_igemm_dispatch(a, GATHER_STEM, S(stream));
 }
 
-int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, int N, int H, int W, int Cin,
-                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+static int set_add_mask(ConvArgs& a, const vfs_bf16* add, const uint8_t* add_mask, int N, int H, int W, int Cin) {
+  if (!add_mask) return VFS_OK;
+  if (!add || Cin % 64) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad: add_mask needs an add operand and Cin % 64 == 0");
+  a.add_mask = add_mask; a.add_rows = (long long)N * H * W;
+  return VFS_OK;
+}
+int vfs_conv_dgrad_maskadd(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const uint8_t* add_mask, int N,
+                           int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
   // gather source = dy [N,Ho,Wo,Cout]; destination grid = dx [N,H,W,Cin]
   ConvArgs a;
   a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
   a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin; a.bn = BnBwdFuse{};
   a.in_bnp = nullptr; a.in_npg = 0;
+  if (int rc = set_add_mask(a, add, add_mask, N, H, W, Cin)) return rc;
   return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
 }
-int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const vfs_bf16* bn_x,
-                      const vfs_bf16* bn_y, const float* bnp, float* bn_partial, int bn_mpg, int bn_relu, int N, int H, int W,
-                      int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+int vfs_conv_dgrad(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, int N, int H, int W, int Cin,
+                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+  return vfs_conv_dgrad_maskadd(dy, wd, dx, add, nullptr, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, stream);
+}
+int vfs_conv_dgrad_bn_maskadd(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const uint8_t* add_mask,
+                              const vfs_bf16* bn_x, const vfs_bf16* bn_y, const float* bnp, float* bn_partial, int bn_mpg, int bn_relu,
+                              int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                              vfs_stream_t stream) {
   if (stride != 1) return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: stride 1 only (strided dgrads run per parity class)");
   if (!bn_x || !bnp || !bn_partial || bn_mpg <= 0) return vfs_set_error(VFS_ERR_ARG, "conv_dgrad_bn: null statistics operand");
   const long long M = (long long)N * H * W;
@@ -158,6 +170,7 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
   a.g = make_geom(N, Ho, Wo, Cout, H, W, KH, KW, stride, pad, KH * KW * Cout);
   a.src = dy; a.wgt = wd; a.out = dx; a.add = add; a.bias = nullptr; a.stats = nullptr; a.Cout = Cin;
   a.in_bnp = nullptr; a.in_npg = 0;
+  if (int rc = set_add_mask(a, add, add_mask, N, H, W, Cin)) return rc;
   a.bn.x = bn_x; a.bn.y = bn_y; a.bn.bnp = bnp; a.bn.partial = bn_partial; a.bn.mpg = bn_mpg; a.bn.relu = bn_relu;
   // a statistics row must belong to ONE group: spatial tiles never straddle images (halo kernels: groups of whole
   // images), linear blocks are 128 pixels
@@ -165,6 +178,12 @@ int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, cons
   if (bn_mpg < M && (tiles ? bn_mpg % ((long long)H * W) != 0 : bn_mpg % 128 != 0))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_dgrad_bn: groups must be whole images (tile kernels) / multiples of 128 pixels");
   return vfs_conv_igemm_dispatch(a, GATHER_DGRAD, S(stream));
+}
+int vfs_conv_dgrad_bn(const vfs_bf16* dy, const vfs_bf16* wd, vfs_bf16* dx, const vfs_bf16* add, const vfs_bf16* bn_x,
+                      const vfs_bf16* bn_y, const float* bnp, float* bn_partial, int bn_mpg, int bn_relu, int N, int H, int W,
+                      int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, vfs_stream_t stream) {
+  return vfs_conv_dgrad_bn_maskadd(dy, wd, dx, add, nullptr, bn_x, bn_y, bnp, bn_partial, bn_mpg, bn_relu, N, H, W, Cin, Ho, Wo, Cout,
+                                   KH, KW, stride, pad, stream);
 }
 
 int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float* grad, int N, int H, int W, int Cin, int Ho,

@@ -113,6 +113,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     u32x2 ad[TM];
+    unsigned long long amw = 0;
     const bool okp = (okt >> tn) & 1u;
     if (do_add) {
       int ti, py, px;
@@ -121,6 +122,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
       const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) ad[tm] = okp ? ld8(a.add + obase + tm * 16) : (u32x2){0u, 0u};
+      if (a.add_mask && okp) amw = addmask_word<64>(a.add_mask, (long long)mdst, c0 + wc * 64, a.add_rows, a.Cout);
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -130,7 +132,11 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
       }
-      if (do_add) {
+      if (do_add && a.add_mask) {       // the add operand gated by its own ReLU mask (vfs_conv.h)
+        const unsigned nib = (unsigned)(amw >> (tm * 16 + lq * 4));
+        v[0] += (nib & 1u) ? bflo(ad[tm].x) : 0.f; v[1] += (nib & 2u) ? bfhi(ad[tm].x) : 0.f;
+        v[2] += (nib & 4u) ? bflo(ad[tm].y) : 0.f; v[3] += (nib & 8u) ? bfhi(ad[tm].y) : 0.f;
+      } else if (do_add) {
         v[0] += bflo(ad[tm].x); v[1] += bfhi(ad[tm].x); v[2] += bflo(ad[tm].y); v[3] += bfhi(ad[tm].y);
       }
       u32x2 pk;

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     const int m = m0 + wp * 64 + tn * 16 + lr;
     const bool mok = m < Mc;
     const size_t mdst = (do_add && mok) ? pixel_dst(m) : 0;
+    unsigned long long amw = 0;      // add_mask: the ReLU-mask bits of this wave's WC channels at the pixel
+    if (do_add && a.add_mask && mok && c0 + wc * WC < a.Cout) amw = addmask_word<WC>(a.add_mask, (long long)mdst, c0 + wc * WC, a.add_rows, a.Cout);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int c = c0 + wc * WC + tm * 16 + lq * 4;
@@ -356,7 +358,13 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       }
       if (do_add && ok) {
         const u32x2 ad = ld8(a.add + mdst * a.Cout + c);
-        v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
+        if (a.add_mask) {
+          const unsigned nib = (unsigned)(amw >> (tm * 16 + lq * 4));
+          v[0] += (nib & 1u) ? bflo(ad.x) : 0.f; v[1] += (nib & 2u) ? bfhi(ad.x) : 0.f;
+          v[2] += (nib & 4u) ? bflo(ad.y) : 0.f; v[3] += (nib & 8u) ? bfhi(ad.y) : 0.f;
+        } else {
+          v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
+        }
       }
       u32x2 pk;
       pk.x = pack2bf(v[0], v[1]);

@@ -61,6 +61,11 @@ struct ConvArgs {
   // partials in slice order (deterministic) and runs the epilogue.
   float* ks_ws = nullptr;
   int ksplit = 1;
+  // optional: `add` is gated by the bit-packed ReLU mask of its own tensor (slab-major, vfs_common.h mask8_index; add_rows =
+  // its pixel count): out = conv + add * (mask bit).  The identity branch of a residual block then adds the block-output
+  // gradient g itself and the masked copy g * (y > 0) is never written (Cout % 64 == 0).
+  const unsigned char* add_mask = nullptr;
+  long long add_rows = 0;
   int xcd_swizzle = 0;   // implicit-GEMM kernel: XCD-aware logical tile order (set by the dispatcher)
 };
 #define KS_TICKETS 1024
@@ -217,6 +222,13 @@ __device__ __forceinline__ void bnfuse_init(BnFuseLane& L, const BnBwdFuse& bn, 
 // gv: the 8 gradient values just stored for one pixel; xv / yv: the unit's raw output / activation at the
 // same place (loaded by the caller EARLY: issued next to the use, each load costs a full HBM round trip
 // per tile and the fusion is no faster than the separate reduction pass)
+// mask bits of the NCH (64 or 32) channels a wave owns at pixel row m of the `add` tensor: bit k <-> channel cw + k
+template <int NCH>
+__device__ __forceinline__ unsigned long long addmask_word(const unsigned char* bits, long long m, int cw, long long M, int C) {
+  const unsigned char* p = bits + mask8_index(m, cw, M, C);
+  if (NCH == 64) return *reinterpret_cast<const unsigned long long*>(p);      // cw % 64 == 0: one aligned slab row
+  return (unsigned long long)*reinterpret_cast<const unsigned*>(p);           // cw % 32 == 0
+}
 // the mask operand of pixel m, channels c..c+7 of the [M][Cout] output: 16 bytes of the activation, or (bit mode) one byte in .x
 __device__ __forceinline__ u32x4 bnfuse_load_mask(const BnBwdFuse& bn, long long m, int c, long long M, int Cout) {
   if (bn.relu == VFS_MASK_BITS) {

@@ -24,6 +24,7 @@ FIN_FUSE = os.environ.get('VFS_FIN_FUSE', '1') == '1'      # BatchNorm statistic
 FIN_MAX_ROWS = int(os.environ.get('VFS_FIN_MAX_ROWS', '128'))   # ... for at most this many statistics rows per group
 # timing experiments only: kernel families (Engine.timed labels) whose launches are dropped - results are garbage, the step
 # time shows what the family costs on the critical path (no kernel here has data-dependent control flow)
+MASK_ADD = os.environ.get('VFS_MASK_ADD', '1') == '1'     # with MASK_BITS: the identity-branch gradient g * (y > 0) is applied on the fly (vfs_conv_dgrad_maskadd), never written
 MASK_BITS = os.environ.get('VFS_MASK_BITS', '1') == '1'   # residual joins also write a bit-packed ReLU mask; their BatchNorm backward reads it instead of y (R50 -0.3 ms)
 NOMASK = os.environ.get('VFS_DEBUG_NOMASK') == '1'     # what-if timing: BatchNorm backward without reading the activation as ReLU mask
 SKIP = frozenset(filter(None, os.environ.get('VFS_DEBUG_SKIP', '').split(',')))
@@ -381,6 +382,9 @@ class Engine:
             self.timed('bn_bwd_reduce', (0.0, 2.0 * M * C * 2 + mask_bytes), dev, lib.bn_bwd_reduce, g, ymask, raw, u.bnp,
                        partial, M, C, mpg, ppb, rl, s)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
+        # with the bit-packed mask the masked gradient is not materialised: its consumers take (g, mask) instead (conv_bwd add_mask,
+        # the downsample unit's bn_bwd)
+        want_gm = want_gm and not (bits and MASK_ADD)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
         abytes = 2.0 * M * C * (3 + want_gm) + mask_bytes      # g, raw in; dx out; activation (or its bit mask) in; masked gradient out
         if FIN_FUSE and not self.collectives_on and nblk // G <= FIN_MAX_ROWS:
@@ -496,7 +500,7 @@ class Engine:
         with self.on_side_stream(dev):
             self.lib.wgrad_reduce_table(tab[0], tab[1], tab[2], self.stream(dev))
 
-    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None, bn_next=None, x_in_bn=None):
+    def conv_bwd(self, u, dx, x_in, N, H, W, Ho, Wo, need_dgrad, add=None, g_out=None, bn_next=None, x_in_bn=None, add_mask=None):
         """weight (and bias) gradients accumulate into .grad; returns the input gradient or None.
         bn_next = (unit, raw, ymask, relu, G): the BatchNorm unit whose backward consumes the input
         gradient; for stride-1 convs the dgrad epilogue also emits that unit's backward statistics
@@ -559,17 +563,18 @@ class Engine:
                 pbits = pymask is not None and pymask.dtype == torch.uint8
                 mask_units = 0.0 if pymask is None else (1.0 / 16 if pbits else 1.0)
                 self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), (flops, dbytes + 2.0 * N * H * W * u.cin * ((1 if add is not None else 0) + 1 + mask_units)),
-                           dev, lib.conv_dgrad_bn, dx, u.wd, gin, add, praw, pymask, pu.bnp, partial,
+                           dev, lib.conv_dgrad_bn_maskadd, dx, u.wd, gin, add, add_mask, praw, pymask, pu.bnp, partial,
                            mpg, 2 if pbits else (1 if (prelu and pymask is None) else 0), N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k,
                            u.stride, u.pad, s)
                 self._fused_bn = (pu, partial, nblk)
                 return gin
         work = (flops, dbytes + (2.0 * N * H * W * u.cin if add is not None else 0.0))
         if ks > 1:
+            assert add_mask is None, 'the split-K dgrad has no mask-gated add'
             self.timed('conv_igemm', work, dev, lib.conv_dgrad_splitk, dx, u.wd, gin, add, self.ksplit_ws(ksws, dev), ks, N, H, W, u.cin,
                        Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
         else:
-            self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), work, dev, lib.conv_dgrad, dx, u.wd, gin, add, N, H, W, u.cin, Ho, Wo, u.cout,
+            self.timed(self.conv_kind(u, N, Ho, Wo, dgrad=True), work, dev, lib.conv_dgrad_maskadd, dx, u.wd, gin, add, add_mask, N, H, W, u.cin, Ho, Wo, u.cout,
                        u.k, u.k, u.stride, u.pad, s)
         return gin
 

@@ -377,8 +377,11 @@ class ResNet(nn.Module):
         M = N * oh * ow
         # join: y = relu(bn_last(raw) + identity)
         dx, gm = eng.bn_bwd(convs[last].unit, g, bctx['mask'], bctx['raws'][last], M, G, want_gm=True)
+        gmask = None
+        if gm is None:       # bit-packed mask: the masked gradient g * (y > 0) is applied on the fly by its consumers
+            gm, gmask = g, bctx['mask']
         if blk.downsample is not None:
-            ddx, _ = eng.bn_bwd(blk.downsample.unit, gm, None, bctx['draw'], M, G)
+            ddx, _ = eng.bn_bwd(blk.downsample.unit, gm, gmask, bctx['draw'], M, G)
         for ci in range(last, -1, -1):
             c = convs[ci]
             ih, iw, oh, ow = bctx['dims'][ci]
@@ -391,7 +394,8 @@ class ResNet(nn.Module):
             else:
                 bn_next = None
             x_in_bn = bctx['act_bn'][ci - 1] if ci > 0 else None
-            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add, bn_next=bn_next, x_in_bn=x_in_bn)
+            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add, bn_next=bn_next, x_in_bn=x_in_bn,
+                               add_mask=gmask if add is not None else None)
             if ci > 0:
                 p = convs[ci - 1]
                 _, _, ph, pw = bctx['dims'][ci - 1]
