@@ -99,13 +99,21 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   const int nk = (MODE == GATHER_STEM) ? 4 : nr * ns * cpt;
 
   // ---- per-row descriptors: byte offset base (mod 2^32) and a validity bit per tap
+  // pure GEMM (1x1, stride 1, no padding: most launches of ResNet-50): pixel m of the destination is row m of the source -
+  // no (n, h, w) decomposition (two integer divisions per row), no tap loop.  SQ counters of the 64 -> 256 layer: 563 of the
+  // 1055 VALU and ~all 550 SALU instructions a wave executed were this prologue, and the kernel is instruction-issue bound
+  // (3 workgroups per CU: VALU busy 78 %, not HBM: 3.4 TB/s).
+  const bool pure = (MODE == GATHER_FWD || MODE == GATHER_DGRAD) && g.KH * g.KW == 1 && g.stride == 1 && g.pad == 0 &&
+                    g.H == g.Ho && g.W == g.Wo;
   unsigned xbase[4], xmask[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + row0 + 32 * i;
     unsigned mask = 0;
     long long base = 0;
-    if (m < Mc) {
+    if (pure) {
+      if (m < Mc) { base = (long long)m * g.C + j * 8; mask = 1u; }
+    } else if (m < Mc) {
       const int hw = Hc * Wc;
       const int n = m / hw;
       const int rem = m - n * hw;
