@@ -94,6 +94,44 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
 ]
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride', [
+    (3, 7, 7, 512, 64, 1, 1),       # DMA ring, ragged M = 147 (rows past M are computed from a re-fetched row)
+    (2, 2, 2, 1024, 256, 1, 1),     # DMA ring, 8 rows only (ResNet-50 layer4 on a 64 x 64 input)
+    (1, 12, 12, 64, 256, 1, 1),     # one K-step, two 128-channel tiles, ragged M = 144
+    (3, 7, 7, 128, 72, 1, 1),       # ragged channel tile (72 = 64 + 8)
+    (2, 9, 11, 64, 64, 3, 2),       # 3x3 stride 2 through the implicit-GEMM kernel
+])
+def test_forward_statistics_rows_without_bias(backend, N, H, W, Cin, Cout, k, stride):
+    """the BatchNorm statistics rows of a bias-free forward conv (the ConvModule case): the implicit-GEMM kernel computes them
+    on the matrix cores from the staged bf16 tile (option igemm_mfma_stats) - equal to the sums over the stored output"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N * 31 + Cin + Cout)
+    pad = k // 2
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    wf, _ = pack(backend, w)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = N * Ho * Wo
+    nblk = conv_stats_rows(N, 1, H, W, Cin, Cout, k, stride, pad, Ho, Wo)
+    outs = []
+    for flag in (1, 0):
+        lib.set_option(b'igemm_mfma_stats', flag)
+        try:
+            y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+            stats = torch.full((nblk, 2, Cout), float('nan'), device=dev)
+            lib.conv_fwd(d(nhwc(x)), wf, y, None, stats, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, None)
+        finally:
+            lib.set_option(b'igemm_mfma_stats', 1)
+        yf = y.float().cpu().reshape(M, Cout).double()
+        st = stats.cpu().double()
+        assert torch.isfinite(st).all()
+        assert torch.allclose(st[:, 0].sum(0), yf.sum(0), rtol=1e-5, atol=2e-3)
+        assert torch.allclose(st[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-5, atol=2e-3)
+        outs.append((y.cpu(), st))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-3)
+
+
 @pytest.mark.parametrize('M_img,nsplit,pps', [(8, 1, 64), (16, 1, 128), (24, 1, 192), (40, 1, 320), (40, 2, 192), (72, 3, 192), (33, 1, 320)])
 def test_wgrad_pixel_step_counts(backend, M_img, nsplit, pps):
     """the generic weight-gradient kernel loads pixel steps in PAIRS (two register stages): 1, 2, 3 (odd) and 5 steps per

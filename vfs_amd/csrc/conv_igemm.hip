@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   // rows.  The K loop ended with a barrier: nobody reads the operand tiles any more.
   const int lr = lane & 15, lq = lane >> 4;
   const bool do_stats = HAS_STATS && a.stats != nullptr, do_add = a.add != nullptr, do_bias = a.bias != nullptr;
+  const bool mstats = do_stats && !do_add && !do_bias && a.mfma_stats;   // uniform
   bf16_t* slab = smem + wave * (64 * SROW);
   auto pixel_dst = [&](int m) -> size_t {         // class-local pixel -> row of the output matrix
     if (MODE != GATHER_DGRAD2) return (size_t)m;
@@ -377,8 +378,9 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       u32x2 pk;
       pk.x = pack2bf(v[0], v[1]);
       pk.y = pack2bf(v[2], v[3]);
+      if (mstats && !mok) { pk.x = 0u; pk.y = 0u; }   // rows past M: the DMA-ring variant computes them from a re-fetched valid row
       st8(&slab[(tn * 16 + lr) * SROW + tm * 16 + lq * 4], pk);
-      if (do_stats && ok) {   // statistics of the STORED (bf16) values
+      if (do_stats && ok && !mstats) {   // statistics of the STORED (bf16) values
         const float q0 = bflo(pk.x), q1 = bfhi(pk.x), q2 = bflo(pk.y), q3 = bfhi(pk.y);
         s1[tm][0] += q0; s2[tm][0] += q0 * q0;
         s1[tm][1] += q1; s2[tm][1] += q1 * q1;
@@ -388,6 +390,37 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     }
   }
   __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
+  if (mstats) {
+    // Statistics rows on the matrix cores (idle here: 16 MFMAs of a one-K-step problem): with Y the wave's staged
+    // [64 pixels][WC channels] bf16 tile, sum_p y = Y^T * 1 and sum_p y^2 = diag(Y^T * Y), pixels as the MFMA k index
+    // (transposing LDS reads).  The per-element VALU version (unpack, add, fma, then a 16-lane DPP tree per value) was
+    // ~400 of the ~770 VALU instructions a wave of the 1x1 forward kernels executed, and those kernels are
+    // issue-bound.  Rows past M and channels past Cout hold zeros (no bias / residual on this path).
+    const int pl = 4 * lq + (lr >> 2), chq = (lr & 3) * 4;
+    const bf16_t* tb = slab + pl * SROW + chq;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (short)0x3f80;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 f = tile_tr_frag(tb, (32 * ks) * SROW + tm * 16, (32 * ks + 16) * SROW + tm * 16);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, ones, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, a2, 0, 0, 0);
+      }
+      // output element [row = 4 lq + r][col = lr]: every column of a1 is the sum; the diagonal of a2 is the sum of squares
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sRed[wp][wc * WC + tm * 16 + lq * 4 + r][0] = a1[r];
+      }
+      if ((lr >> 2) == lq) {
+        const int r = lr & 3;
+        sRed[wp][wc * WC + tm * 16 + lr][1] = r == 0 ? a2[0] : r == 1 ? a2[1] : r == 2 ? a2[2] : a2[3];
+      }
+    }
+  }
   {
     const int ch = lane % CPR, c = c0 + wc * WC + ch * 8;
     if (do_bn && c < a.Cout) bnfuse_init(bl, a.bn, a.Cout, (m0 + wp * 64) / a.bn.mpg, c);
@@ -425,6 +458,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     }
   }
   if (do_stats) {
+    if (!mstats) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -438,6 +472,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
           sRed[wp][cl][1] = x2;
         }
       }
+    }
     __syncthreads();
     if (t < BC && c0 + t < a.Cout) {
       float* dst = a.stats + (size_t)pb * 2 * a.Cout;
@@ -450,6 +485,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
 // ------------------------------------------------------------------ host launcher
 int vfs_option_igemm_bc = 0;     // 64: force the 64-channel tile (A/B knob)
 int vfs_option_igemm_xcd = 1;    // XCD-aware tile order (A/B knob)
+int vfs_option_igemm_mfma_stats = 1;   // forward statistics rows by MFMA from the staged tile (A/B knob; 0: per-element VALU + DPP)
 int vfs_option_igemm_narrow_below = 513;   // 64-channel tiles when the 128-channel tiling has fewer tiles than this (0: never); whole-step A/B: R50 9.45 -> 9.32 ms
 int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a K-step before its MFMAs (prepared, not yet measured)
 int vfs_option_igemm_ring_fbn = 1;      // the DMA ring also for dgrads with fused BatchNorm-backward statistics (A/B knob)
@@ -478,6 +514,7 @@ static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
 int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) {
   ConvArgs a = a_in;
   a.xcd_swizzle = vfs_option_igemm_xcd;
+  a.mfma_stats = vfs_option_igemm_mfma_stats;
   if (a.g.Ktot % 64 != 0 || a.Cout % 8 != 0) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: K%64 or Cout%8");
   if (vfs_option_halo && a.g.C % 64 == 0 && (size_t)a.g.N * a.g.H * a.g.W * a.g.C * 2 < 0xFFFFFFF0ull &&
       vfs_conv_halo_eligible(a, mode))

@@ -66,6 +66,7 @@ struct ConvArgs {
   // gradient g itself and the masked copy g * (y > 0) is never written (Cout % 64 == 0).
   const unsigned char* add_mask = nullptr;
   long long add_rows = 0;
+  int mfma_stats = 0;    // implicit-GEMM kernel: forward statistics rows by MFMA from the staged bf16 tile (set by the dispatcher)
   int xcd_swizzle = 0;   // implicit-GEMM kernel: XCD-aware logical tile order (set by the dispatcher)
 };
 #define KS_TICKETS 1024
@@ -222,6 +223,17 @@ __device__ __forceinline__ void bnfuse_init(BnFuseLane& L, const BnBwdFuse& bn, 
 // gv: the 8 gradient values just stored for one pixel; xv / yv: the unit's raw output / activation at the
 // same place (loaded by the caller EARLY: issued next to the use, each load costs a full HBM round trip
 // per tile and the fusion is no faster than the separate reduction pass)
+// 8 pixels x 16 channels of a pixel-major bf16 tile, transposed by the LDS transpose read: lane gets the 8-pixel MFMA k-run
+// of channel (lane & 15) (as wg_tr_frag of conv_wgrad.hip)
+typedef __attribute__((ext_vector_type(4))) short vfs_s16x4;
+__device__ __forceinline__ bf16x8 tile_tr_frag(const bf16_t* tile, int lo_off, int hi_off) {
+  const vfs_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vfs_s16x4*)(tile + lo_off));
+  const vfs_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vfs_s16x4*)(tile + hi_off));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
 // mask bits of the NCH (64 or 32) channels a wave owns at pixel row m of the `add` tensor: bit k <-> channel cw + k
 template <int NCH>
 __device__ __forceinline__ unsigned long long addmask_word(const unsigned char* bits, long long m, int cw, long long M, int C) {
