@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void labelprop_f32_merge_kernel(LabelPropF32Ar
   }
 }
 
+int vfs_option_lpx_target = 0;   // workgroups the key frames of a query tile are split into; 0 = auto (A/B knob)
 int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s) {
   if (a.C % 4) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: C % 4");
   if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 24");
@@ -458,7 +459,10 @@ int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s) {
   if (!(a.temperature > 0.f)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32: temperature > 0");
   if (a.pval == nullptr || a.pidx == nullptr) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32: partial workspace missing");
   const int tiles = ((a.H + 7) / 8) * ((a.W + 7) / 8);
-  int nsplit = (768 + tiles - 1) / tiles;
+  // long channel loops (ResNet-50 res4: C = 1024) balance better with one or two key frames per workgroup (A/B on MI355X:
+  // 5.22 -> 5.05 ms per frame), short ones (ResNet-18: C = 256) with fewer, longer workgroups (1.46 vs 1.51)
+  const int target = vfs_option_lpx_target > 0 ? vfs_option_lpx_target : (a.C >= 512 ? 2400 : 768);
+  int nsplit = (target + tiles - 1) / tiles;
   if (nsplit > a.nkeys) nsplit = a.nkeys;
   if (nsplit > LP_MAX_SPLIT) nsplit = LP_MAX_SPLIT;
   const int fpb = (a.nkeys + nsplit - 1) / nsplit;
