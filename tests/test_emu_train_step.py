@@ -110,15 +110,21 @@ def _maxrel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize('depth,shape', [(18, [4, 2, 3, 2, 32, 32]), (50, [8, 2, 3, 1, 32, 32]),
-                                         # 16x16 feature maps in layer1: halo-tile kernels, folded input BatchNorm, fused dgrad statistics
-                                         (18, [4, 2, 3, 2, 64, 64]),
-                                         # 14x14 / 7x7 maps (the 224 x 224 crop of the shipped configs, scaled down): ragged halo tiles
-                                         (18, [2, 2, 3, 1, 56, 56]),
-                                         # odd, non-square maps (10x14 ... 2x2): views that are not multiples of the 128-pixel
-                                         # statistics rows (one launch per view, statistics from the stored output)
-                                         (18, [8, 2, 3, 1, 40, 56])])
-def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monkeypatch):
+@pytest.mark.parametrize('depth,shape,extra', [
+    (18, [4, 2, 3, 2, 32, 32], None), (50, [8, 2, 3, 1, 32, 32], None),
+    # 16x16 feature maps in layer1: halo-tile kernels, folded input BatchNorm, fused dgrad statistics
+    (18, [4, 2, 3, 2, 64, 64], None),
+    # 14x14 / 7x7 maps (the 224 x 224 crop of the shipped configs, scaled down): ragged halo tiles
+    (18, [2, 2, 3, 1, 56, 56], None),
+    # odd, non-square maps (10x14 ... 2x2): views that are not multiples of the 128-pixel
+    # statistics rows (one launch per view, statistics from the stored output)
+    (18, [8, 2, 3, 1, 40, 56], None),
+    # the backbone's freezing options inside forward_train (resnet.py:577-654): eval-mode BatchNorm backward (dx = g * scale,
+    # dgamma / dbeta from the running statistics), a frozen prefix (no gradients, propagation stops there)
+    (18, [4, 2, 3, 2, 64, 64], dict(frozen_stages=2)), (18, [4, 2, 3, 2, 64, 64], dict(norm_eval=True)),
+    (18, [4, 2, 3, 2, 32, 32], dict(partial_bn=True)), (50, [8, 2, 3, 1, 32, 32], dict(frozen_stages=1)),
+    (50, [8, 2, 3, 1, 32, 32], dict(norm_eval=True))])
+def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, extra, monkeypatch):
     """Tight orchestration check without the chaos: run the fused step, then for the stem, every
     residual block, the head and the loss feed the ENGINE'S OWN input / incoming-gradient buffers
     to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
@@ -127,11 +133,23 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monk
     monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)
     eng = backend.eng
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
-    model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    extra = extra or {}
+    mcfg = dict(cfg.model)
+    mcfg['backbone'] = dict(mcfg['backbone'], **extra)
+    model = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
     ref = _filled(depth)
     model.load_state_dict(ref.state_dict())
     ref.set_emulate_bf16(True).train()
+    _freeze_like_reference(ref.backbone, **extra)
     model.to(backend.dev).train()
+    for (n, pm), (n2, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == n2 and pm.requires_grad == pr.requires_grad, n
+    for (n, mm), (_, mr) in zip(model.named_modules(), ref.named_modules()):
+        if isinstance(mm, torch.nn.modules.batchnorm._BatchNorm):
+            assert mm.training == mr.training, n
+    for prm in model.parameters():
+        if prm.grad is not None:
+            prm.grad.zero_()
     imgs = O.fill_tensor(shape, seed=11, scale=2.0)
     losses = model.forward_train(imgs.to(backend.dev))
     ctx = model._ctx
@@ -146,9 +164,11 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monk
     # near-zero bf16 activation (engine vs oracle rounding) moves a dgamma/dbeta entry by a few percent
     def check_param_grads(prefix, module, tol=4e-2):
         for n, p in module.named_parameters():
-            g = mg[f'{prefix}.{n}'].grad.cpu()
-            if p.grad is None:
+            g = mg[f'{prefix}.{n}'].grad
+            if p.grad is None:       # frozen in the oracle (and, checked above, in the model): no gradient may arrive
+                assert g is None or float(g.abs().max()) == 0.0, (prefix, n)
                 continue
+            g = g.cpu()
             if p.grad.norm() < 1e-3:     # biases in front of a BatchNorm: zero up to rounding residue
                 assert g.norm() < 5e-3, (prefix, n)
             else:
@@ -200,11 +220,22 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monk
     for (lname, bi), bctx in reversed(list(zip(names, ctx['bctx']['blocks']))):
         rblk = getattr(ref.backbone, lname)[bi]
         ref.zero_grad()
+        if g_in is None:          # below the frozen prefix's upper edge: forward only
+            with torch.no_grad():
+                xb = _nchw(bctx['x'])
+                out = torch.cat([rblk(xb[:Nv]), rblk(xb[Nv:])])
+            assert _maxrel(_nchw(bctx['out']), out) < 1.2e-2, (lname, bi)
+            check_param_grads(f'backbone.{lname}.{bi}', rblk)
+            continue
         out, gx = two_views(rblk, _nchw(bctx['x']), g_in)
         assert _maxrel(_nchw(bctx['out']), out) < 1.2e-2, (lname, bi)
+        check_param_grads(f'backbone.{lname}.{bi}', rblk)
+        below = [q for (ln2, b2) in names[:names.index((lname, bi))] for q in getattr(ref.backbone, ln2)[b2].parameters()]
+        if not any(q.requires_grad for q in list(ref.backbone.conv1.parameters()) + below):
+            g_in = None           # nothing trainable further down: the engine does not compute this input gradient
+            continue
         mine_gx = _nchw(B[f'backbone.{lname}.{bi}.conv1.gin'])
         assert _l2rel(mine_gx, gx) < 3e-2, (lname, bi, _l2rel(mine_gx, gx))
-        check_param_grads(f'backbone.{lname}.{bi}', rblk)
         g_in = mine_gx
 
     # ---- stem + max-pool from the (bf16-rounded) frames
@@ -213,7 +244,12 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, monk
 
     def stem(xv):
         return ref.backbone.maxpool(ref.backbone.conv1(xv))
-    pooled, _ = two_views(stem, O.round_bf16(frames), g_in)
+    if g_in is None:
+        with torch.no_grad():
+            fr = O.round_bf16(frames)
+            pooled = torch.cat([stem(fr[:Nv]), stem(fr[Nv:])])
+    else:
+        pooled, _ = two_views(stem, O.round_bf16(frames), g_in)
     assert _maxrel(_nchw(ctx['bctx']['pooled']), pooled) < 1.2e-2
     check_param_grads('backbone.conv1', ref.backbone.conv1)
 
@@ -616,16 +652,95 @@ def test_bit_packed_relu_mask_step_is_bit_identical(backend, depth, shape, monke
         assert torch.equal(sda[k], sdb[k]), k
 
 
-def test_frozen_or_eval_batchnorm_in_train_step_is_refused(backend):
-    """frozen_stages / norm_eval need the eval-mode BatchNorm backward, which the fused step does not have: it must
-    refuse loudly instead of producing wrong gradients"""
+def _freeze_like_reference(backbone, frozen_stages=-1, norm_eval=False, partial_bn=False):
+    """what ResNet.train() does to an (oracle) backbone in training mode, resnet.py:577-654"""
+    if frozen_stages >= 0:
+        backbone.conv1.eval()
+        for p in backbone.conv1.parameters():
+            p.requires_grad = False
+    for i in range(1, frozen_stages + 1):
+        m = getattr(backbone, f'layer{i}')
+        m.eval()
+        for p in m.parameters():
+            p.requires_grad = False
+    bns = [m for m in backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    if norm_eval:
+        for m in bns:
+            m.eval()
+    if partial_bn:
+        for m in bns[1:]:
+            m.eval()
+            m.weight.requires_grad = False
+            m.bias.requires_grad = False
+
+
+@pytest.mark.parametrize('depth,extra', [(18, dict(frozen_stages=1)), (18, dict(norm_eval=True)), (18, dict(partial_bn=True)),
+                                         (50, dict(frozen_stages=1)), (50, dict(norm_eval=True))])
+def test_frozen_stages_norm_eval_partial_bn_step_matches_oracle(backend, depth, extra):
+    """the backbone's freezing options through train_step + the fused SGD: frozen parameters receive no gradient and are not
+    updated, every trainable one does, eval-mode BatchNorm layers keep their running statistics, the loss agrees with the
+    oracle model put into the same state"""
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
+    head = dict(SHALLOW_HEAD, in_channels=128 if depth == 18 else 512)
+    mcfg = dict(cfg.model)
+    mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE, **extra)
+    mcfg['img_head'] = dict(mcfg['img_head'], **head)
+    ref = O.build_tracker(depth, head_kw=head, **SHALLOW)
+    O.fill_state_dict_(ref, seed=5)
+    with torch.no_grad():      # running statistics that are not the identity: eval-mode BatchNorm must use them
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(O.fill_tensor(list(m.running_mean.shape), seed=m.num_features, scale=0.2))
+                m.running_var.copy_(O.fill_tensor(list(m.running_var.shape), seed=m.num_features + 1, scale=0.2).abs() + 0.8)
+    model = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    model.load_state_dict(ref.state_dict())
+    model.to(backend.dev).train()
+    ref.set_emulate_bf16(True).train()
+    _freeze_like_reference(ref.backbone, **extra)
+    for (n, p), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n == n2 and p.requires_grad == p2.requires_grad, n
+    for (n, m), (n2, m2) in zip(model.named_modules(), ref.named_modules()):
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            assert m.training == m2.training, n
+    shape = [4, 2, 3, 2, 32, 32] if depth == 18 else [4, 2, 3, 1, 32, 32]
+    imgs = O.fill_tensor(shape, seed=23, scale=2.0)
+    rloss, rlog = O.parse_losses(ref.forward_train(imgs))
+    rloss.backward()
+    opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    out = model.train_step(dict(imgs=imgs.to(backend.dev), label=torch.zeros(shape[0], 1)), opt)
+    opt.zero_grad()
+    out['loss'].backward()
+    assert abs(out['log_vars']['loss'] - float(rlog['loss'])) < 2e-2
+    rgrads = dict((n, p.grad) for n, p in ref.named_parameters())
+    for n, p in model.named_parameters():      # (gradient VALUES are held to the oracle per stage in test_every_stage_matches_oracle_on_engine_inputs)
+        if not p.requires_grad:
+            assert rgrads[n] is None
+            assert float(p.grad.abs().max()) == 0.0, f'{n} is frozen but received a gradient'
+        else:
+            assert rgrads[n] is not None and float(p.grad.abs().max()) > 0.0, n
+    opt.step()
+    if backend.dev.type == 'cuda':
+        torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            assert torch.equal(p.detach(), before[n]), f'{n} is frozen but was updated'
+    # frozen / eval BatchNorm layers keep their running statistics
+    for (n, m), (_, m2) in zip(model.named_modules(), ref.named_modules()):
+        if isinstance(m, torch.nn.BatchNorm2d) and not m.training:
+            assert torch.allclose(m.running_mean.cpu(), m2.running_mean, atol=0) and torch.allclose(m.running_var.cpu(), m2.running_var, atol=0), n
+
+
+def test_frozen_head_layers_in_train_step_are_refused(backend):
+    """the head has no freezing option in the reference: a frozen parameter / eval-mode BatchNorm there is refused loudly"""
     import vfs_amd
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', 'vfs_r18.py'))
-    for extra in (dict(frozen_stages=1), dict(norm_eval=True)):
-        mcfg = dict(cfg.model)
-        mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE, **extra)
-        mcfg['img_head'] = dict(mcfg['img_head'], **SHALLOW_HEAD)
-        m = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(backend.dev).train()
-        opt = vfs_amd.build_optimizer(m, cfg.optimizer)
-        with pytest.raises(NotImplementedError):
-            m.train_step(dict(imgs=torch.randn(2, 2, 3, 1, 32, 32).to(backend.dev), label=torch.zeros(2, 1)), opt)
+    mcfg = dict(cfg.model)
+    mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE)
+    mcfg['img_head'] = dict(mcfg['img_head'], **SHALLOW_HEAD)
+    m = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(backend.dev).train()
+    next(m.img_head.parameters()).requires_grad = False
+    opt = vfs_amd.build_optimizer(m, cfg.optimizer)
+    with pytest.raises(NotImplementedError):
+        m.train_step(dict(imgs=torch.randn(2, 2, 3, 1, 32, 32).to(backend.dev), label=torch.zeros(2, 1)), opt)

@@ -360,6 +360,8 @@ class Engine:
         the mask is recomputed from raw inside the kernels."""
         if NOMASK:
             ymask = None       # what-if only (WRONG gradients): the step without the mask operand reads
+        if not u.bn.training:
+            return self._bn_bwd_eval(u, g, ymask, raw, M, want_gm, relu)
         dev = raw.device
         s = self.stream(dev)
         lib = self.lib
@@ -397,6 +399,49 @@ class Engine:
                    float(mpg * self.world), rl, s)
         return dx, gm
 
+    def zero_sums(self, C, dev):
+        """double[1][2][C] of zeros (never written): BatchNorm backward without the batch-statistic terms"""
+        key = f'ws.zero_sums.{C}'
+        t = self.bufs.get(key)
+        if t is None or t.device != dev:
+            t = torch.zeros(1, 2, C, dtype=torch.float64, device=dev)
+            self.bufs[key] = t
+            self.generation += 1
+        return t
+
+    def _bn_bwd_eval(self, u, g, ymask, raw, M, want_gm, relu):
+        """BatchNorm in eval mode inside a training step (resnet.py:577-654: frozen_stages, norm_eval, partial_bn): the output is
+        an affine map of the input with FIXED coefficients, so dx = g * mask * scale - the apply kernel with zero statistic
+        sums - and, when gamma / beta are still trained (norm_eval), dgamma = sum g*mask*xhat, dbeta = sum g*mask with xhat
+        from the running statistics.  One group, no SyncBN exchange (the parameter gradients are local sums like any other)."""
+        dev = raw.device
+        s = self.stream(dev)
+        lib = self.lib
+        C = u.cout
+        bits = ymask is not None and ymask.dtype == torch.uint8
+        rl = 2 if bits else (1 if relu else 0)
+        fused = getattr(self, '_fused_bn', None)
+        self._fused_bn = None
+        if u.bn.weight.requires_grad or u.bn.bias.requires_grad:
+            if fused is not None and fused[0] is u:
+                partial, nblk = fused[1], fused[2]
+            else:
+                ppb = math.gcd(M, 512)
+                if ppb < 16:
+                    ppb = M
+                nblk = M // ppb
+                partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
+                self.timed('bn_bwd_reduce', (0.0, 4.0 * M * C), dev, lib.bn_bwd_reduce, g, ymask, raw, u.bnp, partial, M, C, M, ppb, rl, s)
+            scratch = self.buf(f'{u.name}.bsums', (1, 2, C), torch.float64, dev)
+            self.timed('bn_stats', (0.0, 8.0 * nblk * C), dev, lib.bn_bwd_sums_paramgrad, partial, scratch, self.bn_scratch(1, C, dev),
+                       u.bn.weight.grad, u.bn.bias.grad, 1, nblk, C, s)
+        dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
+        want_gm = want_gm and not (bits and MASK_ADD)
+        gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
+        self.timed('bn_bwd_apply', (0.0, 2.0 * M * C * (3 + want_gm)), dev, lib.bn_bwd_apply, g, ymask, raw, u.bnp, self.zero_sums(C, dev), dx, gm,
+                   M, C, M, 1.0, rl, s)
+        return dx, gm
+
     def _bwd_sums(self, u, partial, G, bpg, C, dev):
         """partial (S1, S2) rows -> u.bsums (all-reduced for SyncBN) and dgamma / dbeta (local sums)"""
         s = self.stream(dev)
@@ -422,6 +467,8 @@ class Engine:
         s = self.stream(dev)
         lib = self.lib
         C = u.cout
+        if not u.bn.training:      # eval-mode BatchNorm (norm_eval): one group, no statistic terms in dx (zero sums)
+            G = 1
         npg = N // G
         mpg_p = npg * Hp * Wp
         ppb = math.gcd(mpg_p, 256)
@@ -432,8 +479,15 @@ class Engine:
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
         self.timed('bn_bwd_reduce', (0.0, (2.0 * 3 + 1.0) * N * Hp * Wp * C), dev, lib.stem_pool_bn_bwd_reduce, gp, yp, idx, raw, xpool,
                    u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
-        self._bwd_sums(u, partial, G, nblk // G, C, dev)
-        return float(npg * H * W * self.world)
+        if u.bn.training:
+            self._bwd_sums(u, partial, G, nblk // G, C, dev)
+            return float(npg * H * W * self.world)
+        if u.bn.weight.requires_grad or u.bn.bias.requires_grad:
+            scratch = self.buf(f'{u.name}.bsums_eval', (1, 2, C), torch.float64, dev)
+            self.timed('bn_stats', (0.0, 8.0 * nblk * C), dev, lib.bn_bwd_sums_paramgrad, partial, scratch, self.bn_scratch(1, C, dev),
+                       u.bn.weight.grad, u.bn.bias.grad, 1, nblk, C, s)
+        u.bsums = self.zero_sums(C, dev)
+        return 1.0
 
     # ------------------------------------------------------------------ side stream for weight gradients
     def on_side_stream(self, dev):
@@ -468,7 +522,7 @@ class Engine:
             self.timed('stem_wgrad', (2.0 * N * H * W * 64 * 147, 2.0 * N * (Hin * Win * 4 + H * W * 64) + 5.0 * N * Hp * Wp * 64),
                        dev, self.lib.stem_wgrad_fused,
                        x4, raw, gp, yp, idx, u.bnp, u.bsums, partial, self.wgrad_target(u, partial, nblocks, 64, 224, 3, 7, 1),
-                       N, Hin, Win, H, W, Hp, Wp, N // G, count, nblocks, self.stream(dev))
+                       N, Hin, Win, H, W, Hp, Wp, (N // G) if u.bn.training else N, count, nblocks, self.stream(dev))
 
     def wgrad_partial(self, u, nsplit, cout, ktot, dev):
         """split-K workspace of unit u's weight gradient: the shared scratch (reduced right after the kernel) or, when the
@@ -523,27 +577,29 @@ class Engine:
         ktot = u.k * u.k * u.cin
         halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
-        partial = self.wgrad_partial(u, nsplit, u.cout, ktot, dev)
+        partial = self.wgrad_partial(u, nsplit, u.cout, ktot, dev) if u.weight.requires_grad else None
         flops = 2.0 * M * u.cout * ktot
         # ALGORITHMIC bytes: dY + x once, the fp32 gradient read-modify-write.  (The fp32 split-K partials - written by the
         # kernel, re-read by the reduction: 8 * nsplit * Cout * Ktot bytes - are implementation traffic; they show up in the
         # PMC 'traffic' figure, not here.)
         wbytes = 2.0 * (M * u.cout + N * H * W * u.cin) + 8.0 * u.cout * ktot
-        wtarget = self.wgrad_target(u, partial, nsplit, u.cout, ktot, u.cin, u.k, 0)
         # dgrad: dY + weights in, dx out (+ residual gradient / fused BatchNorm operands when present)
         dbytes = 2.0 * (M * u.cout + N * H * W * u.cin + u.cout * ktot)
         # the weight gradient only feeds the optimizer: it runs on the side stream, concurrently
-        # with the dgrad / BatchNorm-backward kernels of the critical path (joined by wgrad_join)
-        with self.on_side_stream(dev):
-            ss = self.stream(dev)
-            if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
-                self.timed('conv3x3_wgrad_halo', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
-                           wtarget, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
-            else:
-                self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, wtarget, N, H, W, u.cin, Ho,
-                           Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
-            if u.bias is not None:
-                lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)
+        # with the dgrad / BatchNorm-backward kernels of the critical path (joined by wgrad_join).  Frozen weights
+        # (requires_grad = False: frozen_stages) get none.
+        if u.weight.requires_grad:
+            wtarget = self.wgrad_target(u, partial, nsplit, u.cout, ktot, u.cin, u.k, 0)
+            with self.on_side_stream(dev):
+                ss = self.stream(dev)
+                if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
+                    self.timed('conv3x3_wgrad_halo', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
+                               wtarget, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+                else:
+                    self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, wtarget, N, H, W, u.cin, Ho,
+                               Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+                if u.bias is not None and u.bias.requires_grad:
+                    lib.bias_grad(dx, u.bias.grad, M, u.cout, ss)
         if not need_dgrad:
             return None
         gin = g_out if g_out is not None else self.buf(f'{u.name}.gin', (N, H, W, u.cin), BF16, dev)

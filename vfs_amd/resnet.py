@@ -332,8 +332,16 @@ class ResNet(nn.Module):
             stage_start[bi] = si
             bi += len(getattr(self, lname))
             stage_end[bi - 1] = si
+        # frozen_stages (resnet.py:577-599) freezes a PREFIX of the net: gradients are only propagated down to the first layer
+        # that still has something to train
+        def trainable(mod):
+            return any(p.requires_grad for p in mod.parameters())
+        stem_trains = trainable(self.conv1)
+        first = 0 if stem_trains else next((i for i, b in enumerate(blocks) if trainable(b['blk'])), len(blocks))
         g = None
         for i in range(len(blocks) - 1, -1, -1):
+            if i < first:
+                break
             si = stage_end.get(i)
             if si is not None and si in grads:
                 gs = grads[si]
@@ -346,9 +354,13 @@ class ResNet(nn.Module):
             # the BatchNorm unit that consumes this block's INPUT gradient: the join unit of the block before
             prev = blocks[i - 1] if i > 0 else None
             next_bn = None if prev is None else (prev['blk'].convs[-1].unit, prev['raws'][-1], prev['mask'])
-            g = self._block_bwd(eng, blocks[i], g, N, G, next_bn)
+            g = self._block_bwd(eng, blocks[i], g, N, G, next_bn, need_input_grad=stem_trains or i > first)
             if on_stage_done is not None and i in stage_start:
                 on_stage_done(getattr(self, self.res_layers[stage_start[i]]))
+        if not stem_trains:
+            if on_stage_done is not None:
+                on_stage_done(self.conv1)
+            return
         # stem: maxpool+relu backward -> BN backward -> wgrad
         dev = g.device
         Hs, Ws = ctx['Hs'], ctx['Ws']
@@ -361,14 +373,17 @@ class ResNet(nn.Module):
         else:   # materialise dx, then the generic implicit-GEMM stem wgrad
             dx = eng.buf('backbone.conv1.dx', ctx['stem_raw'].shape, BF16, dev)
             eng.lib.stem_pool_bn_bwd_apply(g, ctx['pooled'], ctx['idx'], ctx['stem_raw'], stem.bnp, stem.bsums, dx, N, Hs,
-                                           Ws, 64, ctx['Hp'], ctx['Wp2'], N // G, count, eng.stream(dev))
+                                           Ws, 64, ctx['Hp'], ctx['Wp2'], (N // G) if stem.bn.training else N, count, eng.stream(dev))
             eng.conv_bwd(stem, dx, ctx['x4'], N, ctx['H'], ctx['Wp'], Hs, Ws, need_dgrad=False)
         if on_stage_done is not None:
             on_stage_done(self.conv1)
 
-    def _block_bwd(self, eng, bctx, g, N, G, next_bn=None):
+    def _block_bwd(self, eng, bctx, g, N, G, next_bn=None, need_input_grad=True):
         """next_bn = (unit, raw, out) of the preceding block's join: the dgrad that completes this block's
-        input gradient also emits that unit's BatchNorm-backward statistics (Engine.conv_bwd)."""
+        input gradient also emits that unit's BatchNorm-backward statistics (Engine.conv_bwd).
+        need_input_grad=False (everything below is frozen): the dgrads towards the block input are skipped."""
+        def groups(unit):      # statistics groups of a unit's BatchNorm backward: one when it runs in eval mode
+            return G if unit.bn.training else 1
         blk = bctx['blk']
         convs = blk.convs
         last = len(convs) - 1
@@ -388,14 +403,14 @@ class ResNet(nn.Module):
             x_in = bctx['x'] if ci == 0 else bctx['acts'][ci - 1]
             add = gm if (ci == 0 and blk.downsample is None) else None
             if ci > 0:       # plain conv-BN-ReLU unit in front: its statistics come out of this dgrad
-                bn_next = (convs[ci - 1].unit, bctx['raws'][ci - 1], None, True, G)
+                bn_next = (convs[ci - 1].unit, bctx['raws'][ci - 1], None, True, groups(convs[ci - 1].unit))
             elif blk.downsample is None and next_bn is not None:
-                bn_next = (next_bn[0], next_bn[1], next_bn[2], True, G)
+                bn_next = (next_bn[0], next_bn[1], next_bn[2], True, groups(next_bn[0]))
             else:
                 bn_next = None
             x_in_bn = bctx['act_bn'][ci - 1] if ci > 0 else None
-            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=True, add=add, bn_next=bn_next, x_in_bn=x_in_bn,
-                               add_mask=gmask if add is not None else None)
+            gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=(ci > 0 or need_input_grad), add=add, bn_next=bn_next,
+                               x_in_bn=x_in_bn, add_mask=gmask if add is not None else None)
             if ci > 0:
                 p = convs[ci - 1]
                 _, _, ph, pw = bctx['dims'][ci - 1]
@@ -403,8 +418,8 @@ class ResNet(nn.Module):
         if blk.downsample is not None:
             d = blk.downsample
             boh, bow = bctx['dims'][last][2:]
-            bn_next = None if next_bn is None else (next_bn[0], next_bn[1], next_bn[2], True, G)
-            gin = eng.conv_bwd(d.unit, ddx, bctx['x'], N, h, w, boh, bow, need_dgrad=True, add=gin, g_out=gin, bn_next=bn_next)
+            bn_next = None if next_bn is None else (next_bn[0], next_bn[1], next_bn[2], True, groups(next_bn[0]))
+            gin = eng.conv_bwd(d.unit, ddx, bctx['x'], N, h, w, boh, bow, need_dgrad=need_input_grad, add=gin, g_out=gin, bn_next=bn_next)
         return gin
 
     # ------------------------------------------------------------------ module-level forward

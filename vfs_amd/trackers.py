@@ -405,16 +405,20 @@ class SimSiamBaseTracker(BaseTracker):
         self._ctx = None
 
     def _check_trainable(self):
-        """the fused step implements batch-statistics BatchNorm and gradients for EVERY parameter; frozen stages /
-        norm_eval / partial_bn (resnet.py:577-654) would need the eval-mode BatchNorm backward (dx = g * scale, no
-        statistics) and skipped weight gradients - refuse instead of returning wrong gradients"""
-        for name, m in self.named_modules():
+        """the backbone's freezing options (frozen_stages / norm_eval / partial_bn, resnet.py:577-654) are on the HIP path: eval-mode
+        BatchNorm backward without statistic terms, no weight gradients for frozen layers, propagation stops at the frozen
+        prefix.  The head has no such option in the reference: a frozen / eval-mode head layer is refused rather than guessed."""
+        for name, m in self.img_head.named_modules():
             if isinstance(m, nn.modules.batchnorm._BatchNorm) and not m.training:
-                raise NotImplementedError(f'{name}: BatchNorm in eval mode inside forward_train (frozen_stages / norm_eval / '
-                                          'partial_bn) is not on the HIP training path')
-        for name, p in self.named_parameters():
+                raise NotImplementedError(f'img_head.{name}: BatchNorm in eval mode inside forward_train is not on the HIP training path')
+        for name, p in self.img_head.named_parameters():
             if not p.requires_grad:
-                raise NotImplementedError(f'{name}: requires_grad=False inside forward_train is not on the HIP training path')
+                raise NotImplementedError(f'img_head.{name}: requires_grad=False inside forward_train is not on the HIP training path')
+        bb = self.backbone
+        frozen = [i for i, (_, m) in enumerate(bb.conv_modules()) if not m.conv.weight.requires_grad]
+        if frozen and frozen != list(range(len(frozen))):
+            raise NotImplementedError('frozen convolution weights must form a prefix of the backbone (frozen_stages); other patterns '
+                                      'are not on the HIP training path')
 
     def _hip_forward_train(self, imgs):
         eng = shared_engine()
