@@ -3,6 +3,7 @@ prototypes are parsed from it).  There is NO fallback: if the HIP library is mis
 product path raises immediately."""
 import ctypes
 import os
+import sys
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -73,8 +74,13 @@ class VfsLib:
         if fn is None:
             raise AttributeError(name)
 
+        trace = os.environ.get('VFS_TRACE_CALLS') == '1'      # diagnostics: name every entry point before it runs (with
+                                                              # AMD_SERIALIZE_KERNEL=3 the last line names a faulting launch)
+
         def call(*args):
             conv = [a.data_ptr() if hasattr(a, 'data_ptr') else a for a in args]
+            if trace:
+                print(f'[vfs] {name}({", ".join(str(c) for c in conv[-14:])})', file=sys.stderr, flush=True)
             rc = fn(*conv)
             if isinstance(rc, int) and rc != 0:
                 raise VfsError(f'vfs_{name} failed ({rc}): {self.last_error()}')

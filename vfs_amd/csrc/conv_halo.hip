@@ -167,7 +167,8 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
     if (ok) st16(a.out + o, gv);
     if (do_bn) {
       if (i == 0) {   // statistics group of this wave's pixels: from the tile's first pixel (always inside the map)
-        const size_t m0 = ((size_t)(tn0 + (SMALLW ? wp : 0)) * g.H + y0) * g.W + x0;
+        const int img = min(tn0 + (SMALLW ? wp : 0), g.N - 1);      // the second image of a small-map tile may not exist (odd N)
+        const size_t m0 = ((size_t)img * g.H + y0) * g.W + x0;
         bnfuse_init(bl, a.bn, a.Cout, (int)(m0 / a.bn.mpg), c0 + wc * 64 + ch * 8);
       }
       if (ok) bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);

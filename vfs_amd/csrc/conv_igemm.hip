@@ -423,7 +423,9 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   }
   {
     const int ch = lane % CPR, c = c0 + wc * WC + ch * 8;
-    if (do_bn && c < a.Cout) bnfuse_init(bl, a.bn, a.Cout, (m0 + wp * 64) / a.bn.mpg, c);
+    // statistics group of this wave's 64 rows (blocks never straddle groups); a wave whose rows all lie past M - a single ragged
+    // block of a tiny map - must not index a group that does not exist
+    if (do_bn && c < a.Cout) bnfuse_init(bl, a.bn, a.Cout, min(m0 + wp * 64, Mc - 1) / a.bn.mpg, c);
 #pragma unroll
     for (int i = 0; i < CPR; ++i) {
       const int p = i * PPI + lane / CPR;
