@@ -130,6 +130,8 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, extr
     to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
     and require outputs, input gradients and parameter gradients to agree to bf16 rounding."""
     import vfs_amd
+    if backend.name == 'emu' and depth == 50 and extra and 'norm_eval' in extra:
+        pytest.skip('the ResNet-50 norm_eval case takes a minute on the emulator; the GPU runs it (R18 covers the emulator)')
     monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)
     eng = backend.eng
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
