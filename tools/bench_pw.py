@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """1x1 (pointwise) convolutions of ResNet-50 at the bench batch (64 frames of 256x256): time and algorithmic
 GB/s of forward and dgrad through the implicit-GEMM kernel, for A/B of its options
-(tools/bench_pw.py [opt=value ...], e.g. igemm_onek=0 igemm_bc=64)."""
+(tools/bench_pw.py [fbn] [opt=value ...], e.g. igemm_onek=0 igemm_bc=64; fbn also times the dgrad with the
+mask-gated identity add and the fused BatchNorm-backward statistics)."""
 import os
 import sys
 
@@ -31,13 +32,14 @@ def timeit(fn, iters=30):
 
 def main():
     lib = get_lib()
-    for kv in sys.argv[1:]:
+    fbn = 'fbn' in sys.argv[1:]
+    for kv in [a for a in sys.argv[1:] if '=' in a]:
         k, v = kv.split('=')
         lib.set_option(k.encode(), int(v))
     dev = torch.device('cuda:0')
     s = torch.cuda.current_stream().cuda_stream
     print(' '.join(sys.argv[1:]) or 'defaults')
-    tot = [0.0, 0.0]
+    tot = [0.0, 0.0, 0.0]
     for (N, H, W, Cin, Cout) in SHAPES:
         M = N * H * W
         x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
@@ -51,8 +53,21 @@ def main():
         tf = timeit(lambda: lib.conv_fwd(x, wf, y, None, stats, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, s))
         td = timeit(lambda: lib.conv_dgrad(dy, wd, dx, None, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, s))
         tot[0] += tf; tot[1] += td
-        print(f'{str((N, H, W, Cin, Cout)):28s} fwd {tf * 1e6:7.1f} us {nbytes / tf / 1e9:7.0f} GB/s   dgrad {td * 1e6:7.1f} us {nbytes / td / 1e9:7.0f} GB/s')
-    print(f'sum us: fwd {tot[0] * 1e6:.1f} dgrad {tot[1] * 1e6:.1f}')
+        line = f'{str((N, H, W, Cin, Cout)):28s} fwd {tf * 1e6:7.1f} us {nbytes / tf / 1e9:7.0f} GB/s   dgrad {td * 1e6:7.1f} us {nbytes / td / 1e9:7.0f} GB/s'
+        if fbn and M % 128 == 0:
+            # the dgrad as the train step runs it at a block input: + identity gradient gated by the mask bits + BatchNorm-backward
+            # statistics of the [M][Cin] tensor it produces (raw x of that unit + its mask bits as operands)
+            add = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
+            xr = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
+            bits = torch.randint(0, 256, (M * Cin // 8,), device=dev, dtype=torch.uint8)
+            bnp = torch.rand(1, 4, Cin, device=dev) + 0.5
+            part = torch.empty((M // 128) * 2 * Cin, device=dev)
+            tb = timeit(lambda: lib.conv_dgrad_bn_maskadd(dy, wd, dx, add, bits, xr, bits, bnp, part, M, 2, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, s))
+            fb = 2.0 * (M * Cout + 3 * M * Cin + Cin * Cout) + 2.0 * M * Cin / 8
+            tot[2] += tb
+            line += f'   dgrad+add+stats {tb * 1e6:7.1f} us {fb / tb / 1e9:7.0f} GB/s'
+        print(line)
+    print(f'sum us: fwd {tot[0] * 1e6:.1f} dgrad {tot[1] * 1e6:.1f}' + (f' dgrad+add+stats {tot[2] * 1e6:.1f}' if fbn else ''))
 
 
 if __name__ == '__main__':
