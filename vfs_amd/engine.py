@@ -386,7 +386,7 @@ class Engine:
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
         # with the bit-packed mask the masked gradient is not materialised: its consumers take (g, mask) instead (conv_bwd add_mask,
         # the downsample unit's bn_bwd)
-        want_gm = want_gm and not (bits and MASK_ADD)
+        want_gm = want_gm and not (bits and MASK_ADD and C % 64 == 0)      # (the mask-gated add reads whole 64-channel mask words)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
         abytes = 2.0 * M * C * (3 + want_gm) + mask_bytes      # g, raw in; dx out; activation (or its bit mask) in; masked gradient out
         if FIN_FUSE and not self.collectives_on and nblk // G <= FIN_MAX_ROWS:
@@ -436,7 +436,7 @@ class Engine:
             self.timed('bn_stats', (0.0, 8.0 * nblk * C), dev, lib.bn_bwd_sums_paramgrad, partial, scratch, self.bn_scratch(1, C, dev),
                        u.bn.weight.grad, u.bn.bias.grad, 1, nblk, C, s)
         dx = self.buf(f'{u.name}.dx', raw.shape, BF16, dev)
-        want_gm = want_gm and not (bits and MASK_ADD)
+        want_gm = want_gm and not (bits and MASK_ADD and C % 64 == 0)      # (the mask-gated add reads whole 64-channel mask words)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
         self.timed('bn_bwd_apply', (0.0, 2.0 * M * C * (3 + want_gm)), dev, lib.bn_bwd_apply, g, ymask, raw, u.bnp, self.zero_sums(C, dev), dx, gm,
                    M, C, M, 1.0, rl, s)
