@@ -252,6 +252,28 @@ def test_forward_test_fp32_options_bit_exact_vs_oracle(backend, opts):
         assert float((out[0] == lab).mean()) > 0.999
 
 
+@pytest.mark.parametrize('T,crop', [(1, (16, 64, 24, 88)), (2, (16, 64, 24, 88)), (3, (10, 61, 20, 93)), (5, (0, 40, 0, 56))])
+def test_forward_test_fp32_edge_clips(backend, T, crop):
+    """edge cases of the clip: a single frame (the output is the resized reference map only), two frames (one key frame), sizes
+    that are not multiples of the stride (51 x 73: ragged feature map, PIL-nearest resize of the map), a clip shorter than the
+    key-frame window - all bit-exact against the C oracle"""
+    model, ref, tc = _davis_model(backend.dev)
+    imgs, seg, _, _ = _clip()
+    y0, y1, x0, x1 = crop
+    imgs = imgs[:, :, :, :T, y0:y1, x0:x1].contiguous()
+    seg = np.ascontiguousarray(seg[y0:y1, x0:x1])
+    H, W = y1 - y0, x1 - x0
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None],
+                img_meta=[dict(original_shape=(H, W, 3))])
+    assert out[0].shape == (T, H, W) and out[0].dtype == np.uint8
+    want = X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc)
+    assert np.array_equal(out[0], want)
+    lab = ref.forward_test(imgs, seg, (H, W, 3))           # the torch restatement of the reference's own code path
+    assert np.array_equal(out[0][0], lab[0])               # frame 0: the resized reference map itself
+    if T > 1:
+        assert float((out[0] == lab).mean()) > 0.995
+
+
 def test_forward_test_onehot_reference_map(backend):
     """4-D (one-hot / soft) ref_seg_map (vanilla_tracker.py:94-111): bilinear resizes, soft maps returned"""
     model, ref, tc = _davis_model(backend.dev)
