@@ -43,6 +43,7 @@ def test_two_ranks_equal_one_process(tmp_path):
     def l2(a, b):
         return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
+    worst = []
     for k in s.files:
         if k.startswith('log/'):
             assert abs(float(r0[k]) - float(s[k])) < 2e-3 and abs(float(r0[k]) - float(r1[k])) < 1e-6, k
@@ -51,9 +52,11 @@ def test_two_ranks_equal_one_process(tmp_path):
         elif k.startswith('grad/'):
             assert np.array_equal(r0[k], r1[k]), k             # both ranks hold the reduced gradient
             if np.linalg.norm(s[k]) > 1e-3:
-                assert l2(r0[k], s[k]) < 3e-2, (k, l2(r0[k], s[k]))
+                worst.append((l2(r0[k], s[k]), k))
+                assert l2(r0[k], s[k]) < 1e-4, (k, l2(r0[k], s[k]))       # measured: <= 2e-6 (fp32 summation order of the split weight gradients)
         elif k.startswith('param/'):
             assert np.array_equal(r0[k], r1[k]), k             # replicas stay in lock-step after SGD
+    print('largest relative L2 gradient differences 2 ranks vs 1 process:', sorted(worst, reverse=True)[:5])
 
 
 def _run_ranks(tmp_path, tag, extra_env):
