@@ -138,6 +138,8 @@ def test_forward_test_all_blocks(backend):
     statistical agreement with the reference's fp32 labels per block, last block = the single-feature path"""
     import os
     import vfs_amd
+    if backend.name == 'emu':
+        pytest.skip('the bf16 all_blocks clip takes 20 s on the emulator; the GPU runs it (the fp32 all_blocks test covers the emulator)')
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'forward_test_r18_all_blocks.npz'))
     cfg = vfs_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(__file__)), 'configs', 'vfs_r18.py'))
     tc = vfs_amd.ConfigDict(cfg.test_cfg)

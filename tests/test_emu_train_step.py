@@ -130,8 +130,8 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, extr
     to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
     and require outputs, input gradients and parameter gradients to agree to bf16 rounding."""
     import vfs_amd
-    if backend.name == 'emu' and depth == 50 and extra and 'norm_eval' in extra:
-        pytest.skip('the ResNet-50 norm_eval case takes a minute on the emulator; the GPU runs it (R18 covers the emulator)')
+    if backend.name == 'emu' and depth == 50 and extra:
+        pytest.skip('the ResNet-50 freezing cases take a minute each on the emulator; the GPU runs them (R18 covers the emulator)')
     monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)
     eng = backend.eng
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
@@ -622,6 +622,8 @@ def test_bit_packed_relu_mask_step_is_bit_identical(backend, depth, shape, monke
     (engine.MASK_BITS, VFS_MASK_BITS): losses and every parameter after two steps equal the run that reads y, bit for bit"""
     import vfs_amd
     from vfs_amd import engine as E
+    if backend.name == 'emu' and depth == 50:
+        pytest.skip('ResNet-50 on the emulator takes half a minute; the GPU runs it (R18 covers the emulator)')
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
     mcfg = dict(cfg.model)
     mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE)
