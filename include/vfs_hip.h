@@ -31,8 +31,13 @@ int vfs_abi_version(void);
  * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default), "bn_ticket",
  * "igemm_onek" (single-buffer implicit-GEMM variant: 0 never, 1 one-K-step problems, 2 every 1x1 (default), 3 all),
  * "igemm_ring_tiles" (1x1 problems with at most this many tiles use the LDS-DMA ring, default 512, 0 = off),
- * "igemm_ring_upfront" (ring variant: all fragment reads of a K-step before its MFMAs; default 0, not yet measured),
- * "igemm_bc" (64 forces the 64-channel tile) */
+ * "igemm_ring_upfront" (ring variant: all fragment reads of a K-step before its MFMAs; default 0: measured, no gain),
+ * "igemm_ring_fbn" (the ring also for dgrads with fused BatchNorm-backward statistics, default 1),
+ * "igemm_bc" (64 forces the 64-channel tile), "igemm_xcd" (XCD-aware tile order, default 1),
+ * "igemm_narrow_below" (64-channel tiles when the 128-channel tiling has fewer tiles than this, default 513),
+ * "igemm_mfma_stats" (forward statistics rows on the matrix cores, default 1),
+ * "wgrad_lin" (linear-address path of the generic weight gradient for 1x1 / stride-1 problems, default 1),
+ * "halo_min_fill", "bn_chunk_rows", "lpx_target" (workgroups of the fp32 label propagation; 0 = by channel count) */
 int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------
