@@ -94,19 +94,36 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
   }
   // fused BatchNorm-backward statistics: this lane's eight (pixel, 8-channel chunk) operands are
   // requested NOW, before the accumulators are converted and staged, and consumed in the row-store loop
-  u32x4 bxv[8], byv[8];
+  // (straight-line batches, pixels outside the map clamped to the tile's first pixel - always inside: loads inside per-pixel
+  // conditionals made the compiler wait for each one separately, see conv_igemm.hip)
+  u32x4 bxv[8];
+  unsigned bym[8];
   if (do_bn) {
+    const int cch = c0 + wc * 64 + (lane & 7) * 8;
+    const size_t mfirst = ((size_t)tn0 * g.H + y0) * g.W + x0;
+    size_t mrow[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int p = i * 8 + (lane >> 3);
       int ti, py, px;
       halo_pixel<SMALLW>(wp, p >> 4, p & 15, ti, py, px);
-      const size_t mrow = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
-      const int cch = c0 + wc * 64 + (lane & 7) * 8;
-      const size_t o = mrow * a.Cout + cch;
-      const bool ok = (oki >> i) & 1u;
-      bxv[i] = ok ? ld16(a.bn.x + o) : zero16();
-      byv[i] = (ok && a.bn.y) ? bnfuse_load_mask(a.bn, (long long)mrow, cch, (long long)g.N * g.H * g.W, a.Cout) : zero16();
+      mrow[i] = ((oki >> i) & 1u) ? ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px) : mfirst;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bxv[i] = ld16(a.bn.x + mrow[i] * a.Cout + cch);
+    const long long rows = (long long)g.N * g.H * g.W;
+    if (a.bn.y && a.bn.relu == VFS_MASK_BITS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bym[i] = mask8_load(a.bn.y, (long long)mrow[i], cch, rows, a.Cout);
+    } else if (a.bn.y) {
+#pragma unroll
+      for (int h = 0; h < 8; h += 4) {
+        u32x4 yv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yv[i] = ld16(a.bn.y + mrow[h + i] * a.Cout + cch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bym[h + i] = mask8_of(yv[i]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -118,11 +135,12 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
     if (do_add) {
       int ti, py, px;
       halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
-      const size_t mdst = ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px);
+      // pixels outside the map: clamped to the tile's first pixel (inside), so that the loads carry no per-lane condition
+      const size_t mdst = okp ? ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px) : ((size_t)tn0 * g.H + y0) * g.W + x0;
       const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) ad[tm] = okp ? ld8(a.add + obase + tm * 16) : (u32x2){0u, 0u};
-      if (a.add_mask && okp) amw = addmask_word<64>(a.add_mask, (long long)mdst, c0 + wc * 64, a.add_rows, a.Cout);
+      for (int tm = 0; tm < TM; ++tm) ad[tm] = ld8(a.add + obase + tm * 16);
+      if (a.add_mask) amw = addmask_word<64>(a.add_mask, (long long)mdst, c0 + wc * 64, a.add_rows, a.Cout);
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -171,7 +189,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
         const size_t m0 = ((size_t)img * g.H + y0) * g.W + x0;
         bnfuse_init(bl, a.bn, a.Cout, (int)(m0 / a.bn.mpg), c0 + wc * 64 + ch * 8);
       }
-      if (ok) bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);
+      if (ok) bnfuse_accum(bl, a.bn, gv, bxv[i], bym[i]);
     }
   }
   if (do_bn) {

@@ -336,26 +336,65 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   constexpr int CPR = WC / 8, PPI = 64 / CPR;     // 16-byte chunks per staged row, pixels per store instruction
   const bool do_bn = CAN_BN && a.bn.partial != nullptr;
   BnFuseLane bl;
-  u32x4 bxv[CPR], byv[CPR];
+  // Every operand of the epilogue is requested HERE, in straight-line batches, before any of it is used.  (Loads placed next
+  // to their use inside the conditional tile loops - the first version - made the compiler wait for each one separately:
+  // s_waitcnt vmcnt(0) after each of the 16 residual loads and after each of the 8 statistics-operand pairs of a lane, i.e.
+  // ~24 dependent memory round trips per workgroup; SQ counters of the 64 -> 256 dgrad: waves waiting 75 % of their lifetime.)
+  u32x4 bxv[CPR];
+  unsigned bym[CPR];        // ReLU-mask byte of each piece (from the bit-packed mask, or compressed from the activation on arrival)
   if (do_bn && c0 + wc * WC + (lane % CPR) * 8 < a.Cout) {
+    const int cch = c0 + wc * WC + (lane % CPR) * 8;
+    int mmv[CPR];
 #pragma unroll
     for (int i = 0; i < CPR; ++i) {
       const int m = m0 + wp * 64 + i * PPI + lane / CPR;
-      const int mm = m < Mc ? m : m0, cch = c0 + wc * WC + (lane % CPR) * 8;
-      const size_t o = (size_t)mm * a.Cout + cch;
-      bxv[i] = ld16(a.bn.x + o);
-      if (a.bn.y) byv[i] = bnfuse_load_mask(a.bn, mm, cch, Mc, a.Cout);
+      mmv[i] = m < Mc ? m : m0;
+    }
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) bxv[i] = ld16(a.bn.x + (size_t)mmv[i] * a.Cout + cch);
+    if (a.bn.y && a.bn.relu == VFS_MASK_BITS) {
+#pragma unroll
+      for (int i = 0; i < CPR; ++i) bym[i] = mask8_load(a.bn.y, mmv[i], cch, Mc, a.Cout);
+    } else if (a.bn.y) {          // the activation itself as mask operand: reduced to its mask byte (same test, y > 0) in two batches
+#pragma unroll
+      for (int h = 0; h < CPR; h += 4) {
+        u32x4 yv[4];
+#pragma unroll
+        for (int i = 0; i < 4 && h + i < CPR; ++i) yv[i] = ld16(a.bn.y + (size_t)mmv[h + i] * a.Cout + cch);
+#pragma unroll
+        for (int i = 0; i < 4 && h + i < CPR; ++i) bym[h + i] = mask8_of(yv[i]);
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
 
+  // the residual operand (`add`) in the accumulator layout - 8 bytes per MFMA tile and lane - is requested for TWO pixel
+  // tiles at a time (8 loads in flight per lane, two round trips in all; all 16 at once costs 32 more VGPRs and spills);
+  // rows / channels past the edge are clamped to a valid address, their values are never used
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
+  for (int th = 0; th < TN; th += 2) {
+  u32x2 adv[2][TM];
+  unsigned long long amwv[2];
+  if (do_add) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int m = m0 + wp * 64 + (th + t2) * 16 + lr;
+      const size_t mdst = pixel_dst(m < Mc ? m : m0);
+      const int cw = c0 + wc * WC < a.Cout ? c0 + wc * WC : c0;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int c = c0 + wc * WC + tm * 16 + lq * 4;
+        adv[t2][tm] = ld8(a.add + mdst * a.Cout + (c < a.Cout ? c : c0));
+      }
+      amwv[t2] = a.add_mask ? addmask_word<WC>(a.add_mask, (long long)mdst, cw, a.add_rows, a.Cout) : ~0ull;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int tn = th + t2;
     const int m = m0 + wp * 64 + tn * 16 + lr;
     const bool mok = m < Mc;
-    const size_t mdst = (do_add && mok) ? pixel_dst(m) : 0;
-    unsigned long long amw = 0;      // add_mask: the ReLU-mask bits of this wave's WC channels at the pixel
-    if (do_add && a.add_mask && mok && c0 + wc * WC < a.Cout) amw = addmask_word<WC>(a.add_mask, (long long)mdst, c0 + wc * WC, a.add_rows, a.Cout);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int c = c0 + wc * WC + tm * 16 + lq * 4;
@@ -366,9 +405,9 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
         for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
       }
       if (do_add && ok) {
-        const u32x2 ad = ld8(a.add + mdst * a.Cout + c);
+        const u32x2 ad = adv[t2][tm];
         if (a.add_mask) {
-          const unsigned nib = (unsigned)(amw >> (tm * 16 + lq * 4));
+          const unsigned nib = (unsigned)(amwv[t2] >> (tm * 16 + lq * 4));
           v[0] += (nib & 1u) ? bflo(ad.x) : 0.f; v[1] += (nib & 2u) ? bfhi(ad.x) : 0.f;
           v[2] += (nib & 4u) ? bflo(ad.y) : 0.f; v[3] += (nib & 8u) ? bfhi(ad.y) : 0.f;
         } else {
@@ -388,6 +427,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
         s1[tm][3] += q3; s2[tm][3] += q3 * q3;
       }
     }
+  }
   }
   __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
   if (mstats) {
@@ -434,7 +474,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
         const size_t o = pixel_dst(m) * a.Cout + c;
         const u32x4 gv = ld16(&slab[p * SROW + ch * 8]);
         st16(a.out + o, gv);
-        if (do_bn) bnfuse_accum(bl, a.bn, gv, bxv[i], byv[i]);
+        if (do_bn) bnfuse_accum(bl, a.bn, gv, bxv[i], bym[i]);
       }
     }
     if (do_bn) {   // uniform: one {S1, S2} row per 128-pixel workgroup, summed over pixel groups and the two pixel waves

@@ -241,27 +241,19 @@ __device__ __forceinline__ unsigned long long addmask_word(const unsigned char* 
   if (NCH == 64) return *reinterpret_cast<const unsigned long long*>(p);      // cw % 64 == 0: one aligned slab row
   return (unsigned long long)*reinterpret_cast<const unsigned*>(p);           // cw % 32 == 0
 }
-// the mask operand of pixel m, channels c..c+7 of the [M][Cout] output: 16 bytes of the activation, or (bit mode) one byte in .x
-__device__ __forceinline__ u32x4 bnfuse_load_mask(const BnBwdFuse& bn, long long m, int c, long long M, int Cout) {
-  if (bn.relu == VFS_MASK_BITS) {
-    u32x4 v;
-    v.x = mask8_load(bn.y, m, c, M, Cout); v.y = 0u; v.z = 0u; v.w = 0u;
-    return v;
-  }
-  return *reinterpret_cast<const u32x4*>(bn.y + (size_t)m * Cout + c);
+// the ReLU-mask byte of pixel m, channels c..c+7 of the [M][Cout] output: from the bit-packed mask, or from the activation
+__device__ __forceinline__ unsigned bnfuse_load_mask(const BnBwdFuse& bn, long long m, int c, long long M, int Cout) {
+  if (bn.relu == VFS_MASK_BITS) return mask8_load(bn.y, m, c, M, Cout);
+  return mask8_of(*reinterpret_cast<const u32x4*>(bn.y + (size_t)m * Cout + c));
 }
-__device__ __forceinline__ void bnfuse_accum(BnFuseLane& L, const BnBwdFuse& bn, u32x4 gv, u32x4 xv, u32x4 yv) {
+__device__ __forceinline__ void bnfuse_accum(BnFuseLane& L, const BnBwdFuse& bn, u32x4 gv, u32x4 xv, unsigned ymask) {
+  // ymask: bit i <-> element i of the unit's activation is positive (residual units: bn.y given, as bits or as the tensor)
   float g[8], x[8];
   unpack8(gv, g);
   unpack8(xv, x);
-  if (bn.y && bn.relu == VFS_MASK_BITS) {
+  if (bn.y) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = ((yv.x >> i) & 1u) ? g[i] : 0.f;
-  } else if (bn.y) {
-    float y[8];
-    unpack8(yv, y);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+    for (int i = 0; i < 8; ++i) g[i] = ((ymask >> i) & 1u) ? g[i] : 0.f;
   } else if (bn.relu) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) g[i] = (x[i] * L.sc[i] + L.sh[i] > 0.f) ? g[i] : 0.f;
