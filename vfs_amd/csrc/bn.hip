@@ -476,15 +476,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
   }
   for (long long r = s.m0 + s.rt; r < s.mend; r += 4 * s.rows) {
     u32x4 xv[4], rv[4], qv[4];
+    size_t oo[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long m = r + (long long)u * s.rows;
       ok[u] = m < s.mend;
-      const size_t o = (size_t)(ok[u] ? m : s.m0) * a.C + s.c;
-      xv[u] = ld16(a.x + o);
-      if (a.res) rv[u] = ld16(a.res + o);
-      if (a.rres) qv[u] = ld16(a.rres + o);
+      oo[u] = (size_t)(ok[u] ? m : s.m0) * a.C + s.c;
+      xv[u] = ld16(a.x + oo[u]);
+    }
+    if (a.res) {              // optional operands: one straight-line batch each
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rv[u] = ld16(a.res + oo[u]);
+    }
+    if (a.rres) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qv[u] = ld16(a.rres + oo[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -534,19 +541,31 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
     ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; xb[i] = 0.f; }
+    // the nine window vectors are requested together (taps outside the map: clamped address, ignored below); with the loads
+    // inside the bounds conditionals every tap was one dependent memory round trip
+    u32x4 win[9];
+    unsigned valid = 0;
+#pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int h = 2 * hp - 1 + dy;
-      if ((unsigned)h >= (unsigned)a.H) continue;
+      const bool hok = (unsigned)h < (unsigned)a.H;
+#pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int w = 2 * wp - 1 + dx;
-        if ((unsigned)w >= (unsigned)a.W) continue;
-        float x[8];
-        unpack8(ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * a.C + c), x);
+        const bool ok = hok && (unsigned)w < (unsigned)a.W;
+        valid |= (ok ? 1u : 0u) << (dy * 3 + dx);
+        win[dy * 3 + dx] = ld16(a.x + (((size_t)n * a.H + (hok ? h : 2 * hp)) * a.W + (ok ? w : 2 * wp)) * a.C + c);
+      }
+    }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float val = round_bf(fmaxf(x[i] * sc[i] + sh[i], 0.f));  // pool the STORED (bf16) activation
-          if (val > best[i]) { best[i] = val; bi[i] = dy * 3 + dx; xb[i] = x[i]; }
-        }
+    for (int k = 0; k < 9; ++k) {       // scan order of the taps as before: the first maximum wins
+      if (!((valid >> k) & 1u)) continue;
+      float x[8];
+      unpack8(win[k], x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float val = round_bf(fmaxf(x[i] * sc[i] + sh[i], 0.f));  // pool the STORED (bf16) activation
+        if (val > best[i]) { best[i] = val; bi[i] = k; xb[i] = x[i]; }
       }
     }
     const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
@@ -624,7 +643,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
     // four pixel rows per trip: 8-12 independent 16-byte loads in flight per lane
     for (int r = rt; r < a.ppb; r += 4 * rows) {
-      u32x4 gv[4], xv[4], yv[4];
+      u32x4 gv[4], xv[4];
+      unsigned ym[4];
+      long long moff[4];
       bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -633,9 +654,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         const size_t o = (size_t)(ok[u] ? m : m0) * a.C + c;
         gv[u] = ld16(a.g + o);
         xv[u] = ld16(a.x + o);
-        if (a.y) {
-          if (bits) yv[u].x = mask8_load(a.y, ok[u] ? m : m0, c, a.M, a.C); else yv[u] = ld16(a.y + o);
-        }
+        moff[u] = ok[u] ? m : m0;
+      }
+      // the mask operand in its own straight-line batch per mode (a load inside the per-row conditional is waited for alone)
+      if (a.y && bits) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ym[u] = mask8_load(a.y, moff[u], c, a.M, a.C);
+      } else if (a.y) {
+        u32x4 yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yv[u] = ld16(a.y + (size_t)moff[u] * a.C + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ym[u] = mask8_of(yv[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -643,14 +673,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
         float g[8], x[8];
         unpack8(gv[u], g);
         unpack8(xv[u], x);
-        if (a.y && bits) {
+        if (a.y) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) g[i] = ((yv[u].x >> i) & 1u) ? g[i] : 0.f;
-        } else if (a.y) {
-          float y[8];
-          unpack8(yv[u], y);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+          for (int i = 0; i < 8; ++i) g[i] = ((ym[u] >> i) & 1u) ? g[i] : 0.f;
         } else if (a.relu) {   // plain conv->BN->ReLU unit: the mask is recomputed from x (saves a read)
 #pragma unroll
           for (int i = 0; i < 8; ++i) g[i] = (x[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
@@ -733,18 +758,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
     }
   }
   for (long long r = s.m0 + s.rt; r < s.mend; r += 4 * s.rows) {
-    u32x4 gv[4], xv[4], yv[4];
+    u32x4 gv[4], xv[4];
+    unsigned ym[4];
+    long long moff[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long m = r + (long long)u * s.rows;
       ok[u] = m < s.mend;
-      const size_t o = (size_t)(ok[u] ? m : s.m0) * a.C + s.c;
+      moff[u] = ok[u] ? m : s.m0;
+      const size_t o = (size_t)moff[u] * a.C + s.c;
       gv[u] = ld16(a.g + o);
       xv[u] = ld16(a.x + o);
-      if (a.y) {
-        if (bits) yv[u].x = mask8_load(a.y, ok[u] ? m : s.m0, s.c, a.M, a.C); else yv[u] = ld16(a.y + o);
-      }
+    }
+    if (a.y && bits) {          // the mask operand in its own straight-line batch per mode (see bn_bwd_reduce_kernel)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ym[u] = mask8_load(a.y, moff[u], s.c, a.M, a.C);
+    } else if (a.y) {
+      u32x4 yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) yv[u] = ld16(a.y + (size_t)moff[u] * a.C + s.c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ym[u] = mask8_of(yv[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -752,14 +787,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
       float g[8], x[8], d[8];
       unpack8(gv[u], g);
       unpack8(xv[u], x);
-      if (a.y && bits) {
+      if (a.y) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = ((yv[u].x >> i) & 1u) ? g[i] : 0.f;
-      } else if (a.y) {
-        float y[8];
-        unpack8(yv[u], y);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : 0.f;
+        for (int i = 0; i < 8; ++i) g[i] = ((ym[u] >> i) & 1u) ? g[i] : 0.f;
       } else if (a.relu) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = (x[i] * A[i] + sh[i] > 0.f) ? g[i] : 0.f;
