@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restri
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int p = 0; p < HW; ++p) {
+#pragma unroll 8
+    for (int p = 0; p < HW; ++p) {       // eight independent loads in flight (the rolled loop waited for each pixel in turn)
       float f[8];
       unpack8(ld16(x + ((size_t)n * HW + p) * C + c), f);
 #pragma unroll
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(64) void cosine_loss_fwd_kernel(LossArgs a) {
   const int i = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
   const int j = roll_src(i, a.T, k);
   float d1 = 0.f, d2 = 0.f, np1 = 0.f, nz2 = 0.f, np2 = 0.f, nz1 = 0.f;
+#pragma unroll 8
   for (int c = lane; c < a.C; c += 64) {
     const float p1 = bf2f(a.p1[(size_t)i * a.C + c]), z1 = bf2f(a.z1[(size_t)i * a.C + c]);
     const float p2 = bf2f(a.p2[(size_t)j * a.C + c]), z2 = bf2f(a.z2[(size_t)j * a.C + c]);
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(64) void cosine_loss_bwd_kernel(LossArgs a) {
   bf16_t* out = view == 0 ? a.dp1 : a.dp2;
   const float eps = 1e-12f, coef = a.negative ? -1.f : -2.f;
   float na = 0.f;
+#pragma unroll 8
   for (int c = lane; c < a.C; c += 64) { const float v = bf2f(A[(size_t)i * a.C + c]); na += v * v; }
   na = fmaxf(sqrtf(wave_sum(na)), eps);
   const int bvid = i / a.T, t = i - bvid * a.T;
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(64) void cosine_loss_bwd_kernel(LossArgs a) {
     else { u = t + k; if (u >= a.T) u -= a.T; gi = bvid * a.T + u; }  // p2[i] is paired with loss index inv_k(i)
     const int j = bvid * a.T + u;
     float nb = 0.f, dot = 0.f;
+#pragma unroll 8
     for (int c = lane; c < a.C; c += 64) {
       const float av = bf2f(A[(size_t)i * a.C + c]), bv = bf2f(Bz[(size_t)j * a.C + c]);
       nb += bv * bv; dot += av * bv;
@@ -260,12 +264,11 @@ __global__ __launch_bounds__(64) void cosine_loss_bwd_kernel(LossArgs a) {
     const float cs = wave_sum(dot) / (na * nb);
     const float gs = a.gloss[(size_t)k * a.N + gi] * a.weight * 0.5f * coef / na;
 #pragma unroll
-    for (int q = 0; q < MAXC; ++q) {
-      const int c = lane + q * 64;
-      if (c < a.C) {
-        const float av = bf2f(A[(size_t)i * a.C + c]), bv = bf2f(Bz[(size_t)j * a.C + c]);
-        acc[q] += gs * (bv / nb - cs * av / na);
-      }
+    for (int q = 0; q < MAXC; ++q) {       // loads without a per-lane condition (index clamped, the update is masked): they batch
+      const int c = lane + q * 64, cc = c < a.C ? c : lane;
+      const float av = bf2f(A[(size_t)i * a.C + cc]), bv = bf2f(Bz[(size_t)j * a.C + cc]);
+      const float upd = gs * (bv / nb - cs * av / na);
+      acc[q] += c < a.C ? upd : 0.f;
     }
   }
 #pragma unroll
