@@ -113,6 +113,18 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   const int co = n0 + wc0 + li;
   if (co < a.Cout) {
     const float sc = a.scale ? a.scale[co] : 1.f, sh = a.scale ? a.shift[co] : 0.f;
+    // the 32 identity values of this lane are requested together (rows past M clamped): inside the per-row conditional each
+    // one was a dependent memory round trip
+    float rv[2][16];
+    if (a.res) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long m = m0 + wp0 + pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          rv[pt][r] = a.res[(size_t)(m < M ? m : M - 1) * a.Cout + co];
+        }
+    }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
           float v = acc[pt][r];
           if (a.scale) v = __builtin_fmaf(v, sc, sh);
           const size_t o = (size_t)m * a.Cout + co;
-          if (a.res) v = v + a.res[o];
+          if (a.res) v = v + rv[pt][r];
           if (a.relu) v = v > 0.f ? v : 0.f;
           a.y[o] = v;
         }
