@@ -127,21 +127,32 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  // the residual operand is requested for TWO pixel tiles at a time (8 loads in flight per lane), as in conv_igemm.hip
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    u32x2 ad[TM];
-    unsigned long long amw = 0;
-    const bool okp = (okt >> tn) & 1u;
-    if (do_add) {
+  for (int th = 0; th < TN; th += 2) {
+  u32x2 adv[2][TM];
+  unsigned long long amwv[2] = {0, 0};
+  if (do_add) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int tn = th + t2;
       int ti, py, px;
       halo_pixel<SMALLW>(wp, tn, lr, ti, py, px);
       // pixels outside the map: clamped to the tile's first pixel (inside), so that the loads carry no per-lane condition
-      const size_t mdst = okp ? ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px) : ((size_t)tn0 * g.H + y0) * g.W + x0;
+      const size_t mdst = ((okt >> tn) & 1u) ? ((size_t)(tn0 + ti) * g.H + (y0 + py)) * g.W + (x0 + px) : ((size_t)tn0 * g.H + y0) * g.W + x0;
       const size_t obase = mdst * a.Cout + c0 + wc * 64 + lq * 4;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) ad[tm] = ld8(a.add + obase + tm * 16);
-      if (a.add_mask) amw = addmask_word<64>(a.add_mask, (long long)mdst, c0 + wc * 64, a.add_rows, a.Cout);
+      for (int tm = 0; tm < TM; ++tm) adv[t2][tm] = ld8(a.add + obase + tm * 16);
+      if (a.add_mask) amwv[t2] = addmask_word<64>(a.add_mask, (long long)mdst, c0 + wc * 64, a.add_rows, a.Cout);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int tn = th + t2;
+    const u32x2 (&ad)[TM] = adv[t2];
+    const unsigned long long amw = amwv[t2];
+    const bool okp = (okt >> tn) & 1u;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
@@ -169,6 +180,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
         s1[tm][3] += q3; s2[tm][3] += q3 * q3;
       }
     }
+  }
   }
   __builtin_amdgcn_wave_barrier();   // no code: in-order LDS pipe; keeps the compiler (and the CPU emulator) honest
   // whole pixel rows out: lane = (pixel p = 8 i + lane/8, 16-byte chunk lane%8)
