@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+os.environ.setdefault('VFS_GC_FREEZE', '1')     # this process is the benchmark's own: see trackers._freeze_gc_once
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector peak, same guide
@@ -118,11 +119,10 @@ def davis_cpu_baseline(depth, threads):
                        f'{t_bb:.2f} s + propagation over 21 key frames {t_lp:.2f} s + post-processing {t_pp:.2f} s')
 
 
-def bench_davis(args, depth, dev, world, rank):
+def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
     """BASELINE.json configs[3]: DAVIS-2017 label propagation, synthetic 480x854 clip, the reference's test-time config"""
     import numpy as np
     import vfs_amd
-    from oracle import vfs_oracle as O      # deterministic weight filler only (no checkpoint on the box)
     from vfs_amd.engine import shared_engine
     from vfs_amd.labelprop import mask_pairs
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
@@ -131,11 +131,10 @@ def bench_davis(args, depth, dev, world, rank):
     bb = dict(cfg.model['backbone'])
     bb['out_indices'], bb['strides'] = tc['out_indices'], tc['strides']          # tools/test.py:129-133
     model = vfs_amd.build_model(dict(type='VanillaTracker', backbone=bb), train_cfg=None, test_cfg=tc)
-    ref = O.VanillaTracker(depth, dict(tc))
-    O.fill_state_dict_(ref, seed=5)
-    model.load_state_dict(ref.state_dict(), strict=False)
+    from vfs_amd.synthetic import synthetic_weights_      # no checkpoint on the box: deterministic non-degenerate weights
+    synthetic_weights_(model, seed=5)
     model.to(dev).eval()
-    K, Wm = args.steps, max(1, args.warmup)
+    K, Wm = (steps or args.steps), max(1, args.warmup if warmup is None else warmup)
     H, W = 480, 854
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     base = torch.randn(1, 1, 3, 1, H, W, device=dev, generator=g)           # a slowly drifting scene: propagation is not pure noise
@@ -225,10 +224,7 @@ def bench_davis(args, depth, dev, world, rank):
                                                                             sample='failed: ' + o.stderr[-300:])
         except subprocess.TimeoutExpired:
             res['cpu_baseline'] = dict(value=None, unit='frames/s', cores=threads, kind='port', sample='timed out after 400 s')
-    if rank == 0:
-        print(json.dumps(res))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    return res
 
 
 def main():
@@ -242,6 +238,8 @@ def main():
     ap.add_argument('--workload', default='train', choices=['train', 'davis'])
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='davis workload: evaluation precision')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-davis', action='store_true', help='train workload: skip the DAVIS leg appended to the JSON line (N = 1 only)')
+    ap.add_argument('--davis-frames', type=int, default=10, help='propagated frames of the appended DAVIS leg')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
@@ -265,7 +263,12 @@ def main():
         Tape.slowest = {}
     depth = 18 if args.model == 'r18' else 50
     if args.workload == 'davis':
-        return bench_davis(args, depth, dev, world, rank)
+        res = bench_davis(args, depth, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(res))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', f'vfs_r{depth}.py'))
     torch.manual_seed(0)
     model = vfs_amd.build_model(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev).train()
@@ -412,7 +415,11 @@ def main():
             ach, peak, unit = (nb / tm / 1e9, PEAK_HBM_GBS, 'GB/s') if hbm_bound else (fl / tm / 1e12, PEAK_BF16_TFLOPS, 'TFLOP/s')
             return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': peak, 'unit': unit,
                     'frac': ach / peak, 'traffic': tr, 'launches_per_step': cnt / args.steps, 'avg_launch_ms': tm / cnt * 1e3,
-                    'time_share_of_step': tm / dt_prof, 'algorithmic_bytes_per_launch': nb / cnt,
+                    'kernel_ms_per_step': tm / args.steps * 1e3,
+                    # share of the REPORTED step (command-tape replay, weight gradients on their own stream: families on the two
+                    # streams overlap, so the shares of one step may add up to more than 1) and of the eager single-stream leg
+                    'time_share_of_step': tm / dt, 'time_share_of_eager_step': tm / dt_prof,
+                    'algorithmic_bytes_per_launch': nb / cnt,
                     'algorithmic_flop_per_launch': fl / cnt, 'GB/s': nb / tm / 1e9, 'TFLOP/s': fl / tm / 1e12}
         kind = max(agg, key=lambda k: agg[k][1])
         res['roofline'] = family(kind)
@@ -434,6 +441,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample) ...')
         res['cpu_baseline'] = cpu_baseline_subprocess(depth, args.size, min(os.cpu_count() or 1, 64))
+    if world == 1 and not args.no_davis:
+        # the second headline metric (BASELINE.json: "DAVIS J&F-Mean"; J&F itself needs the checkpoint + dataset, neither is on
+        # the box): the label-propagation workload of configs[3] on the SAME model family, same process, after the train leg
+        # - its own metric / value / roofline / cpu_baseline under the key "davis" of the same JSON line
+        log(f'DAVIS leg: R{depth} {args.precision}, {args.davis_frames} propagated frames ...')
+        res['davis'] = bench_davis(args, depth, dev, world, rank, steps=args.davis_frames, warmup=2)
     if rank == 0:
         print(json.dumps(res))
     if dist.is_initialized():

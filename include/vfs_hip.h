@@ -245,6 +245,26 @@ int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
                         const vfs_bf16* z2, const float* gloss, vfs_bf16* dp1, vfs_bf16* dp2, int N,
                         int C, int T, int K, int negative, float weight, vfs_stream_t stream);
 
+/* ---- CosineSimLoss on spatial inputs, incl. pairwise=True / mask / with_norm=False (sim_loss.py:42-63) -------------
+ * fp32 [B][C][S] operands = the reference's [B,C,*] tensors flattened (`.flatten(2)`); Sa / Sl: positions of cls_score / label.
+ * colnorm: inv[b][s] = 1 / max(||x[b][:][s]||_2, 1e-12)   (F.normalize(p=2, dim=1), :44-45); pass inv = NULL for with_norm=False.
+ * fwd: pairwise = 1: prod = einsum('bci,bcj->bij') on the matrix cores (fp32 MFMA), * mask[B][Sa][Sl] when given, mean over
+ *      (i, j) (:48-56); pairwise = 0 (Sa == Sl): sum over C per position, mean over positions (:57-58);
+ *      loss[b] = weight * (negative ? -mean : 2 - 2 * mean) (:59-62, losses/base.py:37).  partial: float scratch
+ *      [B][ceil(Sa/32) * ceil(Sl/32)].
+ * bwd: d[B][C][Sself] = gradient wrt the NORMALISED operand of one side given gloss[B]; `other` is the opposite operand
+ *      (raw) with its inverse norms; mask_transposed = 1 when this side is the einsum's j operand (label).
+ * norm_bwd: dx = (d - x^ <x^, d>) * inv per position (backward of F.normalize); inv = NULL: dx = d. */
+int vfs_simloss_colnorm(const float* x, float* inv, int B, int C, int S, vfs_stream_t stream);
+int vfs_simloss_fwd(const float* a, const float* l, const float* inva, const float* invl, const float* mask,
+                    float* partial, float* loss, int B, int C, int Sa, int Sl, int pairwise, int negative,
+                    float weight, vfs_stream_t stream);
+int vfs_simloss_bwd(const float* other, const float* invo, const float* mask, int mask_transposed,
+                    const float* gloss, float* d, int B, int C, int Sself, int Sother, int pairwise,
+                    int negative, float weight, vfs_stream_t stream);
+int vfs_simloss_norm_bwd(const float* x, const float* inv, const float* d, float* dx, int B, int C, int S,
+                         vfs_stream_t stream);
+
 /* ---- optimizer: torch.optim.SGD(lr, momentum, weight_decay) (configs/r*_*.py:134) on flat arenas --- */
 int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
                  float momentum, float weight_decay, vfs_stream_t stream);

@@ -279,6 +279,30 @@ def cosine_sim_loss(p, z, negative=False):
     return -prod.mean(dim=-1) if negative else 2 - 2 * prod.mean(dim=-1)
 
 
+def cosine_sim_loss_general(a, l, mask=None, with_norm=True, negative=False, pairwise=False, loss_weight=1.0):
+    """losses/sim_loss.py:42-63 with every constructor option, losses/base.py:25-37: operands [B,C,*]; pairwise: the affinity
+    matrix A^T L per sample (a sum over C for every pair of positions), optionally masked, averaged over all pairs."""
+    if with_norm:
+        a = a / a.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        l = l / l.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    if mask is not None:
+        assert pairwise
+    B = a.shape[0]
+    if pairwise:
+        a3, l3 = a.reshape(B, a.shape[1], -1), l.reshape(B, l.shape[1], -1)      # flatten(2) fails on [N,C] in the reference too
+        if a.ndim < 3:
+            raise IndexError('Dimension out of range')
+        prod = torch.bmm(a3.transpose(1, 2), l3)
+        if mask is not None:
+            assert prod.shape == mask.shape
+            prod = prod * mask.float()
+        prod = prod.reshape(B, -1)
+    else:
+        prod = (a * l).sum(dim=1).reshape(B, -1)
+    m = prod.mean(dim=-1)
+    return (-m if negative else 2 - 2 * m) * loss_weight
+
+
 def head_loss(p1, z1, p2, z2, weight=1.0):
     """heads/sim_siam_head.py:165-174: symmetric, stop-gradient on z."""
     return (cosine_sim_loss(p1, z2.detach()) * 0.5 + cosine_sim_loss(p2, z1.detach()) * 0.5) * weight

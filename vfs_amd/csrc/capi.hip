@@ -435,6 +435,28 @@ int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
   return vfs_cosine_loss_bwd_launch(a, S(stream));
 }
 
+int vfs_simloss_colnorm(const float* x, float* inv, int B, int C, int S, vfs_stream_t stream) {
+  if (!x || !inv || B <= 0 || C <= 0 || S <= 0) return vfs_set_error(VFS_ERR_ARG, "simloss_colnorm: bad argument");
+  return vfs_simloss_colnorm_launch(x, inv, B, C, S, S(stream));
+}
+int vfs_simloss_fwd(const float* a, const float* l, const float* inva, const float* invl, const float* mask, float* partial, float* loss,
+                    int B, int C, int Sa, int Sl, int pairwise, int negative, float weight, vfs_stream_t stream) {
+  if (!a || !l || !partial || !loss || B <= 0 || C <= 0 || Sa <= 0 || Sl <= 0) return vfs_set_error(VFS_ERR_ARG, "simloss_fwd: bad argument");
+  if (!pairwise && Sa != Sl) return vfs_set_error(VFS_ERR_SHAPE, "simloss_fwd: non-pairwise operands must have the same positions");
+  if (!pairwise && mask) return vfs_set_error(VFS_ERR_ARG, "simloss_fwd: a mask needs pairwise (sim_loss.py:46-47)");
+  return vfs_simloss_fwd_launch(a, l, inva, invl, mask, partial, loss, B, C, Sa, Sl, pairwise, negative, weight, S(stream));
+}
+int vfs_simloss_bwd(const float* other, const float* invo, const float* mask, int mask_transposed, const float* gloss, float* d, int B,
+                    int C, int Sself, int Sother, int pairwise, int negative, float weight, vfs_stream_t stream) {
+  if (!other || !gloss || !d || B <= 0 || C <= 0 || Sself <= 0 || Sother <= 0) return vfs_set_error(VFS_ERR_ARG, "simloss_bwd: bad argument");
+  if (!pairwise && Sself != Sother) return vfs_set_error(VFS_ERR_SHAPE, "simloss_bwd: non-pairwise operands must have the same positions");
+  return vfs_simloss_bwd_launch(other, invo, mask, mask_transposed, gloss, d, B, C, Sself, Sother, pairwise, negative, weight, S(stream));
+}
+int vfs_simloss_norm_bwd(const float* x, const float* inv, const float* d, float* dx, int B, int C, int S, vfs_stream_t stream) {
+  if (!x || !d || !dx || B <= 0 || C <= 0 || S <= 0) return vfs_set_error(VFS_ERR_ARG, "simloss_norm_bwd: bad argument");
+  return vfs_simloss_norm_bwd_launch(x, inv, d, dx, B, C, S, S(stream));
+}
+
 int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
                  float weight_decay, vfs_stream_t stream) {
   return vfs_sgd_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, S(stream));

@@ -166,6 +166,13 @@ struct XcorrArgs {
   int nz, nx, Hz, Wz, H, W, C;
   float scale;
 };
+// simloss.hip: CosineSimLoss on spatial inputs (pairwise affinity on the matrix cores, fp32)
+int vfs_simloss_colnorm_launch(const float* x, float* inv, int B, int C, int S, hipStream_t s);
+int vfs_simloss_fwd_launch(const float* a, const float* l, const float* inva, const float* invl, const float* mask, float* partial,
+                           float* loss, int B, int C, int Sa, int Sl, int pairwise, int negative, float weight, hipStream_t s);
+int vfs_simloss_bwd_launch(const float* other, const float* invo, const float* mask, int mask_transposed, const float* gloss, float* d,
+                           int B, int C, int Sself, int Sother, int pairwise, int negative, float weight, hipStream_t s);
+int vfs_simloss_norm_bwd_launch(const float* x, const float* inv, const float* d, float* dx, int B, int C, int S, hipStream_t s);
 int vfs_xcorr_fwd_launch(const XcorrArgs& a, hipStream_t s);
 struct XcorrBwdArgs {
   const bf16_t* z;   // [nz][Hz][Wz][C]

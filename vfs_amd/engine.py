@@ -337,7 +337,7 @@ class Engine:
         bit-packed mask y > 0 (uint8 [M][C/8], left in u.mask_bits) - the unit's BatchNorm backward reads it instead of y"""
         dev = raw.device
         y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
-        u.mask_bits = self.buf(f'{u.name}{tag}.mbits', (M * u.cout // 8,), torch.uint8, dev) if (want_mask and MASK_BITS and u.cout % 8 == 0) else None
+        u.mask_bits = self.buf(f'{u.name}{tag}.mbits', (M * u.cout // 8,), torch.uint8, dev) if (want_mask and MASK_BITS and u.cout % 8 == 0 and (u.cout < 64 or u.cout % 64 == 0)) else None      # slab-major layout (mask8_index): whole 64-channel slabs
         mpg = M // G if train else M
         nbytes = 2.0 * M * u.cout * (2 + (res is not None) + (rres is not None)) + (M * u.cout / 8.0 if u.mask_bits is not None else 0.0)      # raw in, activation out, identity in (+ mask bits out)
         fin = getattr(self, '_pending_fin', None)
@@ -636,6 +636,20 @@ class Engine:
 
 
 _ENGINES = {}
+
+# Bumped by everything that writes parameters or BatchNorm running statistics THROUGH RAW POINTERS (vfs_sgd_step /
+# vfs_adam_step on the arenas, the BatchNorm kernels of a training forward): such writes never touch tensor._version, so
+# caches of derived data (the fp32 evaluation executor's folded BatchNorm / repacked weights, the SiamFC head's packed
+# weights) key on this counter as well.
+_PARAMS_EPOCH = [0]
+
+
+def params_epoch():
+    return _PARAMS_EPOCH[0]
+
+
+def bump_params_epoch():
+    _PARAMS_EPOCH[0] += 1
 
 
 def shared_engine(device=None):

@@ -41,7 +41,10 @@ class ExactResNet:
     def prepare(self, dev):
         bb = self.bb
         tensors = list(bb.parameters()) + list(bb.buffers())
-        key = (str(dev),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        # params_epoch: the fused training path writes weights (SGD on the arena) and running statistics (the BatchNorm
+        # kernels) through raw pointers, which leaves tensor._version alone
+        from .engine import params_epoch
+        key = (str(dev), params_epoch()) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key == self.key:
             return
         self.units = {}

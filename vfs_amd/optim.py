@@ -5,7 +5,7 @@ they get neither weight decay nor momentum.  The momentum arena is exposed throu
 (views), so `state_dict()` / `load_state_dict()` - what mmcv's checkpoint hook and `--resume-from` use - carry it."""
 import torch
 
-from .engine import shared_engine
+from .engine import bump_params_epoch, shared_engine
 
 
 class SGD(torch.optim.Optimizer):
@@ -56,6 +56,7 @@ class SGD(torch.optim.Optimizer):
         flat, g = f['params'], f['grads']
         grp = self.param_groups[0]
         eng = shared_engine()
+        bump_params_epoch()      # raw-pointer update: caches derived from the parameters (vfs_amd/exact.py) must refresh
         for lo, hi in segs:
             eng.timed('sgd', (0.0, 20.0 * (hi - lo)), flat.device, eng.lib.sgd_step, flat[lo:hi], g[lo:hi], self._buf[lo:hi], hi - lo,
                       float(grp['lr']), float(grp['momentum']), float(grp['weight_decay']), eng.stream(flat.device))

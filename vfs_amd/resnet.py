@@ -339,8 +339,14 @@ class ResNet(nn.Module):
         stem_trains = trainable(self.conv1)
         first = 0 if stem_trains else next((i for i, b in enumerate(blocks) if trainable(b['blk'])), len(blocks))
         g = None
+        notified = set()
         for i in range(len(blocks) - 1, -1, -1):
             if i < first:
+                # a frozen prefix that ends INSIDE a stage: the stage's trainable blocks are final now (data parallel: their
+                # gradients must still be all-reduced)
+                si = max(s for b, s in stage_start.items() if b <= min(first, len(blocks) - 1))
+                if on_stage_done is not None and si not in notified:
+                    on_stage_done(getattr(self, self.res_layers[si]))
                 break
             si = stage_end.get(i)
             if si is not None and si in grads:
@@ -356,6 +362,7 @@ class ResNet(nn.Module):
             next_bn = None if prev is None else (prev['blk'].convs[-1].unit, prev['raws'][-1], prev['mask'])
             g = self._block_bwd(eng, blocks[i], g, N, G, next_bn, need_input_grad=stem_trains or i > first)
             if on_stage_done is not None and i in stage_start:
+                notified.add(stage_start[i])
                 on_stage_done(getattr(self, self.res_layers[stage_start[i]]))
         if not stem_trains:
             if on_stage_done is not None:
@@ -446,6 +453,9 @@ class ResNet(nn.Module):
         x4 = eng.buf('backbone.x4', (N, H, Wp, 4), BF16, x.device)
         eng.lib.imgs_to_nhwc4(x.contiguous().float(), x4, N, 1, 1, H, W, Wp, eng.stream(x.device))
         train = self.training
+        if train:
+            from .engine import bump_params_epoch
+            bump_params_epoch()      # running statistics change through raw pointers
         outs, _ = self.forward_nhwc(eng, x4, N, H, W, 1, train, stop_after_out=True)
         res = [outs[i][0].float().permute(0, 3, 1, 2).contiguous() for i in sorted(outs)]
         return res[0] if len(res) == 1 else tuple(res)

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .engine import BF16, shared_engine
+from .engine import BF16, bump_params_epoch, shared_engine
 from .packing import wgrad_splits
 from .siamfc_heads import SiamConvFC, SiamFC, _nhwc_bf16
 
@@ -38,6 +38,7 @@ class Adam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         eng = shared_engine()
+        bump_params_epoch()      # raw-pointer update: packed / folded copies of the parameters must refresh
         for grp in self.param_groups:
             for p in grp['params']:
                 if p.grad is None:
@@ -61,6 +62,7 @@ class ParamSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         eng = shared_engine()
+        bump_params_epoch()      # raw-pointer update: packed / folded copies of the parameters must refresh
         for grp in self.param_groups:
             for p in grp['params']:
                 if p.grad is None:

@@ -52,7 +52,8 @@ class SiamConvFC(nn.Module):
     def _conv1x1(self, conv, t):
         """t NHWC bf16 -> conv(t) + bias, NHWC bf16 (vfs_conv_fwd; the bf16 copy of the weight is re-packed when it changes)"""
         eng = shared_engine(t.device)
-        key = (conv.weight.data_ptr(), conv.weight._version)
+        from .engine import params_epoch      # the probe's optimizers update weights through raw pointers (no _version bump)
+        key = (conv.weight.data_ptr(), conv.weight._version, params_epoch())
         if self._packed.get(id(conv), (None,))[0] != key:
             wf = torch.empty(conv.out_channels, 1, 1, conv.in_channels, dtype=BF16, device=t.device)
             tab, n, total = build_pack_table([(conv.weight.data, wf, None, 0)], t.device)

@@ -17,7 +17,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import builder
-from .engine import BF16, shared_engine
+from .engine import BF16, bump_params_epoch, shared_engine
 from .registry import TRACKERS
 from .resnet import ResNet
 
@@ -136,6 +136,26 @@ class LazyLogVars(OrderedDict):
         self._load()
         return (OrderedDict, (list(self.items()),))
 
+    def copy(self):
+        self._load()
+        return OrderedDict(self)
+
+    def pop(self, *a):
+        self._load()
+        return super().pop(*a)
+
+    def popitem(self, last=True):
+        self._load()
+        return super().popitem(last)
+
+    def setdefault(self, k, default=None):
+        self._load()
+        return super().setdefault(k, default)
+
+    def __iter__(self):       # keys are known up front, but dict(self) / OrderedDict(self) read values through the C fast path
+        self._load()
+        return super().__iter__()
+
 
 _GC_FROZEN = [False]
 
@@ -145,8 +165,9 @@ def _freeze_gc_once():
     of thousands of long-lived container objects) out of the cyclic collector's working set.  A full (generation-2) collection
     over them takes tens of milliseconds - measured on the MI355X host: one such pause inside 20 ResNet-18 steps showed up as
     +3.5 ms per step although the GPU never waited for the host otherwise.  The objects stay alive anyway; young garbage is
-    still collected.  VFS_GC_FREEZE=0 leaves the collector alone."""
-    if _GC_FROZEN[0] or os.environ.get('VFS_GC_FREEZE', '1') != '1':
+    still collected.  Process-wide, therefore OPT-IN: VFS_GC_FREEZE=1 (bench.py sets it; a training script that owns its
+    process can too)."""
+    if _GC_FROZEN[0] or os.environ.get('VFS_GC_FREEZE', '0') != '1':
         return
     import gc
     gc.collect()
@@ -321,6 +342,7 @@ class SimSiamBaseTracker(BaseTracker):
 
     def _step_forward(self, imgs):
         dev = imgs.device
+        bump_params_epoch()      # the BatchNorm kernels update running_mean / running_var through raw pointers (eager or replayed)
         mode = self._chain_mode(dev)
         if mode is None:
             self._gs = None
