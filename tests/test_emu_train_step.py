@@ -806,3 +806,47 @@ def test_frozen_head_layers_in_train_step_are_refused(backend):
     opt = vfs_amd.build_optimizer(m, cfg.optimizer)
     with pytest.raises(NotImplementedError):
         m.train_step(dict(imgs=torch.randn(2, 2, 3, 1, 32, 32).to(backend.dev), label=torch.zeros(2, 1)), opt)
+
+
+def test_eval_after_training_sees_current_weights(backend):
+    """train -> eval -> train -> eval (periodic validation during training): the fp32 evaluation executor caches repacked weights
+    and folded BatchNorm; the fused training path writes parameters (vfs_sgd_step on the arena) and running statistics (the
+    BatchNorm kernels) through raw pointers, which never bumps tensor._version - the cache must refresh anyway."""
+    import vfs_amd
+    cfg = vfs_amd.Config.fromfile(os.path.join(REPO, 'configs', 'vfs_r18.py'))
+    mcfg = dict(cfg.model)
+    mcfg['backbone'] = dict(mcfg['backbone'], **SHALLOW_MINE)
+    mcfg['img_head'] = dict(mcfg['img_head'], **SHALLOW_HEAD)
+    model = vfs_amd.build_model(mcfg, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    model.load_state_dict(_filled(18, shallow=True).state_dict())
+    model.to(backend.dev)
+    opt = vfs_amd.build_optimizer(model, dict(cfg.optimizer, lr=0.5))
+    imgs = O.fill_tensor([2, 2, 3, 1, 32, 32], seed=11, scale=2.0).to(backend.dev)
+    frame = O.fill_tensor([1, 3, 32, 32], seed=12, scale=2.0).to(backend.dev)
+
+    def evaluate(fresh):
+        model.eval()
+        if fresh:
+            model.backbone._exact_state = None       # rebuild the executor state from the live parameters / buffers
+        with torch.no_grad():
+            y = model.backbone(frame).cpu().clone()
+        model.train()
+        return y
+
+    def train_once():
+        out = model.train_step(dict(imgs=imgs, label=torch.zeros(2, 1)), opt)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+
+    model.train()
+    train_once()
+    y1 = evaluate(False)
+    versions = [t._version for t in list(model.backbone.parameters()) + list(model.backbone.buffers())]
+    train_once()
+    train_once()
+    assert versions == [t._version for t in list(model.backbone.parameters()) + list(model.backbone.buffers())]   # the premise
+    y2 = evaluate(False)
+    want = evaluate(True)
+    assert torch.equal(y2, want)
+    assert not torch.equal(y1, y2)

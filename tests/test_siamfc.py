@@ -165,6 +165,37 @@ def test_hip_probe_training_matches_reference(backend, tag):
             assert float((upd - want_upd).norm() / want_upd.norm()) < (0.12 if optname == 'Adam' else 3e-2), (n, step)
 
 
+def test_head_uses_weights_after_optimizer_steps(backend):
+    """the probe's optimizers write p.data through raw pointers (no tensor._version bump): the head's packed bf16 weight copies
+    must refresh anyway - responses after N large Adam steps equal those of a FRESH head holding the updated weights"""
+    import vfs_amd
+    from vfs_amd import siamfc as SF
+    dev = backend.dev
+    zf, xf = _train_inputs()
+    head = vfs_amd.SiamConvFC(64, 64, out_scale=0.01)
+    ref = SO.SiamConvFC(64, 64, out_scale=0.01)
+    O.fill_state_dict_(ref, seed=21)
+    head.load_state_dict(ref.state_dict())
+    head.to(dev)
+    params = list(head.parameters())
+    opt = SF.Adam(params, lr=0.1)
+    labels = SF.create_labels((4, 1, 8, 8), 16, 0, 8, dev)
+    first = None
+    for step in range(3):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        _, resp = SF.head_loss_backward(head, zf.to(dev), xf.to(dev), labels, 'balance')
+        first = resp.cpu().clone() if first is None else first
+        opt.step()
+    with torch.no_grad():
+        got = head(zf.to(dev), xf.to(dev)).cpu()
+        fresh = vfs_amd.SiamConvFC(64, 64, out_scale=0.01)
+        fresh.load_state_dict(head.state_dict())
+        want = fresh.to(dev)(zf.to(dev), xf.to(dev)).cpu()
+    assert torch.equal(got, want)
+    assert float((got - first).abs().max()) > 0.05 * float(first.abs().max())      # the weights really moved
+
+
 def test_adam_kernel_equals_torch(backend):
     lib = backend.hostlib
     g = torch.Generator().manual_seed(0)
