@@ -239,7 +239,7 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='davis workload: evaluation precision')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-davis', action='store_true', help='train workload: skip the DAVIS leg appended to the JSON line (N = 1 only)')
-    ap.add_argument('--davis-frames', type=int, default=10, help='propagated frames of the appended DAVIS leg')
+    ap.add_argument('--davis-frames', type=int, default=30, help='propagated frames of the appended DAVIS leg')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 

@@ -20,6 +20,23 @@ import gen_golden as G      # noqa: E402  (the mmcv stand-in + reference import 
 from gen_golden import fill_state_dict_, fill_tensor      # noqa: E402
 
 
+def damp_block_outputs_(model):
+    """the filler puts every BatchNorm scale around 1, the last one of each residual block included (the reference zero-initialises
+    those): 8 / 16 undamped residual additions make the net ill-conditioned, and a bf16-storage implementation is then compared
+    with the fp32 golden through amplified rounding noise.  x 0.25 on those scales (as tests/test_emu_train_step.py::_filled)."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            parts = name.split('.')
+            if len(parts) >= 5 and parts[0] == 'backbone' and parts[1].startswith('layer') and parts[-2:] == ['bn', 'weight']:
+                nconv = 2 if _is_basic(model) else 3
+                if parts[3] == f'conv{nconv}':
+                    p.mul_(0.25)
+
+
+def _is_basic(model):
+    return not hasattr(model.backbone.layer1[0], 'conv3')
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -30,6 +47,7 @@ def main():
         cfg = runpy.run_path(os.path.join(G.REF, 'configs', cfgname))
         model = builder.build_model(cfg['model'], train_cfg=cfg['train_cfg'], test_cfg=G.AttrDict(cfg['test_cfg']))
         fill_state_dict_(model, seed=3)
+        damp_block_outputs_(model)
         model.train()
         imgs = fill_tensor(shape, seed=11, scale=2.0)
         feats = []

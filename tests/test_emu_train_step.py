@@ -187,8 +187,14 @@ def _every_stage(backend, depth, shape, extra, bars, size=None):
                 assert g is None or float(g.abs().max()) == 0.0, (prefix, n)
                 continue
             g = g.cpu()
-            if p.grad.norm() < 1e-3 * max(1.0, (shape[0] * shape[3]) ** 0.5 / 4):     # biases in front of a BatchNorm: zero up to rounding residue
-                assert g.norm() < 5e-3 * max(1.0, (shape[0] * shape[3]) ** 0.5 / 4), (prefix, n, float(g.norm()))
+            # biases in front of a BatchNorm (the head's Linear layers): exactly zero in exact arithmetic, rounding residue of the
+            # bf16 dx column sums in both implementations - recognised by their size next to the layer's weight gradient
+            wname = n[:-4] + 'weight'
+            wref = dict(module.named_parameters()).get(wname) if n.endswith('.bias') else None
+            residue = wref is not None and wref.grad is not None and float(p.grad.norm()) < 0.02 * float(wref.grad.norm())
+            if p.grad.norm() < 1e-3 or residue:
+                lim = 5e-3 if wref is None or wref.grad is None else max(5e-3, 0.05 * float(wref.grad.norm()))
+                assert g.norm() < lim, (prefix, n, float(g.norm()), lim)
             else:
                 worst = max(worst, _l2rel(g, p.grad))
                 if not _l2rel(g, p.grad) < bar:
@@ -299,7 +305,10 @@ def _keep_parity_table(size, depth, shape, bars, table):
 # folding thresholds (what bench.py runs).  Bars = measured on the MI355X + ~20 % (profiles/r03_parity_per_stage_*.json holds the
 # tables); statistics over >= 2048 samples per channel, so they are TIGHTER than the toy bars.  relative L2 of one bf16 rounding
 # (uniform in +-2^-9 relative) is 2^-9 / sqrt(3) = 1.1e-3: that is the floor of every bf16-stored tensor compared here.
-FULL_BARS = dict(loss=1e-4, dp=1e-2, head_p=2e-2, head_gfeat=0.1, head_pgrad=0.1, out=1.2e-2, out_l2=1.2e-2, gin=3e-2, pgrad=4e-2)
+# Measured (profiles/r03_parity_per_stage_*.json, worst over the five sizes): block outputs max-rel 5.6e-3 / rel-L2 8.0e-4, input
+# gradients 1.2e-2, backbone parameter gradients 2.5e-2; the head (FIVE Linear+BN layers compared as one stage): p 6.8e-3,
+# feature gradient 5.7e-2, parameter gradients 7.0e-2; d loss / d p 1.7e-3; loss rows 1.2e-7.
+FULL_BARS = dict(loss=1e-6, dp=2.2e-3, head_p=8.5e-3, head_gfeat=7e-2, head_pgrad=8.5e-2, out=7e-3, out_l2=1e-3, gin=1.5e-2, pgrad=3e-2)
 
 
 @pytest.mark.gpu
