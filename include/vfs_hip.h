@@ -265,6 +265,25 @@ int vfs_simloss_bwd(const float* other, const float* invo, const float* mask, in
 int vfs_simloss_norm_bwd(const float* x, const float* inv, const float* d, float* dx, int B, int C, int S,
                          vfs_stream_t stream);
 
+/* ---- SyncBN statistic exchange over xGMI (configs/r*_*.py:9,15 SyncBN under MMDistributedDataParallel, apis/train.py:58-66):
+ * a latency-bound all-reduce of <= 8192 doubles among the <= 8 ranks of one node as ONE small kernel - peer stores into
+ * IPC-mapped windows + epoch flags (csrc/p2p.hip) - instead of a collective-library call per BatchNorm layer and direction.
+ *   window_bytes: size of a window, the largest n and world supported
+ *   alloc / free: a zeroed window in fine-grained device memory (hipExtMallocWithFlags)
+ *   export: 64-byte IPC handle of the own window (hipIpcGetMemHandle); import / unimport: map / unmap a peer's window
+ *   allreduce_f64: buf[0..n) <- sum over ranks, in rank order (bit-identical on every rank).  peers: DEVICE array of `world`
+ *     window pointers (peers[rank] = the own window); state: 2 x uint64 in device memory, zero-initialised ({exchange
+ *     counter, error flag}); phase 3 = push + wait (1 / 2: the halves, for protocol tests); spin_limit: polls before the
+ *     kernel gives up, sets state[1] = 1 and returns garbage (a lost peer must not hang the GPU). */
+int vfs_p2p_window_bytes(long long* bytes, int* max_doubles, int* max_world);
+int vfs_p2p_alloc(void** window);
+int vfs_p2p_free(void* window);
+int vfs_p2p_export(void* window, void* handle64);
+int vfs_p2p_import(const void* handle64, void** window);
+int vfs_p2p_unimport(void* window);
+int vfs_p2p_allreduce_f64(double* buf, int n, const void* peers, int rank, int world, void* state, int phase,
+                          long long spin_limit, vfs_stream_t stream);
+
 /* ---- optimizer: torch.optim.SGD(lr, momentum, weight_decay) (configs/r*_*.py:134) on flat arenas --- */
 int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
                  float momentum, float weight_decay, vfs_stream_t stream);

@@ -47,6 +47,15 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
   return hipSuccess;
 }
 static const int hipMemcpyDeviceToDevice = 3;
+// the host calls of csrc/p2p.hip: a "window" is plain host memory, an IPC handle carries the pointer itself
+struct hipIpcMemHandle_t { char reserved[64]; };
+static const unsigned hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1;
+inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 2; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h, &p, sizeof(p)); return hipSuccess; }
+inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, &h, sizeof(*p)); return hipSuccess; }
+inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
 static const int hipDeviceAttributeMultiprocessorCount = 63;
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }   // "8 CUs"
@@ -442,6 +451,17 @@ inline void vfs_store_agent(double* p, double v) { __atomic_store(p, &v, __ATOMI
 inline double vfs_load_agent(const double* p) { double v; __atomic_load(const_cast<double*>(p), &v, __ATOMIC_SEQ_CST); return v; }
 inline unsigned vfs_ticket_agent(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
 inline void vfs_release_workgroup() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+// system-scope accesses of csrc/p2p.hip: two "ranks" are two host threads of the test process
+inline void vfs_store_system(double* p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
+inline double vfs_load_system(const double* p) { double v; __atomic_load(const_cast<double*>(p), &v, __ATOMIC_SEQ_CST); return v; }
+inline void vfs_store_system_release(unsigned long long* p, unsigned long long v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
+inline unsigned long long vfs_load_system_acquire(const unsigned long long* p) {
+  unsigned long long v;
+  __atomic_load(const_cast<unsigned long long*>(p), &v, __ATOMIC_SEQ_CST);
+  return v;
+}
+inline void vfs_fence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void vfs_spin_pause() { std::this_thread::yield(); }
 
 template <typename T>
 inline T atomicAdd(T* p, T v) {

@@ -1,0 +1,149 @@
+"""SyncBN statistic exchange through IPC-mapped windows (csrc/p2p.hip, vfs_amd/p2p.py).
+  * emulator: the protocol with two "ranks" = two host threads of this process (the emulator's IPC handle is the pointer);
+  * GPU: TWO PROCESSES sharing the one GPU of the box (hipIpcGetMemHandle / hipIpcOpenMemHandle between real processes - RCCL
+    refuses two ranks on one device, IPC does not): protocol soak vs a gloo all-reduce, and data-parallel train steps whose
+    SyncBN statistics travel through the windows vs the same steps with collective-library all-reduces - bit-equal."""
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _windows(lib, world):
+    out = torch.zeros(1, dtype=torch.int64)
+    wins = []
+    for _ in range(world):
+        lib.p2p_alloc(out)
+        wins.append(int(out[0]))
+    # export / import round trip (in the emulator the handle carries the pointer)
+    mapped = []
+    for w in wins:
+        h = torch.zeros(64, dtype=torch.uint8)
+        lib.p2p_export(w, h)
+        lib.p2p_import(h, out)
+        mapped.append(int(out[0]))
+    return wins, mapped
+
+
+def test_protocol_two_threads_emulator(emu_backend):
+    lib = emu_backend.lib
+    meta, i32 = torch.zeros(1, dtype=torch.int64), torch.zeros(2, dtype=torch.int32)
+    lib.p2p_window_bytes(meta, i32[0:1], i32[1:2])
+    assert int(i32[0]) == 8192 and int(i32[1]) == 8 and int(meta[0]) > 8192 * 8 * 8
+    world = 3
+    wins, mapped = _windows(lib, world)
+    peers = torch.tensor(mapped, dtype=torch.int64)
+    sizes = [1, 7, 256, 1000, 8192, 33, 4096, 2, 513, 64]      # more exchanges than slots: the ring wraps
+    g = torch.Generator().manual_seed(0)
+    data = [[torch.randn(n, generator=g, dtype=torch.float64) for n in sizes] for _ in range(world)]
+    results = [[None] * len(sizes) for _ in range(world)]
+    states = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+
+    def rank_main(r):
+        for k, n in enumerate(sizes):
+            t = data[r][k].clone()
+            lib.p2p_allreduce_f64(t, n, peers, r, world, states[r], 3, 1 << 40, None)
+            results[r][k] = t
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    for k in range(len(sizes)):
+        want = data[0][k].clone()
+        for r in range(1, world):
+            want = want + data[r][k]          # rank order
+        for r in range(world):
+            assert torch.equal(results[r][k], want), (r, k)
+    for st in states:
+        assert int(st[0]) == len(sizes) and int(st[1]) == 0
+    # a lost peer: bounded spin, error word set, no hang
+    lone = torch.ones(4, dtype=torch.float64)
+    lib.p2p_allreduce_f64(lone, 4, peers, 0, world, states[0], 3, 1000, None)
+    assert int(states[0][1]) == 1
+    for w in wins:
+        lib.p2p_free(w)
+
+
+def test_argument_checks(emu_backend):
+    from vfs_amd._lib import VfsError
+    lib = emu_backend.lib
+    wins, mapped = _windows(lib, 1)
+    peers, st = torch.tensor(mapped, dtype=torch.int64), torch.zeros(2, dtype=torch.int64)
+    t = torch.zeros(8193, dtype=torch.float64)
+    with pytest.raises(VfsError):
+        lib.p2p_allreduce_f64(t, 8193, peers, 0, 1, st, 3, 10, None)
+    with pytest.raises(VfsError):
+        lib.p2p_allreduce_f64(t, 4, peers, 1, 1, st, 3, 10, None)
+    with pytest.raises(VfsError):
+        lib.p2p_allreduce_f64(t, 4, peers, 0, 9, st, 3, 10, None)
+    lib.p2p_allreduce_f64(t, 4, peers, 0, 1, st, 3, 10, None)      # world 1: the identity
+    assert int(st[0]) == 1 and int(st[1]) == 0
+    lib.p2p_free(wins[0])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_two(tmp_path, tag, mode, extra_env):
+    port = str(_free_port())
+    procs, outs = [], []
+    for r in range(2):
+        o = str(tmp_path / f'{tag}_rank{r}.npz')
+        outs.append(o)
+        env = dict(os.environ, WORLD_SIZE='2', RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   VFS_P2P_SPIN=str(1 << 24), **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', 'p2p_worker.py'), mode, o], env=env))
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert rcs == [0, 0], rcs
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.gpu
+def test_two_processes_one_gpu_protocol(gpu_backend, tmp_path):
+    """300 exchanges of random sizes between two processes on cuda:0, every result compared with the sum computed from both
+    ranks' inputs (gathered through gloo): bit-equal on both ranks"""
+    r = _run_two(tmp_path, 'proto', 'protocol', {})
+    assert int(r[0]['exchanges']) == int(r[1]['exchanges']) == 300
+    assert int(r[0]['mismatches']) == 0 and int(r[1]['mismatches']) == 0
+    assert int(r[0]['error_word']) == 0 and int(r[1]['error_word']) == 0
+    print('two processes, one GPU: us per exchange (kernel launch to completion, host-timed, 4 KB payload):', float(r[0]['us_per_exchange']))
+
+
+@pytest.mark.gpu
+def test_two_processes_one_gpu_train_steps_equal_collective_path(gpu_backend, tmp_path):
+    """3 data-parallel steps (eager, recorded, replayed) of the shallow R18 on two processes sharing cuda:0: SyncBN statistics through
+    the P2P windows vs through gloo all-reduces (gradients through gloo in both) - every parameter, gradient and running statistic
+    bit-equal, and the two ranks in lock-step"""
+    p2p = _run_two(tmp_path, 'p2p', 'train', dict(VFS_SYNCBN_P2P='1', VFS_TEST_STEPS='3'))
+    coll = _run_two(tmp_path, 'coll', 'train', dict(VFS_SYNCBN_P2P='0', VFS_TEST_STEPS='3'))
+    assert int(p2p[0]['p2p_active']) == 1 and int(coll[0]['p2p_active']) == 0
+    assert int(p2p[0]['p2p_exchanges']) > 0
+    n = 0
+    for k in coll[0].files:
+        if k.startswith(('param/', 'grad/', 'buf/', 'log/')):
+            assert np.array_equal(p2p[0][k], coll[0][k]), k
+            n += 1
+        if k.startswith(('param/', 'grad/', 'buf/')):
+            assert np.array_equal(p2p[0][k], p2p[1][k]), k
+    assert n > 50

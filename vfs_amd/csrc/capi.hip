@@ -435,6 +435,26 @@ int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
   return vfs_cosine_loss_bwd_launch(a, S(stream));
 }
 
+int vfs_p2p_window_bytes(long long* bytes, int* max_doubles, int* max_world) {
+  if (!bytes || !max_doubles || !max_world) return vfs_set_error(VFS_ERR_ARG, "p2p_window_bytes: null");
+  return vfs_p2p_window_bytes_host(bytes, max_doubles, max_world);
+}
+int vfs_p2p_alloc(void** window) { return window ? vfs_p2p_alloc_host(window) : vfs_set_error(VFS_ERR_ARG, "p2p_alloc: null"); }
+int vfs_p2p_free(void* window) { return window ? vfs_p2p_free_host(window) : VFS_OK; }
+int vfs_p2p_export(void* window, void* handle64) {
+  return (window && handle64) ? vfs_p2p_export_host(window, handle64) : vfs_set_error(VFS_ERR_ARG, "p2p_export: null");
+}
+int vfs_p2p_import(const void* handle64, void** window) {
+  return (window && handle64) ? vfs_p2p_import_host(handle64, window) : vfs_set_error(VFS_ERR_ARG, "p2p_import: null");
+}
+int vfs_p2p_unimport(void* window) { return window ? vfs_p2p_unimport_host(window) : VFS_OK; }
+int vfs_p2p_allreduce_f64(double* buf, int n, const void* peers, int rank, int world, void* state, int phase, long long spin_limit,
+                          vfs_stream_t stream) {
+  if (!buf || !peers || !state || !(phase & 3) || spin_limit <= 0) return vfs_set_error(VFS_ERR_ARG, "p2p_allreduce_f64: bad argument");
+  return vfs_p2p_allreduce_f64_launch(buf, n, reinterpret_cast<void* const*>(peers), rank, world,
+                                      reinterpret_cast<unsigned long long*>(state), phase, (unsigned long long)spin_limit, S(stream));
+}
+
 int vfs_simloss_colnorm(const float* x, float* inv, int B, int C, int S, vfs_stream_t stream) {
   if (!x || !inv || B <= 0 || C <= 0 || S <= 0) return vfs_set_error(VFS_ERR_ARG, "simloss_colnorm: bad argument");
   return vfs_simloss_colnorm_launch(x, inv, B, C, S, S(stream));

@@ -124,6 +124,18 @@ __device__ __forceinline__ unsigned vfs_ticket_agent(unsigned* p) {
   return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void vfs_release_workgroup() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// System scope (other GPUs over xGMI, other processes through hipIpc mappings; csrc/p2p.hip): accesses that are performed
+// at the memory, not in this GPU's caches.
+__device__ __forceinline__ void vfs_store_system(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double vfs_load_system(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void vfs_store_system_release(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long vfs_load_system_acquire(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void vfs_fence_system() { __threadfence_system(); }
+__device__ __forceinline__ void vfs_spin_pause() { __builtin_amdgcn_s_sleep(8); }
 #else   // host emulation: blocks run on different threads
 inline void vfs_store_agent(float* p, f32x4 v) {
   for (int i = 0; i < 4; ++i) { float x = v[i]; __atomic_store(p + i, &x, __ATOMIC_SEQ_CST); }

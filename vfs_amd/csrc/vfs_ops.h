@@ -166,6 +166,15 @@ struct XcorrArgs {
   int nz, nx, Hz, Wz, H, W, C;
   float scale;
 };
+// p2p.hip: SyncBN statistic exchange through IPC-mapped windows
+int vfs_p2p_window_bytes_host(long long* bytes, int* max_doubles, int* max_world);
+int vfs_p2p_alloc_host(void** ptr);
+int vfs_p2p_free_host(void* ptr);
+int vfs_p2p_export_host(void* ptr, void* handle64);
+int vfs_p2p_import_host(const void* handle64, void** ptr);
+int vfs_p2p_unimport_host(void* ptr);
+int vfs_p2p_allreduce_f64_launch(double* buf, int n, void* const* peers, int rank, int world, unsigned long long* state, int phase,
+                                 unsigned long long spin_limit, hipStream_t s);
 // simloss.hip: CosineSimLoss on spatial inputs (pairwise affinity on the matrix cores, fp32)
 int vfs_simloss_colnorm_launch(const float* x, float* inv, int B, int C, int S, hipStream_t s);
 int vfs_simloss_fwd_launch(const float* a, const float* l, const float* inva, const float* invl, const float* mask, float* partial,

@@ -64,6 +64,7 @@ class Engine:
         self.defer_wgrad = False
         self._wpending = []
         self._wtables = {}
+        self._p2p, self._p2p_tried = None, False      # SyncBN statistic exchange over xGMI (vfs_amd/p2p.py), set up lazily
         self.generation = 0  # bumped whenever a persistent buffer is (re)allocated: recorded launch chains hold raw pointers
         for kv in filter(None, os.environ.get('VFS_OPTS', '').split(',')):      # kernel A/B knobs: "name=value,..."
             name, value = kv.split('=')
@@ -160,8 +161,43 @@ class Engine:
         return self.world > 1 or os.environ.get('VFS_FORCE_COLLECTIVES') == '1'
 
     def allreduce(self, t):
-        if self.collectives_on:
+        """sum a SyncBN statistic buffer over the ranks: the P2P window exchange (vfs_amd/p2p.py; one small kernel, on the launch
+        stream and on a recording tape like any other C-ABI call) when it is up, a collective-library all-reduce otherwise"""
+        if not self.collectives_on:
+            return
+        x = self.p2p_exchange(t.device)
+        if x is not None and x.fits(t):
+            x.allreduce(self.lib, t, self.stream(t.device))
+        else:
             self.record(self._all_reduce, t)
+
+    def p2p_exchange(self, dev):
+        """the SyncBN exchange of this process, set up on first use (VFS_SYNCBN_P2P=0: never; GPUs only; world > 1 - a 1-rank
+        group with VFS_FORCE_COLLECTIVES=1 keeps exercising the collective-library calls).  Set-up or self-test failure on any
+        rank -> None for good (collective library)."""
+        if self._p2p is not None or self._p2p_tried:
+            return self._p2p
+        self._p2p_tried = True
+        if os.environ.get('VFS_SYNCBN_P2P', '1') != '1' or dev.type != 'cuda' or self.world < 2:
+            return None
+        from .p2p import P2PExchange
+        x, ok = None, 1
+        try:
+            x = P2PExchange(self._real_lib if self.tape is not None else self.lib, dev, self.process_group)
+        except Exception as e:      # noqa: BLE001
+            print(f'[vfs_amd] SyncBN P2P exchange unavailable ({type(e).__name__}: {e}); using the collective library', flush=True)
+            ok = 0
+        # every rank must take the same path: agree before (and inside) the self-test
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend(self.process_group) == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
+        if int(flag.item()) and x.self_test(self.stream(dev)):
+            self._p2p = x
+            self.generation += 1
+        elif x is not None:
+            if ok:
+                print('[vfs_amd] SyncBN P2P exchange failed its self-test; using the collective library', flush=True)
+            x.close()
+        return self._p2p
 
     def _all_reduce(self, t):
         dist.all_reduce(t, group=self.process_group)

@@ -102,8 +102,11 @@ class LazyLogVars(OrderedDict):
     def _load(self):
         snap = self.__dict__.pop('_snap', None)
         if snap is not None:
-            if isinstance(snap, tuple):       # (pinned host copy, event recorded behind the asynchronous copy)
+            if isinstance(snap, tuple):       # (pinned host copy, event recorded behind the asynchronous copy[, P2P error word])
                 snap[1].synchronize()
+                if len(snap) > 2 and int(snap[2][0]):
+                    raise RuntimeError('SyncBN P2P exchange: a peer did not arrive within the spin limit (VFS_P2P_SPIN); the '
+                                       'BatchNorm statistics of this step are invalid')
                 snap = snap[0]
             for k, v in zip(list(super().keys()), snap.tolist()):
                 super().__setitem__(k, v)
@@ -600,9 +603,13 @@ class SimSiamBaseTracker(BaseTracker):
                 # step - ~0.1 ms of GPU idle time at each step boundary.
                 host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
                 host.copy_(packed, non_blocking=True)
+                x = shared_engine()._p2p      # SyncBN window exchange: its error word travels with the log values
+                if x is not None:
+                    xflag = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                    xflag.copy_(x.state[1:2], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                packed = (host, ev)
+                packed = (host, ev) if x is None else (host, ev, xflag)
             log_vars = LazyLogVars(keys, packed)
         else:
             log_vars = OrderedDict(zip(keys, packed.tolist()))
