@@ -37,6 +37,7 @@ int vfs_abi_version(void);
  * "igemm_narrow_below" (64-channel tiles when the 128-channel tiling has fewer tiles than this, default 513),
  * "igemm_mfma_stats" (forward statistics rows on the matrix cores, default 1),
  * "wgrad_lin" (linear-address path of the generic weight gradient for 1x1 / stride-1 problems, default 1),
+ * "wgrad_xcd" / "halo_xcd" (XCD-aware block order of the weight-gradient kernels / the 3x3 halo kernels, default 1),
  * "halo_min_fill", "bn_chunk_rows", "lpx_target" (workgroups of the fp32 label propagation; 0 = by channel count) */
 int vfs_set_option(const char* name, int value);
 

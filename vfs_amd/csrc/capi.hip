@@ -29,7 +29,7 @@ int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
-extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_igemm_mfma_stats, vfs_option_lpx_target;
+extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -58,6 +58,8 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "lpx_target")) { vfs_option_lpx_target = value; return VFS_OK; }
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
+  if (!strcmp(name, "wgrad_xcd")) { vfs_option_wgrad_xcd = value; return VFS_OK; }
+  if (!strcmp(name, "halo_xcd")) { vfs_option_halo_xcd = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_fbn")) { vfs_option_igemm_ring_fbn = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_upfront")) { vfs_option_igemm_ring_upfront = value; return VFS_OK; }
   return vfs_set_error(VFS_ERR_ARG, "vfs_set_option: unknown option");

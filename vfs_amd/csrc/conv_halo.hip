@@ -281,7 +281,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
   const int wc = wave / WAVES_P, wp = wave - wc * WAVES_P;
   const int lr = lane & 15, lq = lane >> 4;
   const int ncb = a.Cout / BC;
-  const int tile = blockIdx.x / ncb, cb = blockIdx.x - tile * ncb;
+  // XCD-aware tile order (as in conv_igemm.hip): hardware workgroup b runs on XCD b % 8 behind its own L2; neighbouring spatial
+  // tiles share halo rows (an 8x16 tile reads a 10x18 patch) and the channel blocks of a tile share the whole patch - in plain
+  // order they sit on eight different XCDs.  Every XCD gets a contiguous range of logical blocks (bijective remap).
+  int bx = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
+  }
+  const int tile = bx / ncb, cb = bx - tile * ncb;
   const int c0 = cb * BC;
   const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;     // ragged edge tiles are masked in the epilogue
   const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tn0 = (tile / (tiles_x * tiles_y)) * TI;
@@ -433,7 +441,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
 }
 
 template <int BC, bool DGRAD, bool SMALLW>
-static int launch_halo(const ConvArgs& a, hipStream_t stream) {
+static int launch_halo(const ConvArgs& a0, hipStream_t stream) {
+  ConvArgs a = a0;
+  a.xcd_swizzle = vfs_option_halo_xcd;
   const int WAVES_P = 4 / (BC / 64);
   const int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
   const int tiles = ((a.g.N + TI - 1) / TI) * ((a.g.H + TH - 1) / TH) * ((a.g.W + TW - 1) / TW);
@@ -444,6 +454,7 @@ static int launch_halo(const ConvArgs& a, hipStream_t stream) {
   return vfs_check_launch("conv3x3_halo");
 }
 
+int vfs_option_halo_xcd = 1;          // XCD-aware tile order of the halo kernels (A/B knob)
 int vfs_option_halo_min_fill = 70;    // percent of a ragged tiling that must be real pixels (100: exact tilings only)
 
 // eligibility: 3x3 / stride 1 / pad 1, 64-channel granularity, and a spatial tiling that keeps the

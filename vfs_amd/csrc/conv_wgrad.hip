@@ -46,6 +46,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int nkb = (g.Ktot + BKC - 1) / BKC;
   const int ncb = a.Cout / BCW;
   int b = blockIdx.x;
+  // XCD-aware block order (as in conv_igemm.hip): hardware workgroup b runs on XCD b % 8, each XCD behind its own L2.  The
+  // nkb * ncb tiles of ONE pixel split read the same dY / X rows; in plain order they sit on eight different XCDs and every L2
+  // fetches those rows again (PMC: 139 MB per launch against 75 MB of operands + 16-32 MB of partials).  Give every XCD a
+  // contiguous range of logical blocks (bijective remap; which workgroup computes which tile changes, no number does).
+  if (a.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
   const int kb = b % nkb; b /= nkb;
   const int cb = b % ncb; b /= ncb;
   const int split = b;
@@ -196,12 +204,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+int vfs_option_wgrad_xcd = 1;   // XCD-aware block order of the generic weight-gradient kernel (A/B knob)
 int vfs_option_wgrad_lin = 1;   // the linear-address path for 1x1 / stride-1 problems (A/B knob)
 
 template <int BCW, int MODE, bool LIN = false>
-static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+static int launch_wgrad(const WgradArgs& a0, hipStream_t stream) {
+  WgradArgs a = a0;
   int nkb = (a.g.Ktot + 127) / 128;
   int ncb = a.Cout / BCW;
+  a.xcd_swizzle = vfs_option_wgrad_xcd && nkb * ncb > 1 && nkb * ncb * a.nsplit >= 16;
   hipLaunchKernelGGL((conv_wgrad_kernel<BCW, MODE, LIN>), dim3(nkb * ncb * a.nsplit), dim3(256), 0, stream, a);
   return vfs_check_launch("conv_wgrad");
 }

@@ -34,6 +34,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int lo_off, int hi
   return f;
 }
 
+extern int vfs_option_wgrad_xcd;      // conv_wgrad.hip
+
 template <bool SMALLW, bool BNIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a, int tiles_per_split, int ntiles) {
   constexpr int TW = SMALLW ? 8 : 16, TH = 8, TI = SMALLW ? 2 : 1;
@@ -53,6 +55,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
   const int lr = lane & 15, lq = lane >> 4;
   const int nchunk = g.C >> 6, ncb = a.Cout >> 6;
   int b = blockIdx.x;
+  if (a.xcd_swizzle) {      // XCD-aware block order (see conv_wgrad.hip): the (cin chunk, cout block) tiles of one split share an L2
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
   const int cc = b % nchunk; b /= nchunk;
   const int cb = b % ncb; b /= ncb;
   const int split = b;
@@ -225,6 +231,7 @@ int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsp
   b.nsplit = (ntiles + tps - 1) / tps;
   *eff_nsplit = b.nsplit;
   const int blocks = (a.g.C >> 6) * (a.Cout >> 6) * b.nsplit;
+  b.xcd_swizzle = vfs_option_wgrad_xcd && (a.g.C >> 6) * (a.Cout >> 6) > 1 && blocks >= 16;
   if (a.in_bnp && (a.g.N + a.in_npg - 1) / a.in_npg > 8) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: more than 8 BatchNorm groups");
   if (smallw) {
     if (a.in_bnp) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);

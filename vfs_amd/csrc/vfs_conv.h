@@ -81,6 +81,7 @@ struct WgradArgs {
   int nsplit;
   const float* in_bnp; // optional: x is a RAW conv output, relu(x*scale+shift) is applied while staging (halo kernel)
   int in_npg;
+  int xcd_swizzle = 0; // generic kernel: XCD-aware logical block order (set by the dispatcher)
 };
 
 // relu(x*scale + shift) on one 16-byte vector (8 channels), rounded to bf16 exactly as bn_act_kernel does
@@ -99,7 +100,7 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode);
 // maps of at most 8x8 pixels that fill most of an 8x8 tile (8x8, 7x7 with the default 70 %): the halo kernels take
 // two whole images per workgroup
-extern int vfs_option_halo_min_fill;
+extern int vfs_option_halo_min_fill, vfs_option_halo_xcd;
 static inline bool vfs_small_map(int H, int W) { return H <= 8 && W <= 8 && H * W * 100 >= 64 * vfs_option_halo_min_fill; }
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode);

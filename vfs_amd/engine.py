@@ -178,7 +178,8 @@ class Engine:
         if self._p2p is not None or self._p2p_tried:
             return self._p2p
         self._p2p_tried = True
-        if os.environ.get('VFS_SYNCBN_P2P', '1') != '1' or dev.type != 'cuda' or self.world < 2:
+        want = os.environ.get('VFS_SYNCBN_P2P', '1')      # 'force': also in a 1-rank group (measures the exchange kernels' cost on one GPU)
+        if want not in ('1', 'force') or dev.type != 'cuda' or (self.world < 2 and want != 'force'):
             return None
         from .p2p import P2PExchange
         x, ok = None, 1
