@@ -273,10 +273,20 @@ int vfs_simloss_norm_bwd(const float* x, const float* inv, const float* d, float
  *   alloc / free: a zeroed window in fine-grained device memory (hipExtMallocWithFlags)
  *   export: 64-byte IPC handle of the own window (hipIpcGetMemHandle); import / unimport: map / unmap a peer's window
  *   allreduce_f64: buf[0..n) <- sum over ranks, in rank order (bit-identical on every rank).  peers: DEVICE array of `world`
- *     window pointers (peers[rank] = the own window); state: 2 x uint64 in device memory, zero-initialised ({exchange
- *     counter, error flag}); phase 3 = push + wait (1 / 2: the halves, for protocol tests); spin_limit: polls before the
+ *     window pointers (peers[rank] = the own window); state: 4 x uint64 in device memory, zero-initialised ({exchange
+ *     counter, error flag, -, -}); phase 3 = push + wait (1 / 2: the halves, for protocol tests); spin_limit: polls before the
  *     kernel gives up, sets state[1] = 1 and returns garbage (a lost peer must not hang the GPU). */
 int vfs_p2p_window_bytes(long long* bytes, int* max_doubles, int* max_world);
+/* the SyncBN reductions with the exchange as their TAIL: vfs_bn_reduce_partials (forward: statistics rows -> sums) and
+ * vfs_bn_bwd_sums_paramgrad (backward: rows -> sums + LOCAL dgamma / dbeta) whose last workgroup runs the window exchange on
+ * sums[G][2][C] (G*2*C <= 8192) - no launch and no collective call between "local sums" and "sums over all ranks".
+ * state: 4 x uint64, zero-initialised ({exchange counter, error flag, workgroup ticket, -}); other arguments as above. */
+int vfs_bn_reduce_partials_xchg(const float* partial, double* sums, double* scratch, int G, int bpg, int C,
+                                const void* peers, int rank, int world, void* state, long long spin_limit,
+                                vfs_stream_t stream);
+int vfs_bn_bwd_sums_paramgrad_xchg(const float* partial, double* sums, double* scratch, float* dgamma,
+                                   float* dbeta, int G, int bpg, int C, const void* peers, int rank, int world,
+                                   void* state, long long spin_limit, vfs_stream_t stream);
 int vfs_p2p_alloc(void** window);
 int vfs_p2p_free(void* window);
 int vfs_p2p_export(void* window, void* handle64);

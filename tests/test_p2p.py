@@ -73,6 +73,54 @@ def test_protocol_two_threads_emulator(emu_backend):
         lib.p2p_free(w)
 
 
+@pytest.mark.parametrize('G,bpg,C', [(2, 8, 64), (2, 40, 256), (2, 300, 128), (1, 130, 2048)])
+def test_reductions_with_exchange_tail_two_threads_emulator(emu_backend, G, bpg, C):
+    """vfs_bn_reduce_partials_xchg / vfs_bn_bwd_sums_paramgrad_xchg (the last workgroup of the reduction runs the exchange): two
+    "ranks" on two host threads, each with its own statistics rows - every rank ends with the SUM of both ranks' plain
+    reductions (rank order), local dgamma / dbeta untouched by the exchange; small (one workgroup per channel block), medium and
+    ticketed (> 64 rows per group) reductions, C up to 2048 (64 channel blocks: every ticket counter in use)"""
+    lib = emu_backend.lib
+    world = 2
+    wins, mapped = _windows(lib, world)
+    peers = torch.tensor(mapped, dtype=torch.int64)
+    g = torch.Generator().manual_seed(G * 1000 + bpg)
+    rows = [torch.randn(G * bpg, 2, C, generator=g) for _ in range(world)]
+    plain = []
+    for r in range(world):
+        sums = torch.zeros(G, 2, C, dtype=torch.float64)
+        lib.bn_reduce_partials(rows[r], sums, torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64), G, bpg, C, None)
+        plain.append(sums)
+    want = plain[0] + plain[1]
+    for mode in ('fwd', 'bwd'):
+        states = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+        out = [torch.zeros(G, 2, C, dtype=torch.float64) for _ in range(world)]
+        dg = [torch.zeros(C) for _ in range(world)]
+        db = [torch.zeros(C) for _ in range(world)]
+
+        def rank_main(r):
+            scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64)
+            for _ in range(3):      # repeated launches: tickets and counters must return to zero
+                if mode == 'fwd':
+                    lib.bn_reduce_partials_xchg(rows[r], out[r], scratch, G, bpg, C, peers, r, world, states[r], 1 << 40, None)
+                else:
+                    dg[r].zero_(), db[r].zero_()
+                    lib.bn_bwd_sums_paramgrad_xchg(rows[r], out[r], scratch, dg[r], db[r], G, bpg, C, peers, r, world, states[r], 1 << 40, None)
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+            assert not t.is_alive()
+        for r in range(world):
+            assert torch.equal(out[r], want), (mode, r)
+            assert int(states[r][0]) == 3 and int(states[r][1]) == 0 and int(states[r][2]) == 0
+            if mode == 'bwd':      # dbeta = sum over groups of S1, dgamma of S2 - LOCAL sums (they travel with the gradient buckets)
+                assert torch.allclose(db[r].double(), plain[r][:, 0].sum(0), rtol=1e-6, atol=1e-6)
+                assert torch.allclose(dg[r].double(), plain[r][:, 1].sum(0), rtol=1e-6, atol=1e-6)
+    for w in wins:
+        lib.p2p_free(w)
+
+
 def test_argument_checks(emu_backend):
     from vfs_amd._lib import VfsError
     lib = emu_backend.lib

@@ -10,7 +10,28 @@
 // bnp layout (per layer): float[G][4][C] = {scale = gamma*invstd, shift = beta - mean*scale,
 //                                           mean, invstd}
 #include "vfs_ops.h"
+#include "vfs_p2p.h"
 #include "vfs_stem.h"
+
+// SyncBN (configs/r*_*.py:9,15): the sums of a BatchNorm layer are needed over ALL ranks before the apply pass.  When the P2P
+// window exchange is up (vfs_amd/p2p.py), the reduction kernels below finish with it: the workgroup that completes LAST of
+// `nblocks` (a ticket in state[2]) pushes sums[0..n) into every rank's window, waits for the peers' stamps and writes back the
+// sum over the ranks (vfs_p2p.h) - "local sums" and "sums over the ranks" are one launch, and no collective-library call.
+// Every writer of `sums` uses agent-scope stores and calls this with ALL its threads after the last store.
+__device__ __forceinline__ void bn_xchg_tail(const P2PTail& x, double* sums, int n, unsigned nblocks) {
+  __shared__ unsigned s_last;
+  __shared__ int s_failed;
+  vfs_release_workgroup();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = vfs_ticket_agent(reinterpret_cast<unsigned*>(x.state + 2));
+  __syncthreads();
+  if (s_last != nblocks - 1u) return;
+  p2p_exchange_body(sums, n, x.peers, x.rank, x.world, x.state, 3, x.spin_limit, &s_failed);
+  if (threadIdx.x == 0) vfs_store_agent(reinterpret_cast<unsigned*>(x.state + 2), 0u);
+}
+__device__ __forceinline__ void bn_store_sum(const P2PTail& x, double* p, double v) {
+  if (x.peers) vfs_store_agent(p, v); else *p = v;
+}
 
 // ------------------------------------------------------------------------------------------
 // partial[nblk][2][C] (fp32, one per producer block) -> sums[G][2][C] (fp64), fixed order.
@@ -19,7 +40,7 @@
 // per view of the stem do not serialise on four workgroups.
 template <typename TIN>
 __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const TIN* __restrict__ in, double* __restrict__ out, int bpg,
-                                                             int C, int rpc, int nchunks) {
+                                                             int C, int rpc, int nchunks, P2PTail x) {
   __shared__ double sh[8][2][32];
   const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
   const int c = blockIdx.x * 32 + cl, gi = blockIdx.y, ch = blockIdx.z;
@@ -40,9 +61,10 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const TIN* __restri
 #pragma unroll
     for (int s = 0; s < 8; ++s) { r0s += sh[s][0][cl]; r1s += sh[s][1][cl]; }
     double* o = out + ((size_t)gi * nchunks + ch) * 2 * C;
-    o[c] = r0s;
-    o[C + c] = r1s;
+    bn_store_sum(x, &o[c], r0s);
+    bn_store_sum(x, &o[C + c], r1s);
   }
+  if (x.peers) bn_xchg_tail(x, out, (int)(gridDim.y * 2 * C), gridDim.x * gridDim.y);      // (only launched with nchunks == 1: out = sums)
 }
 
 // sums[G][2][C] (sum x, sum x^2; already all-reduced across ranks for SyncBN) + count ->
@@ -82,7 +104,8 @@ __global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restr
                                                               int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ bnp, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, double count, float eps,
-                                                              float momentum, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                              float momentum, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              P2PTail x) {
   __shared__ double sh[8][2][32];
   const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -106,8 +129,8 @@ __global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restr
       double r0 = 0.0, r1 = 0.0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { r0 += sh[k][0][cl]; r1 += sh[k][1][cl]; }
-      sums[((size_t)gi * 2 + 0) * C + c] = r0;
-      sums[((size_t)gi * 2 + 1) * C + c] = r1;
+      bn_store_sum(x, &sums[((size_t)gi * 2 + 0) * C + c], r0);
+      bn_store_sum(x, &sums[((size_t)gi * 2 + 1) * C + c], r1);
       if (MODE == 0) {
         const double mean = r0 / count;
         double var = r1 / count - mean * mean;
@@ -136,6 +159,7 @@ __global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restr
       dgamma[c] += (float)g2;
     }
   }
+  if (MODE != 0 && x.peers) bn_xchg_tail(x, sums, G * 2 * C, gridDim.x);
 }
 
 // Statistics straight from the stored bf16 conv output for SMALL groups (the head's Linear layers: 32 rows per view):
@@ -210,7 +234,8 @@ __global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ bnp, float* __restrict__ running_mean,
                                                                float* __restrict__ running_var, double count, float eps,
-                                                               float momentum, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               float momentum, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               P2PTail x) {
   __shared__ double sh[8][2][32];
   __shared__ unsigned s_ticket;
   const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
@@ -281,8 +306,8 @@ __global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __re
       double r0 = 0.0, r1 = 0.0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { r0 += sh[k][0][cl]; r1 += sh[k][1][cl]; }
-      sums[((size_t)gi * 2 + 0) * C + c] = r0;
-      sums[((size_t)gi * 2 + 1) * C + c] = r1;
+      bn_store_sum(x, &sums[((size_t)gi * 2 + 0) * C + c], r0);
+      bn_store_sum(x, &sums[((size_t)gi * 2 + 1) * C + c], r1);
       if (MODE == 0) {
         const double mean = r0 / count;
         double var = r1 / count - mean * mean;
@@ -312,6 +337,7 @@ __global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __re
     }
   }
   if (t == 0) tickets[blockIdx.x] = 0u;  // ready for the next launch on this stream
+  if (MODE != 0 && x.peers) bn_xchg_tail(x, sums, G * 2 * C, gridDim.x);      // one finisher per channel block arrives here
 }
 
 // eval-mode BN: bnp from running statistics (G = 1)
@@ -958,28 +984,35 @@ static inline void bn_chunk_plan(int bpg, int* nchunks, int* rpc) {
 }
 int vfs_bn_reduce_fused_launch(int mode, const float* partial, double* sums, double* scratch, int G, int bpg, int C,
                                const float* gamma, const float* beta, float* bnp, float* rm, float* rv, double count, float eps,
-                               float momentum, float* dgamma, float* dbeta, hipStream_t s) {
+                               float momentum, float* dgamma, float* dbeta, hipStream_t s, const P2PTail* tail) {
   const int cb = (C + 31) / 32;
+  P2PTail x;
+  if (tail) {
+    if (mode == 0) return vfs_set_error(VFS_ERR_ARG, "bn_reduce: the fused finalize has no exchange (SyncBN finalizes after the exchange)");
+    if (G * 2 * C > P2P_MAXN || tail->world < 1 || tail->world > P2P_MAXW || tail->rank < 0 || tail->rank >= tail->world || !tail->peers || !tail->state)
+      return vfs_set_error(VFS_ERR_ARG, "bn_reduce + exchange: G*2*C <= 8192 doubles, world <= 8, peers / state set");
+    x = *tail;
+  }
   if (vfs_option_bn_ticket && bpg > 64 && scratch != nullptr && cb <= VFS_BN_TICKETS) {   // chunked, single launch (last workgroup finishes)
     int nchunks, rpc;
     bn_chunk_plan(bpg, &nchunks, &rpc);
     unsigned* tickets = reinterpret_cast<unsigned*>(scratch);
     double* chunks = scratch + VFS_BN_TICKETS / 2;
     const dim3 grid(cb, G, nchunks);
-    if (mode == 0) hipLaunchKernelGGL((bn_reduce_ticket_kernel<0>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-    else if (mode == 1) hipLaunchKernelGGL((bn_reduce_ticket_kernel<1>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-    else hipLaunchKernelGGL((bn_reduce_ticket_kernel<2>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
+    if (mode == 0) hipLaunchKernelGGL((bn_reduce_ticket_kernel<0>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta, x);
+    else if (mode == 1) hipLaunchKernelGGL((bn_reduce_ticket_kernel<1>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta, x);
+    else hipLaunchKernelGGL((bn_reduce_ticket_kernel<2>), grid, dim3(256), 0, s, partial, sums, chunks, tickets, G, bpg, C, rpc, nchunks, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta, x);
     return vfs_check_launch("bn_reduce_ticket");
   }
-  if (mode == 0) hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 0>), dim3(cb), dim3(256), 0, s, partial, sums, G, bpg, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-  else if (mode == 1) hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 1>), dim3(cb), dim3(256), 0, s, partial, sums, G, bpg, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta);
-  else hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, 1), dim3(256), 0, s, partial, sums, bpg, C, bpg, 1);
+  if (mode == 0) hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 0>), dim3(cb), dim3(256), 0, s, partial, sums, G, bpg, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta, x);
+  else if (mode == 1) hipLaunchKernelGGL((bn_reduce_fused_kernel<float, 1>), dim3(cb), dim3(256), 0, s, partial, sums, G, bpg, C, gamma, beta, bnp, rm, rv, count, eps, momentum, dgamma, dbeta, x);
+  else hipLaunchKernelGGL((bn_reduce_rows_kernel<float>), dim3(cb, G, 1), dim3(256), 0, s, partial, sums, bpg, C, bpg, 1, x);
   return vfs_check_launch("bn_reduce_fused");
 }
 // mode 0: statistics -> bnp + running stats ; mode 1: backward sums -> bsums + dgamma/dbeta ; 2: sums only
-int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s) {
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s, const P2PTail* tail) {
   return vfs_bn_reduce_fused_launch(2, partial, sums, scratch, G, bpg, C, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.f, 0.f,
-                                    nullptr, nullptr, s);
+                                    nullptr, nullptr, s, tail);
 }
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s) {

@@ -4,6 +4,7 @@
 #include "../../include/vfs_hip.h"
 #include "vfs_conv.h"
 #include "vfs_ops.h"
+#include "vfs_p2p.h"
 
 static thread_local char g_err[512] = "";
 
@@ -437,6 +438,28 @@ int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
   return vfs_cosine_loss_bwd_launch(a, S(stream));
 }
 
+static P2PTail make_tail(const void* peers, int rank, int world, void* state, long long spin_limit) {
+  P2PTail x;
+  x.peers = reinterpret_cast<void* const*>(peers);
+  x.state = reinterpret_cast<unsigned long long*>(state);
+  x.spin_limit = (unsigned long long)spin_limit;
+  x.rank = rank;
+  x.world = world;
+  return x;
+}
+int vfs_bn_reduce_partials_xchg(const float* partial, double* sums, double* scratch, int G, int bpg, int C, const void* peers, int rank,
+                                int world, void* state, long long spin_limit, vfs_stream_t stream) {
+  if (!partial || !sums || !peers || !state || spin_limit <= 0) return vfs_set_error(VFS_ERR_ARG, "bn_reduce_partials_xchg: bad argument");
+  const P2PTail x = make_tail(peers, rank, world, state, spin_limit);
+  return vfs_bn_reduce_partials_launch(partial, sums, scratch, G, bpg, C, S(stream), &x);
+}
+int vfs_bn_bwd_sums_paramgrad_xchg(const float* partial, double* sums, double* scratch, float* dgamma, float* dbeta, int G, int bpg, int C,
+                                   const void* peers, int rank, int world, void* state, long long spin_limit, vfs_stream_t stream) {
+  if (!partial || !sums || !peers || !state || spin_limit <= 0) return vfs_set_error(VFS_ERR_ARG, "bn_bwd_sums_paramgrad_xchg: bad argument");
+  const P2PTail x = make_tail(peers, rank, world, state, spin_limit);
+  return vfs_bn_reduce_fused_launch(1, partial, sums, scratch, G, bpg, C, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.f, 0.f,
+                                    dgamma, dbeta, S(stream), &x);
+}
 int vfs_p2p_window_bytes(long long* bytes, int* max_doubles, int* max_world) {
   if (!bytes || !max_doubles || !max_world) return vfs_set_error(VFS_ERR_ARG, "p2p_window_bytes: null");
   return vfs_p2p_window_bytes_host(bytes, max_doubles, max_world);

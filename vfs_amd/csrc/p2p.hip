@@ -19,59 +19,14 @@
 //   A bounded spin (spin_limit polls, then state[1] = 1 and garbage out) keeps a lost peer from hanging the GPU.
 #include <string.h>
 
-#include "vfs_common.h"
-
-#define P2P_SLOTS 4
-#define P2P_MAXW 8
-#define P2P_MAXN 8192
-
-__host__ __device__ inline size_t p2p_flag_bytes() { return sizeof(unsigned long long) * P2P_SLOTS * P2P_MAXW; }
-__host__ __device__ inline size_t p2p_window_bytes() { return p2p_flag_bytes() + sizeof(double) * P2P_SLOTS * P2P_MAXW * P2P_MAXN; }
-
-__device__ __forceinline__ unsigned long long* p2p_flags(void* win) { return reinterpret_cast<unsigned long long*>(win); }
-__device__ __forceinline__ double* p2p_data(void* win) { return reinterpret_cast<double*>(reinterpret_cast<char*>(win) + p2p_flag_bytes()); }
+#include "vfs_p2p.h"
 
 // phase: 1 = push, 2 = wait + reduce, 3 = both (the product path; the split exists for single-threaded protocol tests)
 __global__ __launch_bounds__(256) void p2p_allreduce_f64_kernel(double* __restrict__ buf, int n, void* const* __restrict__ peers, int rank,
                                                                 int world, unsigned long long* __restrict__ state, int phase,
                                                                 unsigned long long spin_limit) {
-  const int tid = threadIdx.x;
-  const unsigned long long epoch = state[0] + 1;
-  const int slot = (int)(epoch % P2P_SLOTS);
-  if (phase & 1) {
-    for (int p = 0; p < world; ++p) {
-      double* dst = p2p_data(peers[p]) + ((size_t)slot * P2P_MAXW + rank) * P2P_MAXN;
-      for (int i = tid; i < n; i += 256) vfs_store_system(dst + i, buf[i]);
-    }
-    vfs_fence_system();          // this thread's payload stores are performed at system scope ...
-    __syncthreads();             // ... for every thread of the workgroup, before any flag goes out
-    if (tid < world) vfs_store_system_release(p2p_flags(peers[tid]) + slot * P2P_MAXW + rank, epoch);
-  }
-  if (phase & 2) {
-    __shared__ int failed;
-    if (tid == 0) failed = 0;
-    __syncthreads();
-    if (tid < world) {
-      const unsigned long long* f = p2p_flags(peers[rank]) + slot * P2P_MAXW + tid;
-      unsigned long long polls = 0;
-      while (vfs_load_system_acquire(f) != epoch) {
-        if (++polls > spin_limit) { failed = 1; break; }
-        vfs_spin_pause();
-      }
-    }
-    __syncthreads();
-    const double* src = p2p_data(peers[rank]) + (size_t)slot * P2P_MAXW * P2P_MAXN;
-    for (int i = tid; i < n; i += 256) {
-      double acc = vfs_load_system(src + i);
-      for (int q = 1; q < world; ++q) acc += vfs_load_system(src + (size_t)q * P2P_MAXN + i);
-      buf[i] = acc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      state[0] = epoch;
-      if (failed) state[1] = 1;
-    }
-  }
+  __shared__ int failed;
+  p2p_exchange_body(buf, n, peers, rank, world, state, phase, spin_limit, &failed);
 }
 
 int vfs_p2p_window_bytes_host(long long* bytes, int* max_doubles, int* max_world) {

@@ -97,10 +97,12 @@ int vfs_stem_pool_bn_bwd_reduce_launch(const StemBwdArgs& a, int nblk, hipStream
 int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s);
 int vfs_stem_wgrad_fused_launch(const StemBwdArgs& a, const bf16_t* x4, int Hin, int Win, float* partial, int nblocks,
                                 hipStream_t stream);
-int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s);
+struct P2PTail;      // vfs_p2p.h: the SyncBN window exchange run by the last workgroup of a reduction (nullptr: none)
+int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s,
+                                  const P2PTail* tail = nullptr);
 int vfs_bn_reduce_fused_launch(int mode, const float* partial, double* sums, double* scratch, int G, int bpg, int C,
                                const float* gamma, const float* beta, float* bnp, float* rm, float* rv, double count, float eps,
-                               float momentum, float* dgamma, float* dbeta, hipStream_t s);
+                               float momentum, float* dgamma, float* dbeta, hipStream_t s, const P2PTail* tail = nullptr);
 int vfs_bn_finalize_launch(const double* sums, const float* gamma, const float* beta, float* bnp, float* rm, float* rv,
                            int G, int C, double count, float eps, float momentum, hipStream_t s);
 int vfs_bn_eval_params_launch(const float* gamma, const float* beta, const float* rm, const float* rv, float* bnp, int C,

@@ -310,10 +310,15 @@ class Engine:
                 elif raw_stats:
                     self.timed('bn_stats', (0.0, 2.0 * M * u.cout), dev, lib.bn_stats_raw_finalize, y, u.sums, bn.weight.data, bn.bias.data, u.bnp, bn.running_mean, bn.running_var,
                                               G, mpg, u.cout, float(mpg), float(bn.eps), float(bn.momentum), s)
-                elif self.collectives_on:     # SyncBN: statistics are all-reduced between the two stages
-                    self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_reduce_partials, partial, u.sums,
-                               self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
-                    self.allreduce(u.sums)
+                elif self.collectives_on:     # SyncBN: statistics are summed over the ranks between the two stages
+                    x = self.p2p_exchange(dev)
+                    if x is not None and x.fits(u.sums):      # rows -> sums -> window exchange, one launch
+                        self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_reduce_partials_xchg, partial, u.sums,
+                                   self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, *x.tail_args(), s)
+                    else:
+                        self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_reduce_partials, partial, u.sums,
+                                   self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
+                        self.allreduce(u.sums)
                     if defer_fin and FIN_FUSE and u.kind != 'stem':
                         # the bn_act that follows turns the all-reduced sums into scale / shift itself (any size)
                         self._pending_fin = (u, None, 0, float(mpg * self.world))
@@ -482,7 +487,12 @@ class Engine:
     def _bwd_sums(self, u, partial, G, bpg, C, dev):
         """partial (S1, S2) rows -> u.bsums (all-reduced for SyncBN) and dgamma / dbeta (local sums)"""
         s = self.stream(dev)
-        if self.collectives_on:     # local sums + local dgamma / dbeta in one launch, then the SyncBN all-reduce of the sums
+        if self.collectives_on:     # local sums + local dgamma / dbeta in one launch, then the sums over the ranks (SyncBN)
+            x = self.p2p_exchange(dev)
+            if x is not None and x.fits(u.bsums):      # ... in the same launch: the reduction's last workgroup runs the window exchange
+                self.timed('bn_stats', (0.0, 8.0 * G * bpg * C), dev, self.lib.bn_bwd_sums_paramgrad_xchg, partial, u.bsums,
+                           self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad, G, bpg, C, *x.tail_args(), s)
+                return
             self.timed('bn_stats', (0.0, 8.0 * G * bpg * C), dev, self.lib.bn_bwd_sums_paramgrad, partial, u.bsums,
                        self.bn_scratch(G, C, dev), u.bn.weight.grad, u.bn.bias.grad, G, bpg, C, s)
             self.allreduce(u.bsums)

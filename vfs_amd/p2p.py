@@ -44,12 +44,16 @@ class P2PExchange:
             ptrs.append(int(out[0]))
             self._imported.append(int(out[0]))
         self.peers = torch.tensor(ptrs, dtype=torch.int64, device=dev)
-        self.state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.state = torch.zeros(4, dtype=torch.int64, device=dev)      # {exchange counter, error flag, ticket of the fused reductions, -}
 
     def allreduce(self, lib, t, stream):
         """in place: t <- sum over ranks (rank order; bit-identical everywhere).  `lib` = the engine's current library object,
         so that a recording command tape sees the call"""
         lib.p2p_allreduce_f64(t, t.numel(), self.peers, self.rank, self.world, self.state, 3, self.spin_limit, stream)
+
+    def tail_args(self):
+        """the trailing arguments of the vfs_*_xchg entry points (reductions that run the exchange as their tail)"""
+        return (self.peers, self.rank, self.world, self.state, self.spin_limit)
 
     def fits(self, t):
         return t.dtype == torch.float64 and t.is_contiguous() and 0 < t.numel() <= self.max_doubles and t.device == self.dev
