@@ -53,7 +53,6 @@ class Engine:
         self.bufs = {}
         self.units = []
         self._pack = None
-        self._pack_split = None
         self._pack_key = None
         self.process_group = None
         self._side = {}
@@ -211,11 +210,8 @@ class Engine:
         self.generation += 1      # the pack table (and its bf16 weight copies) will be rebuilt
         return unit
 
-    def pack_weights(self, overlap=False):
-        """fp32 OIHW master weights -> bf16 MFMA layouts, all layers in ONE launch.
-        overlap=True (the train step): the stem's weights are packed on the launch stream, everything else on the side stream
-        (idle during the forward chain) while the frame conversion, the stem and the max-pool run; the caller joins with
-        pack_join() before the first layer that reads packed weights."""
+    def pack_weights(self):
+        """fp32 OIHW master weights -> bf16 MFMA layouts, all layers in ONE launch."""
         if not self.units:
             return
         dev = self.units[0].weight.device
@@ -233,26 +229,12 @@ class Engine:
             if dev.type == 'cuda':
                 torch.cuda.synchronize(dev)     # the previous packed copies may still be in use
             self._pack = build_pack_table(entries, dev)
-            # the same work as two launches: [stem] and [everything else] (pack_weights(overlap=True))
-            self._pack_split = (build_pack_table(entries[:1], dev), build_pack_table(entries[1:], dev)) \
-                if (len(entries) > 1 and self.units[0].kind == 'stem') else None
             self._pack_key = key
             self.generation += 1
         tab, n, total = self._pack
         nel = sum(u.weight.numel() for u in self.units)
-        work = (0.0, 4.0 * nel + 2.0 * sum(u.weight.numel() * (2 if u.wd is not None else 1) for u in self.units))
-        if (overlap and self._pack_split is not None and dev.type == 'cuda' and self.prof is None
-                and os.environ.get('VFS_PACK_OVERLAP', '1') == '1' and os.environ.get('VFS_SIDE_STREAM', '1') == '1'):
-            (t0, n0, tot0), (t1, n1, tot1) = self._pack_split
-            self.lib.pack_weights(t0, n0, tot0, self.stream(dev))
-            with self.on_side_stream(dev):      # ordered after everything on the launch stream so far (the optimizer step)
-                self.lib.pack_weights(t1, n1, tot1, self.stream(dev))
-            return
-        self.timed('pack_weights', work, dev, self.lib.pack_weights, tab, n, total, self.stream(dev))
-
-    def pack_join(self, dev):
-        """the launch stream waits for the weight repack issued by pack_weights(overlap=True)"""
-        self.wgrad_join(dev)
+        self.timed('pack_weights', (0.0, 4.0 * nel + 2.0 * sum(u.weight.numel() * (2 if u.wd is not None else 1) for u in self.units)), dev,
+                   self.lib.pack_weights, tab, n, total, self.stream(dev))
 
     # ------------------------------------------------------------------ forward primitives
     def conv_fwd(self, u, x, N, H, W, G, train, tag='', in_bn=None, defer_fin=False):

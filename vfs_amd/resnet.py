@@ -260,7 +260,6 @@ class ResNet(nn.Module):
         eng.timed('bn_relu_maxpool', (0.0, 2.0 * N * Hs * Ws * 64 + N * Hp * Wp * 64 * (2.0 + (3.0 if train else 0.0))), dev,
                   eng.lib.bn_relu_maxpool, raw, stem.bnp, pooled, idx, xpool, N, Hs, Ws, 64, Hp, Wp, npg, eng.stream(dev))
         ctx.update(stem_raw=raw, Hs=Hs, Ws=Ws, pooled=pooled, idx=idx, xpool=xpool, Hp=Hp, Wp2=Wp)
-        eng.pack_join(dev)      # the repack of every later layer's weights ran beside the stem (Engine.pack_weights(overlap=True))
         x, h, w = pooled, Hp, Wp
         outs = {}
         for si, lname in enumerate(self.res_layers):

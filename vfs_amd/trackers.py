@@ -455,7 +455,7 @@ class SimSiamBaseTracker(BaseTracker):
         self.backbone.attach(eng)
         self.img_head.attach(eng)
         self._ensure_arena()
-        eng.pack_weights(overlap=True)      # all but the stem's weights on the side stream; joined behind the stem (ResNet.forward_nhwc)
+        eng.pack_weights()
         B, V, _, T, H, W = imgs.shape
         Nv = B * T
         N = V * Nv
