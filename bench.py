@@ -401,7 +401,7 @@ def main():
         # HBM bytes per launch of every family from the committed PMC passes (tools/gpu_pmc.sh + make_traffic_json.py:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as the guide prescribes for gfx950)
         tclasses, tsource = {}, None
-        for tag in ('r02', 'r01'):
+        for tag in ('r03', 'r02', 'r01'):
             tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_{args.model}.json')
             if os.path.exists(tpath):
                 tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)

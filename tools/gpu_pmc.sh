@@ -4,7 +4,7 @@ MODEL=${1:-r18}
 mkdir -p gpurun_out && cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-davis > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
   echo "$C exit $?"
 done
 cd $GRAFT_REPO_ROOT

@@ -3,7 +3,7 @@
 MODEL=${1:-r18}; TAG=${2:-prof}
 mkdir -p gpurun_out && cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/$TAG.log 2>&1
+cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-davis > $GRAFT_REPO_ROOT/gpurun_out/$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/$TAG -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 for M in ${2:-r18 r50}; do
   ./tools/gpu_pmc.sh $M > gpurun_out/${TAG}_pmc_$M.txt 2>&1
   python tools/make_traffic_json.py $M $TAG >> gpurun_out/${TAG}_pmc_$M.txt 2>&1
-  cp profiles/${TAG}_traffic_$M.json profiles/r02_traffic_$M.json
+  cp profiles/${TAG}_traffic_$M.json profiles/r03_traffic_$M.json
   cp profiles/${TAG}_traffic_$M.json gpurun_out/
   timeout 600 python bench.py --model $M --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_$M.json 2> gpurun_out/${TAG}_bench_$M.log
   tail -3 gpurun_out/${TAG}_bench_$M.log; cat gpurun_out/${TAG}_bench_$M.json
