@@ -126,7 +126,7 @@ class BasicBlock(nn.Module):
     """resnet.py:15-113: relu(bn2(conv2(relu(bn1(conv1(x))))) + identity)."""
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1, style='pytorch'):      # (style: Bottleneck only)
         super().__init__()
         self.conv1 = ConvBN(inplanes, planes, 3, stride, dilation, relu=True, dilation=dilation)   # resnet.py:51-58
         self.conv2 = ConvBN(planes, planes, 3, 1, 1, relu=False)
@@ -142,10 +142,11 @@ class Bottleneck(nn.Module):
     """resnet.py:116-232, style='pytorch': the stride sits on the 3x3."""
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1, style='pytorch'):
         super().__init__()
-        self.conv1 = ConvBN(inplanes, planes, 1, 1, 0, relu=True)
-        self.conv2 = ConvBN(planes, planes, 3, stride, dilation, relu=True, dilation=dilation)     # resnet.py:172-179
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)                                 # resnet.py:156-161
+        self.conv1 = ConvBN(inplanes, planes, 1, s1, 0, relu=True)
+        self.conv2 = ConvBN(planes, planes, 3, s2, dilation, relu=True, dilation=dilation)         # resnet.py:172-179
         self.conv3 = ConvBN(planes, planes * 4, 1, 1, 0, relu=False)
         self.downsample = downsample
 
@@ -162,7 +163,7 @@ class ResNet(nn.Module):
                      152: (Bottleneck, (3, 8, 36, 3))}
 
     def __init__(self, depth, strides=(1, 2, 2, 2), out_indices=(3,), zero_init_residual=True,
-                 stop_after_out=False, num_stages=4, dilations=(1, 1, 1, 1)):
+                 stop_after_out=False, num_stages=4, dilations=(1, 1, 1, 1), style='pytorch'):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError(f'invalid depth {depth} for resnet')
@@ -179,9 +180,9 @@ class ResNet(nn.Module):
             if stride != 1 or inplanes != planes * block.expansion:   # resnet.py:266-277
                 down = ConvBN(inplanes, planes * block.expansion, 1, stride, 0, relu=False)
             dil = dilations[i]                                            # resnet.py:279-300
-            layers = [block(inplanes, planes, stride, down, dil if dil == 1 else dil // 2)]
+            layers = [block(inplanes, planes, stride, down, dil if dil == 1 else dil // 2, style=style)]
             inplanes = planes * block.expansion
-            layers += [block(inplanes, planes, 1, None, dil) for _ in range(1, nb)]
+            layers += [block(inplanes, planes, 1, None, dil, style=style) for _ in range(1, nb)]
             self.add_module(f'layer{i + 1}', nn.Sequential(*layers))
             self.res_layers.append(f'layer{i + 1}')
         self.feat_dim = inplanes

@@ -157,3 +157,16 @@ def test_dilated_resnet_eval_matches_reference(depth):
     flat = y.flatten()
     assert rel(flat[::13].numpy(), g['sample']) < 1e-5
     assert abs(flat.double().abs().sum().item() - g['checksum'][1]) < 1e-5 * g['checksum'][1]
+
+
+def test_resnet50_caffe_style_matches_reference():
+    """style='caffe' (resnet.py:156-161): stage outputs of the reference class, train mode (tests/golden/gen_caffe_golden.py)"""
+    g = load('resnet50_caffe_fwd')
+    net = O.ResNet(50, out_indices=(0, 1, 2, 3), style='caffe')
+    assert list(net.state_dict().keys()) == [str(k) for k in g['keys']]
+    O.fill_state_dict_(net, seed=50)
+    net.train()
+    outs = net(O.fill_tensor([2, 3, 64, 64], seed=7, scale=2.0))
+    for i, o in enumerate(outs):
+        assert list(o.shape) == list(g[f'shape{i}'])
+        assert rel(o.detach().flatten()[::7].numpy(), g[f'sample{i}']) < 1e-5, i

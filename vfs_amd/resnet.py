@@ -59,7 +59,7 @@ class _Block(nn.Module):
 class BasicBlock(_Block):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride, downsample, norm_cfg, dilation=1):
+    def __init__(self, inplanes, planes, stride, downsample, norm_cfg, dilation=1, style='pytorch'):      # (style: Bottleneck only, resnet.py:15-73)
         super().__init__([ConvBN(inplanes, planes, 3, stride, dilation, norm_cfg, True, dilation),   # resnet.py:51-58
                           ConvBN(planes, planes, 3, 1, 1, norm_cfg, False)], downsample)
 
@@ -67,9 +67,11 @@ class BasicBlock(_Block):
 class Bottleneck(_Block):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride, downsample, norm_cfg, dilation=1):
-        super().__init__([ConvBN(inplanes, planes, 1, 1, 0, norm_cfg, True),
-                          ConvBN(planes, planes, 3, stride, dilation, norm_cfg, True, dilation),     # style='pytorch', resnet.py:172-179
+    def __init__(self, inplanes, planes, stride, downsample, norm_cfg, dilation=1, style='pytorch'):
+        # resnet.py:156-161: 'pytorch' puts the stride on the 3x3 conv, 'caffe' on the first 1x1 conv
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        super().__init__([ConvBN(inplanes, planes, 1, s1, 0, norm_cfg, True),
+                          ConvBN(planes, planes, 3, s2, dilation, norm_cfg, True, dilation),     # resnet.py:172-179
                           ConvBN(planes, planes * 4, 1, 1, 0, norm_cfg, False)], downsample)
 
 
@@ -90,8 +92,9 @@ class ResNet(nn.Module):
         assert 1 <= num_stages <= 4
         assert len(strides) == len(dilations) == num_stages
         assert max(out_indices) < num_stages
-        if in_channels != 3 or style != 'pytorch':
-            raise NotImplementedError('HIP path covers in_channels=3, style=pytorch')
+        assert style in ('pytorch', 'caffe')                                                  # resnet.py:154
+        if in_channels != 3:
+            raise NotImplementedError('HIP path covers in_channels=3 (the stem kernels read NHWC4 frames)')
         self.depth, self.pretrained, self.torchvision_pretrain = depth, pretrained, torchvision_pretrain
         self.in_channels, self.num_stages = in_channels, num_stages
         self.strides, self.dilations = tuple(strides), tuple(dilations)
@@ -112,9 +115,9 @@ class ResNet(nn.Module):
             if stride != 1 or inplanes != planes * self.block.expansion:
                 down = ConvBN(inplanes, planes * self.block.expansion, 1, stride, 0, norm_cfg, False)
             dil = dilations[i]          # make_res_layer (resnet.py:279-300): the first block of a dilated stage gets dil // 2
-            blocks = [self.block(inplanes, planes, stride, down, norm_cfg, dil if dil == 1 else dil // 2)]
+            blocks = [self.block(inplanes, planes, stride, down, norm_cfg, dil if dil == 1 else dil // 2, style=style)]
             inplanes = planes * self.block.expansion
-            blocks += [self.block(inplanes, planes, 1, None, norm_cfg, dil) for _ in range(1, nb)]
+            blocks += [self.block(inplanes, planes, 1, None, norm_cfg, dil, style=style) for _ in range(1, nb)]
             self.add_module(f'layer{i + 1}', nn.Sequential(*blocks))
             self.res_layers.append(f'layer{i + 1}')
         self.feat_dim = self.block.expansion * 64 * 2 ** (len(self.stage_blocks) - 1)
@@ -179,7 +182,7 @@ class ResNet(nn.Module):
             blk = getattr(self, name)[0]
             if blk.downsample is None:
                 continue
-            tgt = blk.conv1 if self.depth in (18, 34) else blk.conv2
+            tgt = blk.conv1 if (self.depth in (18, 34) or self.style == 'caffe') else blk.conv2      # resnet.py:624-637
             for m in (blk.downsample, tgt):
                 m.conv.stride = (stride, stride)
                 m.unit = None
