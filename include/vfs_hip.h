@@ -38,7 +38,8 @@ int vfs_abi_version(void);
  * "igemm_mfma_stats" (forward statistics rows on the matrix cores, default 1),
  * "wgrad_lin" (linear-address path of the generic weight gradient for 1x1 / stride-1 problems, default 1),
  * "wgrad_xcd" / "halo_xcd" (XCD-aware block order of the weight-gradient kernels / the 3x3 halo kernels, default 1),
- * "halo_min_fill", "bn_chunk_rows", "lpx_target" (workgroups of the fp32 label propagation; 0 = by channel count) */
+ * "halo_min_fill", "bn_chunk_rows", "bn_wide" / "bn_wide_min_mb" (plain BatchNorm apply passes on >= 128-channel tensors of at least
+ * that many MB stream whole pixel rows per workgroup, default 1 / 8), "lpx_target" (workgroups of the fp32 label propagation; 0 = by channel count) */
 int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------

@@ -499,3 +499,43 @@ def test_bn_shape_sweep(backend, G, npg, H, W, C):
     lib.bn_bwd_apply_fin(gh, y, xh, bnp, partial, nblk // G, bs, dg, db, dx, None, M, C, mpg, float(mpg), 0, None)
     assert relerr(nchw(dx), xs.grad) < 1e-2
     assert relerr(dg, gm_.grad) < 2e-3 and relerr(db, bt_.grad) < 2e-3
+
+
+@pytest.mark.parametrize('G,mpg,C', [(2, 100, 128), (2, 72, 256), (1, 50, 512), (2, 20, 1024), (1, 9, 2048)])
+def test_wide_slab_streaming_equals_64_channel_slabs(backend, G, mpg, C):
+    """round 3: the plain (non-FIN) bn_act / bn_bwd_apply launches on >= 128-channel tensors stream whole pixel rows per workgroup
+    (`bn_wide`, up to 512 channels per slab) instead of 64-channel slabs - every output, the bit-packed mask included, must be
+    BIT-identical to the 64-channel-slab launch (ragged row counts, both mask modes, residual operands)"""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(C + mpg)
+    M = G * mpg
+    x = rb(torch.randn(M, C, generator=g) * 1.3 - 0.1).to(torch.bfloat16)
+    res = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    rres = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    gy = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    bnp = torch.randn(G, 4, C, generator=g) * 0.5 + 0.8
+    rbnp = torch.randn(G, 4, C, generator=g) * 0.5 + 0.8
+    bs = torch.randn(G, 2, C, generator=g, dtype=torch.float64)
+
+    def run(wide):
+        backend.lib.set_option(b'bn_wide', wide)
+        backend.lib.set_option(b'bn_wide_min_mb', 0)
+        out = []
+        for r, rr, relu in ((res, None, 1), (None, rres, 1), (None, None, 0)):
+            y, mb = torch.empty(M, C, dtype=torch.bfloat16), torch.zeros(M * C // 8, dtype=torch.uint8)
+            lib.bn_act_mask(x, bnp, r, rr, rbnp if rr is not None else None, y, mb, M, C, mpg, relu, None)
+            out += [y, mb]
+        y0, m0 = out[0], out[1]
+        for ym, rl in ((y0, 0), (m0, 2), (None, 1)):
+            dx, gm = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+            lib.bn_bwd_apply(gy, ym, x, bnp, bs, dx, gm, M, C, mpg, float(mpg), rl, None)
+            out += [dx, gm]
+        return out
+    try:
+        narrow, wide = run(0), run(1)
+    finally:
+        backend.lib.set_option(b'bn_wide', 1)
+        backend.lib.set_option(b'bn_wide_min_mb', 8)
+    for a, b in zip(narrow, wide):
+        assert torch.equal(a, b)
+    assert torch.equal(narrow[1], pack_relu_mask(narrow[0]))

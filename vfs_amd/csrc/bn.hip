@@ -370,9 +370,15 @@ struct SlabGeom {
   int cv, rows, rt, c, gi;
   long long m0, mend;
 };
-__device__ __forceinline__ SlabGeom slab_geom(long long M, int C, int mpg, int ppb) {
+// `wide` (the plain, non-FIN launches on tensors of >= 128 channels): the slab is up to 512 channels (1 KB per pixel row, a whole
+// wave per row) instead of 64 - a workgroup then streams whole pixel rows linearly instead of 128-byte pieces at a stride of
+// 2 C bytes.  Measured ceiling of this box for the same traffic pattern (2 reads + 1 write, torch's elementwise add): 5.7-6.0 TB/s;
+// the 64-channel slabs reached 4.4-4.8 (tools/probe_stream_bw.py, MEASUREMENTS.md).  The bit-packed mask keeps its slab-major
+// layout (64-channel sub-slabs, vfs_common.h): a lane still writes / reads the byte of its own 8 channels.
+__device__ __forceinline__ int slab_width(int C, int wide) { return C < 64 ? C : (wide ? (C < 512 ? C : 512) : 64); }
+__device__ __forceinline__ SlabGeom slab_geom(long long M, int C, int mpg, int ppb, int wide = 0) {
   SlabGeom s;
-  const int cslab = C < 64 ? C : 64;
+  const int cslab = slab_width(C, wide);
   s.cv = cslab >> 3;
   s.rows = 256 / s.cv;
   const int t = threadIdx.x;
@@ -389,9 +395,10 @@ __device__ __forceinline__ SlabGeom slab_geom(long long M, int C, int mpg, int p
   return s;
 }
 // host side: pixels per block (a multiple of the 4-row trip) for ~4096 workgroups, and the grid
-static inline dim3 slab_grid(long long M, int C, int mpg, int* ppb_out) {
-  const int cslab = C < 64 ? C : 64, rows = 256 / (cslab >> 3), unit = 4 * rows;
-  const int slabs = C < 64 ? 1 : C / 64;
+static inline int slab_wide_ok(int C) { return C >= 128 && (C <= 512 ? (512 % C == 0 || C % 64 == 0) && 256 % (C >> 3) == 0 : C % 512 == 0); }
+static inline dim3 slab_grid(long long M, int C, int mpg, int* ppb_out, int wide = 0) {
+  const int cslab = C < 64 ? C : (wide ? (C < 512 ? C : 512) : 64), rows = 256 / (cslab >> 3), unit = 4 * rows;
+  const int slabs = C < 64 ? 1 : C / cslab;
   long long per = (M * slabs + 4095) / 4096;
   long long ppb = ((per + unit - 1) / unit) * unit;
   if (ppb < unit) ppb = unit;
@@ -437,7 +444,7 @@ __device__ __forceinline__ void slab_rows_reduce(const BnFin& f, int gi, int C, 
 
 template <bool FIN>
 __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int ppb) {
-  const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb);
+  const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb, FIN ? 0 : a.wide);
   float sc[8], sh[8], rsc[8], rsh[8];
   if (FIN) {
     __shared__ double red[4][2][64], sums_s[2][64];
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 // A = scale, B = -scale*invstd*m2, D = scale*(mean*invstd*m2 - m1) held in registers
 template <bool FIN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f, int ppb) {
-  const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb);
+  const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb, FIN ? 0 : a.wide);
   double s1d[8], s2d[8];
   if (FIN) {
     __shared__ double red[4][2][64], sums_s[2][64], mine[2][64];
@@ -972,6 +979,8 @@ static inline int grid_for(long long total_vec) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
+int vfs_option_bn_wide = 1;          // plain bn_act / bn_bwd_apply on >= 128-channel tensors: whole pixel rows per workgroup (A/B knob)
+int vfs_option_bn_wide_min_mb = 8;   // ... from this tensor size on
 int vfs_option_bn_ticket = 1;   // capi: vfs_set_option("bn_ticket", 0) = single-workgroup-per-channel-block reduction
 // scratch = [VFS_BN_TICKETS ticket counters (zero before the first use, left zero by every launch)]
 //           [double[G][<=VFS_BN_MAX_CHUNKS][2][C] chunk sums]
@@ -1029,8 +1038,10 @@ int vfs_bn_act_launch(const BnActArgs& a, hipStream_t s) {
   if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_act: C must be 8*2^k below 64, a multiple of 64 above");
   if (a.M <= 0) return VFS_OK;
   int ppb;
-  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
-  hipLaunchKernelGGL((bn_act_kernel<false>), grid, dim3(256), 0, s, a, BnFin{}, ppb);
+  BnActArgs aw = a;
+  aw.wide = vfs_option_bn_wide && slab_wide_ok(a.C) && (long long)a.M * a.C * 2 >= (long long)vfs_option_bn_wide_min_mb << 20;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb, aw.wide);
+  hipLaunchKernelGGL((bn_act_kernel<false>), grid, dim3(256), 0, s, aw, BnFin{}, ppb);
   return vfs_check_launch("bn_act");
 }
 static int fin_check(const BnFin& f, long long M, int mpg, const char* who, bool sums_ok = false) {
@@ -1068,8 +1079,10 @@ int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
   if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply: C must be 8*2^k below 64, a multiple of 64 above");
   if (a.M <= 0) return VFS_OK;
   int ppb;
-  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, a, BnFin{}, ppb);
+  BnBwdArgs aw = a;
+  aw.wide = vfs_option_bn_wide && slab_wide_ok(a.C) && (long long)a.M * a.C * 2 >= (long long)vfs_option_bn_wide_min_mb << 20;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb, aw.wide);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, aw, BnFin{}, ppb);
   return vfs_check_launch("bn_bwd_apply");
 }
 int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s) {

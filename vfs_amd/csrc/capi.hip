@@ -27,7 +27,7 @@ int vfs_check_launch(const char* what) {
 
 int vfs_option_halo = 1;
 int vfs_option_stem_blocks = 0;
-extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows;
+extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_bn_wide, vfs_option_bn_wide_min_mb;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
 extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target;
@@ -49,6 +49,8 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo_min_fill")) { vfs_option_halo_min_fill = value; return VFS_OK; }
   if (!strcmp(name, "stem_blocks")) { vfs_option_stem_blocks = value; return VFS_OK; }
   if (!strcmp(name, "bn_ticket")) { vfs_option_bn_ticket = value; return VFS_OK; }
+  if (!strcmp(name, "bn_wide")) { vfs_option_bn_wide = value; return VFS_OK; }
+  if (!strcmp(name, "bn_wide_min_mb")) { vfs_option_bn_wide_min_mb = value; return VFS_OK; }
   if (!strcmp(name, "bn_chunk_rows")) { vfs_option_bn_chunk_rows = value > 0 ? value : 64; return VFS_OK; }
   if (!strcmp(name, "stem_direct")) { vfs_option_stem_direct = value; return VFS_OK; }
   if (!strcmp(name, "igemm_bc")) { vfs_option_igemm_bc = value; return VFS_OK; }

@@ -13,6 +13,7 @@ struct BnActArgs {
   long long M;
   int C, mpg, relu;     // mpg = pixels per group
   unsigned char* mbits = nullptr;   // optional second output: the bit-packed mask y > 0, [M][C/8] (vfs_common.h mask8_of)
+  int wide = 0;         // plain (non-FIN) launch: whole pixel rows per workgroup (set by the launcher, bn.hip slab_geom)
 };
 
 // Optional in-kernel statistics finalisation for the apply passes (bn_act / bn_bwd_apply, SMALL row counts): the
@@ -74,6 +75,7 @@ struct BnBwdArgs {
   int C, mpg, ppb;     // pixels per group, pixels per block (pass 1; mpg % ppb == 0)
   int relu;            // with y == null: recompute the ReLU mask as x*scale+shift > 0; VFS_MASK_BITS (2): y is the bit-packed mask
   double count;        // pass 2: elements per channel per group (global for SyncBN)
+  int wide = 0;        // pass 2, plain (non-FIN) launch: whole pixel rows per workgroup (set by the launcher)
 };
 
 #define VFS_BN_MAX_CHUNKS 128
