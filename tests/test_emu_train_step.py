@@ -132,7 +132,7 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, extr
     residual block, the head and the loss feed the ENGINE'S OWN input / incoming-gradient buffers
     to the corresponding oracle module (bf16 emulation, the two views as separate BN batches)
     and require outputs, input gradients and parameter gradients to agree to bf16 rounding."""
-    if backend.name == 'emu' and depth == 50 and os.environ.get('VFS_TEST_EMU_R50') != '1':
+    if backend.name == 'emu' and depth == 50:
         pytest.skip('ResNet-50 takes 40-80 s per case on the emulator; the GPU runs these cases (the emulator runs every Bottleneck kernel '
                     'shape in tests/test_emu_conv.py / test_emu_bn.py and the ResNet-18 cases here)')
     monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)

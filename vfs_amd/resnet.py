@@ -405,38 +405,27 @@ class ResNet(nn.Module):
         gmask = None
         if gm is None:       # bit-packed mask: the masked gradient g * (y > 0) is applied on the fly by its consumers
             gm, gmask = g, bctx['mask']
-        gds = None
         if blk.downsample is not None:
             ddx, _ = eng.bn_bwd(blk.downsample.unit, gm, gmask, bctx['draw'], M, G)
-            d = blk.downsample
-            # A STRIDED shortcut (the first block of layers 2-4) cannot emit the BatchNorm-backward statistics of the block input
-            # from its dgrad epilogue (that fusion needs a stride-1 dgrad), and as the LAST writer of the input gradient it forced a
-            # separate statistics pass over the widest tensors of the previous stage (3 launches of up to 58 us per ResNet-50 step).
-            # When the main branch ends in a stride-1 dgrad (Bottleneck, style='pytorch': conv1 is 1x1 / stride 1), the shortcut's
-            # input gradient is computed FIRST and the main branch adds it - and emits the statistics.
-            if (d.unit.stride != 1 and convs[0].unit.stride == 1 and next_bn is not None and need_input_grad
-                    and os.environ.get('VFS_DS_FIRST', '1') == '1'):
-                boh, bow = bctx['dims'][last][2:]
-                gds = eng.conv_bwd(d.unit, ddx, bctx['x'], N, h, w, boh, bow, need_dgrad=True)
         for ci in range(last, -1, -1):
             c = convs[ci]
             ih, iw, oh, ow = bctx['dims'][ci]
             x_in = bctx['x'] if ci == 0 else bctx['acts'][ci - 1]
-            add = gm if (ci == 0 and blk.downsample is None) else (gds if ci == 0 else None)
+            add = gm if (ci == 0 and blk.downsample is None) else None
             if ci > 0:       # plain conv-BN-ReLU unit in front: its statistics come out of this dgrad
                 bn_next = (convs[ci - 1].unit, bctx['raws'][ci - 1], None, True, groups(convs[ci - 1].unit))
-            elif (blk.downsample is None or gds is not None) and next_bn is not None:
+            elif blk.downsample is None and next_bn is not None:
                 bn_next = (next_bn[0], next_bn[1], next_bn[2], True, groups(next_bn[0]))
             else:
                 bn_next = None
             x_in_bn = bctx['act_bn'][ci - 1] if ci > 0 else None
             gin = eng.conv_bwd(c.unit, dx, x_in, N, ih, iw, oh, ow, need_dgrad=(ci > 0 or need_input_grad), add=add, bn_next=bn_next,
-                               x_in_bn=x_in_bn, add_mask=gmask if (add is not None and gds is None) else None)
+                               x_in_bn=x_in_bn, add_mask=gmask if add is not None else None)
             if ci > 0:
                 p = convs[ci - 1]
                 _, _, ph, pw = bctx['dims'][ci - 1]
                 dx, _ = eng.bn_bwd(p.unit, gin, None, bctx['raws'][ci - 1], N * ph * pw, G, relu=True)
-        if blk.downsample is not None and gds is None:
+        if blk.downsample is not None:
             d = blk.downsample
             boh, bow = bctx['dims'][last][2:]
             bn_next = None if next_bn is None else (next_bn[0], next_bn[1], next_bn[2], True, groups(next_bn[0]))
