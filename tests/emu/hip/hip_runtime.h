@@ -446,22 +446,18 @@ inline void vfs_dma16_async(vfs_rsrc_words rsrc, void* lds_wave_base, unsigned v
   memcpy((char*)lds_wave_base + 16 * emu::lane_id(), &v, 16);
 }
 inline void vfs_dma_wait_all() {}
-// agent-scope relaxed accesses (csrc/vfs_common.h): blocks may run on different host threads
-inline void vfs_store_agent(double* p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
-inline double vfs_load_agent(const double* p) { double v; __atomic_load(const_cast<double*>(p), &v, __ATOMIC_SEQ_CST); return v; }
-inline unsigned vfs_ticket_agent(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
-inline void vfs_release_workgroup() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-// system-scope accesses of csrc/p2p.hip: two "ranks" are two host threads of the test process
-inline void vfs_store_system(double* p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
-inline double vfs_load_system(const double* p) { double v; __atomic_load(const_cast<double*>(p), &v, __ATOMIC_SEQ_CST); return v; }
-inline void vfs_store_system_release(unsigned long long* p, unsigned long long v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
-inline unsigned long long vfs_load_system_acquire(const unsigned long long* p) {
-  unsigned long long v;
-  __atomic_load(const_cast<unsigned long long*>(p), &v, __ATOMIC_SEQ_CST);
-  return v;
-}
-inline void vfs_fence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-inline void vfs_spin_pause() { std::this_thread::yield(); }
+// The HIP atomic intrinsics, scopes and fences csrc/vfs_common.h uses for inter-workgroup / inter-process hand-offs: blocks run on
+// different host threads, two "ranks" of csrc/p2p.hip on two host threads of the test process.
+// (__hip_atomic_load / _store / _fetch_add are clang builtins in host C++ too; the scope macros are only predefined in HIP mode -
+// on the host every scope is the whole process)
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#define __builtin_amdgcn_s_sleep(n) std::this_thread::yield()
 
 template <typename T>
 inline T atomicAdd(T* p, T v) {

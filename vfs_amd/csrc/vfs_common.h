@@ -95,8 +95,8 @@ inline void vfs_dma_wait() {}
 // that bypass the non-coherent per-XCD L2 state, WITHOUT the L2 write-back + invalidate a full
 // __threadfence() costs on gfx950 (measured: a 512-workgroup reduction went from 17 to 50 us with
 // fences while megabytes of dirty conv output sat in the L2).  vfs_release_workgroup() makes the wave
-// wait until its own stores have been performed.  (tests/emu supplies host versions.)
-#ifndef VFS_EMU
+// wait until its own stores have been performed.  (Plain HIP intrinsics: tests/emu/hip/hip_runtime.h defines __hip_atomic_* / the
+// fences for the host build, so nothing here is conditional.)
 __device__ __forceinline__ void vfs_store_agent(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -136,17 +136,6 @@ __device__ __forceinline__ unsigned long long vfs_load_system_acquire(const unsi
 }
 __device__ __forceinline__ void vfs_fence_system() { __threadfence_system(); }
 __device__ __forceinline__ void vfs_spin_pause() { __builtin_amdgcn_s_sleep(8); }
-#else   // host emulation: blocks run on different threads
-inline void vfs_store_agent(float* p, f32x4 v) {
-  for (int i = 0; i < 4; ++i) { float x = v[i]; __atomic_store(p + i, &x, __ATOMIC_SEQ_CST); }
-}
-inline f32x4 vfs_load_agent4(const float* p) {
-  f32x4 v;
-  for (int i = 0; i < 4; ++i) { float x; __atomic_load(const_cast<float*>(p + i), &x, __ATOMIC_SEQ_CST); v[i] = x; }
-  return v;
-}
-inline void vfs_store_agent(unsigned* p, unsigned v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
-#endif
 
 __device__ __forceinline__ u32x4 zero16() {
   u32x4 z = {0u, 0u, 0u, 0u};
