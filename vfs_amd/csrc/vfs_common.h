@@ -95,7 +95,7 @@ inline void vfs_dma_wait() {}
 // that bypass the non-coherent per-XCD L2 state, WITHOUT the L2 write-back + invalidate a full
 // __threadfence() costs on gfx950 (measured: a 512-workgroup reduction went from 17 to 50 us with
 // fences while megabytes of dirty conv output sat in the L2).  vfs_release_workgroup() makes the wave
-// wait until its own stores have been performed.  (Plain HIP intrinsics: tests/emu/hip/hip_runtime.h defines __hip_atomic_* / the
+// wait until its own stores have been performed (acknowledged).  (Plain HIP intrinsics: tests/emu/hip/hip_runtime.h defines __hip_atomic_* / the
 // fences for the host build, so nothing here is conditional.)
 __device__ __forceinline__ void vfs_store_agent(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -123,7 +123,16 @@ __device__ __forceinline__ void vfs_store_agent(unsigned* p, unsigned v) {
 __device__ __forceinline__ unsigned vfs_ticket_agent(unsigned* p) {
   return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void vfs_release_workgroup() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// Round 3 FIX: the workgroup-scope release fence alone compiles to NO wait for vector-memory stores (in the non-tgsplit memory
+// model the waves of a workgroup share their CU's L1, so workgroup scope needs none): the ISA was `global_store ... sc1`, `s_barrier`,
+// `global_atomic_add` - the ticket could be performed at the L2 while a chunk sum was still in flight, and the workgroup that drew
+// the last ticket could read a stale sum (seen as a wrong loss in ~1 of 30 eager ResNet-18 full-size runs,
+// test_train_step_properties_r18_full_size).  `s_waitcnt vmcnt(0)` first: the sc1 stores of this wave have been acknowledged by
+// the memory side before its threads reach the barrier in front of the ticket.
+__device__ __forceinline__ void vfs_release_workgroup() {
+  vfs_dma_wait_all();      // s_waitcnt vmcnt(0)  (host emulation: nothing to wait for)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
 // System scope (other GPUs over xGMI, other processes through hipIpc mappings; csrc/p2p.hip): accesses that are performed
 // at the memory, not in this GPU's caches.
 __device__ __forceinline__ void vfs_store_system(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
