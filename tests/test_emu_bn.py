@@ -539,3 +539,33 @@ def test_wide_slab_streaming_equals_64_channel_slabs(backend, G, mpg, C):
     for a, b in zip(narrow, wide):
         assert torch.equal(a, b)
     assert torch.equal(narrow[1], pack_relu_mask(narrow[0]))
+
+
+@pytest.mark.gpu
+def test_ticketed_reduction_under_memory_pressure(gpu_backend):
+    """regression for the round-3 memory-ordering fix (vfs_release_workgroup: s_waitcnt vmcnt(0) before the ticket): the chunked
+    single-launch reduction - chunk sums handed to the last-ticket workgroup through agent-scope stores - repeated 400 times on
+    8192 statistics rows while a second stream keeps the memory system busy; every repetition must reproduce the first one bit for bit
+    and equal the fp64 host sum"""
+    lib, dev = gpu_backend.lib, gpu_backend.dev
+    G, bpg, C = 2, 4096, 64
+    g = torch.Generator().manual_seed(5)
+    part = torch.randn(G * bpg, 2, C, generator=g).to(dev)
+    want = part.double().view(G, bpg, 2, C).sum(1).cpu()
+    scratch = torch.zeros(32 + G * 128 * 2 * C, dtype=torch.float64, device=dev)
+    big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    big_b = torch.empty_like(big_a)
+    side = torch.cuda.Stream(dev)
+    outs = []
+    for it in range(400):
+        if it % 4 == 0:
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a)
+        sums = torch.zeros(G, 2, C, dtype=torch.float64, device=dev)
+        lib.bn_reduce_partials(part, sums, scratch, G, bpg, C, None)
+        outs.append(sums)
+    torch.cuda.synchronize()
+    first = outs[0].cpu()
+    assert torch.allclose(first, want, rtol=1e-12, atol=1e-9)
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o.cpu(), first)]
+    assert not bad, bad[:10]
