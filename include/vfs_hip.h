@@ -313,7 +313,7 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
  * (affinity_utils.py:144-156): fbank [frames][H*W][C] normalised bf16, sbank [frames][H*W][CO]
  * fp32; key frames kslot[0..nkeys) in the reference's order (first frame first, duplicates
  * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), the first non_mask_len
- * key frames are never masked (test_cfg.with_first_neighbor=False -> 1), topk <= 10, nkeys <= 24,
+ * key frames are never masked (test_cfg.with_first_neighbor=False -> 1), topk <= 10, nkeys <= 64,
  * C % 64 == 0.  workspace: 24*H*W*10*8 bytes (per-split partial top-k lists: key frames are split
  * over workgroups because a DAVIS frame has only 8x14 query tiles) */
 int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe,

@@ -369,3 +369,25 @@ def test_full_size_davis_clip_fp32_bit_exact_vs_oracle(gpu_backend, depth, T):
     assert out[0].shape == (T, H, W)
     assert np.array_equal(out[0], want), float((out[0] != want).mean())
     assert len(np.unique(out[0][-1])) == 4
+
+
+def test_forward_test_many_key_frames(backend):
+    """precede_frames + first frame = 41 key frames per step (round 3: the kernels take up to 64, was 24): a 44-frame 32x40 clip
+    (4x5 feature map) - the window fills at frame 40 and slides afterwards - bit-exact against the C oracle, fp32 and (labels
+    statistically) bf16 kernels take the same number of keys; one key more than the limit is refused, not clipped"""
+    model, ref, tc = _davis_model(backend.dev, precede_frames=40, neighbor_range=6)
+    T, H, W = 44, 32, 40
+    imgs = O.fill_tensor([1, 1, 3, 1, H, W], 71, scale=2.0) + 0.3 * O.fill_tensor([1, 1, 3, T, H, W], 72, scale=2.0)
+    seg = np.zeros((H, W), np.uint8)
+    seg[4:20, 6:22] = 1
+    seg[14:30, 20:38] = 2
+    out = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None], img_meta=[dict(original_shape=(H, W, 3))])
+    want = X.forward_test(ref.state_dict(), 18, imgs, seg, (H, W, 3), tc)
+    assert out[0].shape == (T, H, W) and np.array_equal(out[0], want)
+    model.test_cfg['precision'] = 'bf16'
+    out16 = model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None], img_meta=[dict(original_shape=(H, W, 3))])
+    assert out16[0].shape == (T, H, W) and float((out16[0] == want).mean()) > 0.9
+    model.test_cfg['precision'] = 'fp32'
+    model.test_cfg['precede_frames'] = 64
+    with pytest.raises(NotImplementedError):
+        model(imgs.to(backend.dev), return_loss=False, ref_seg_map=torch.from_numpy(seg)[None], img_meta=[dict(original_shape=(H, W, 3))])

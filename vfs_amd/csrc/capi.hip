@@ -519,7 +519,7 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
 }
 int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
                   int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {
-  if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 24");
+  if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 64");
   if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop: 0 <= non_mask_len < nkeys");
   LabelPropArgs a;
   a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;
@@ -559,7 +559,7 @@ int vfs_l2norm_rows_f32(const float* x, float* y, long long P, int C, vfs_stream
 }
 int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
                       int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {
-  if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 24");
+  if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 64");
   if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32: 0 <= non_mask_len < nkeys");
   LabelPropF32Args a;
   a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;

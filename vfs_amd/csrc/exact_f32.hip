@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void labelprop_f32_merge_kernel(LabelPropF32Ar
 int vfs_option_lpx_target = 0;   // workgroups the key frames of a query tile are split into; 0 = auto (A/B knob)
 int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s) {
   if (a.C % 4) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: C % 4");
-  if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 24");
+  if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 64");
   if (a.topk < 1 || a.topk > LPX_TOPK) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= topk <= 10");
   if (a.H >= 32768 || a.W >= 65536 || (long long)a.nkeys * a.H * a.W >= 0x7fffffffLL)
     return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: map too large for the packed candidate ids");

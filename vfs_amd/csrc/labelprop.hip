@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void labelprop_merge_kernel(LabelPropArgs a, i
 
 int vfs_labelprop_launch(const LabelPropArgs& a, hipStream_t s) {
   if (a.C % 64) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: C%64");
-  if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 24");
+  if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 64");
   if (a.topk < 1 || a.topk > LP_TOPK) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= topk <= 10");
   if (a.H >= 65536 || a.W >= 65536) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: H,W < 65536");
   const int tiles = ((a.H + 7) / 8) * ((a.W + 7) / 8);

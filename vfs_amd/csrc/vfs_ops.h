@@ -214,7 +214,7 @@ int vfs_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, float sca
 int vfs_bf16_to_f32_launch(const bf16_t* src, float* dst, long long n, hipStream_t s);
 
 // ---- labelprop.hip -------------------------------------------------------------------------
-#define LP_MAX_KEYS 24
+#define LP_MAX_KEYS 64      // key frames per propagation step (precede_frames + the first frame); round 3: 24 -> 64
 #define LP_MAX_CLASSES 256
 #define LP_POST_BLOCKS 64
 #define LP_MAX_SPLIT 24

@@ -11,8 +11,8 @@ Two precisions (test_cfg.precision, default 'fp32'; env VFS_EVAL_PRECISION overr
           reference computes in; label maps equal the C oracle's bit for bit;
   'bf16'  the training path's bf16 kernels and a bf16 bank (about 3x faster; labels differ where the exact
           10th / 11th affinities or the two best classes are nearly tied).
-Limits of the kernels (checked, errors raised): topk <= 10, at most 24 key frames per step
-(precede_frames + 1 <= 24), feature channels % 64 == 0 (bf16) / % 4 == 0 (fp32), <= 256 classes."""
+Limits of the kernels (checked, errors raised): topk <= 10, at most 64 key frames per step
+(precede_frames + 1 <= 64), feature channels % 64 == 0 (bf16) / % 4 == 0 (fp32), <= 256 classes."""
 import ctypes
 import os
 import tempfile
@@ -146,8 +146,8 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
     all_blocks = bool(tc.get('all_blocks', False))
     precede = int(tc['precede_frames'])
     topk, temp = int(tc['topk']), float(tc['temperature'])
-    if topk > 10 or precede + (1 if with_first else 0) > 24:
-        raise NotImplementedError(f'label propagation kernels: topk <= 10 (got {topk}), precede_frames + first frame <= 24 '
+    if topk > 10 or precede + (1 if with_first else 0) > 64:
+        raise NotImplementedError(f'label propagation kernels: topk <= 10 (got {topk}), precede_frames + first frame <= 64 '
                                   f'(got {precede + (1 if with_first else 0)})')
     if all_blocks:
         banks, shapes = extract_features(tracker, eng, imgs, int(tc.get('batch_step', 10)), True, precision, with_norm)
