@@ -314,8 +314,10 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
  * fp32; key frames kslot[0..nkeys) in the reference's order (first frame first, duplicates
  * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), the first non_mask_len
  * key frames are never masked (test_cfg.with_first_neighbor=False -> 1), topk <= 10, nkeys <= 64,
- * C % 64 == 0.  workspace: 24*H*W*10*8 bytes (per-split partial top-k lists: key frames are split
- * over workgroups because a DAVIS frame has only 8x14 query tiles) */
+ * C % 64 == 0.  workspace: vfs_labelprop_workspace_bytes (= 96*H*W*10*8: per-split partial top-k lists - key frames,
+ * and for vfs_labelprop_f32 the 64-key blocks of a frame's window as well, are split over workgroups because a DAVIS
+ * frame has only 8x14 query tiles) */
+int vfs_labelprop_workspace_bytes(int H, int W, long long* bytes);
 int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe,
                   const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len,
                   int topk, float temperature, vfs_stream_t stream);

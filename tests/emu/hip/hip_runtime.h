@@ -372,6 +372,7 @@ inline int __ffsll(unsigned long long x) { return __builtin_ffsll(x); }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2_f32(a, b, c)
 #define __builtin_amdgcn_readfirstlane(x) __shfl((x), 0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, sync) ((void)0)   // an instruction-scheduling hint: nothing to emulate
 // v_mov_b32 with a DPP control (gfx9 encodings): quad_perm 0x00-0xFF, row_shl 0x101-0x10F,
 // row_shr 0x111-0x11F, row_ror 0x121-0x12F, row_mirror 0x140, row_half_mirror 0x141.
 // All lanes active, full row/bank masks (the only form the kernels use).

@@ -117,6 +117,13 @@ LP_CASES = [
 ]
 
 
+def lp_workspace_floats(lib, H, W):
+    n = torch.zeros(1, dtype=torch.int64)
+    lib.labelprop_workspace_bytes(H, W, n)
+    assert n.item() == 96 * H * W * 10 * 8
+    return int(n.item()) // 4
+
+
 def run_labelprop_f32(be, T, H, W, C, CO, radius, slots, qframe, topk=10, non_mask_len=0, seed=0):
     lib = be.hostlib
     feats, seg = _bank(T, H, W, C, CO, seed)
@@ -124,11 +131,27 @@ def run_labelprop_f32(be, T, H, W, C, CO, radius, slots, qframe, topk=10, non_ma
     lib.l2norm_rows_f32(feats.reshape(-1, C).contiguous(), fb, T * H * W, C, None)
     out = torch.full((H * W, CO), float('nan'))
     ks = (ctypes.c_int * len(slots))(*slots)
-    ws = torch.zeros(24 * H * W * 10 * 2)
+    ws = torch.zeros(lp_workspace_floats(lib, H, W))
     lib.labelprop_f32(fb, seg, out, ws, qframe, ks, len(slots), H, W, C, CO, radius, non_mask_len, topk, 0.07, None)
     want = X.labelprop(fb.numpy(), seg.numpy(), qframe, slots, H, W, radius, topk, 0.07, non_mask_len=non_mask_len)
     assert same_bits(out.numpy(), want), float(np.abs(out.numpy() - want).max())
     return fb, seg, out
+
+
+@pytest.mark.parametrize('wgs,minb', [(1 << 20, 1), (1 << 20, 2), (40, 1)])
+def test_labelprop_f32_window_subsplit_bit_exact(backend, wgs, minb):
+    """the 64-key blocks of a key frame's window dealt to several workgroups (lpx_wgs / lpx_minb: more partial top-k lists per
+    query, some of them empty on border tiles): the same bits as the oracle for every split"""
+    lib = backend.hostlib
+    try:
+        lib.set_option(b'lpx_wgs', wgs)
+        lib.set_option(b'lpx_minb', minb)
+        for case in LP_CASES:
+            run_labelprop_f32(backend, **case)
+        run_labelprop_f32(backend, T=3, H=24, W=40, C=32, CO=4, radius=9, slots=[0, 0, 1], qframe=2)    # 10 blocks per window
+    finally:
+        lib.set_option(b"lpx_wgs", 0)
+        lib.set_option(b'lpx_minb', 4)
 
 
 @pytest.mark.parametrize('case', LP_CASES)

@@ -72,7 +72,7 @@ def main():
     CO = 3
     sbank = torch.rand(T, h * w, CO, device=dev)
     s = eng.stream(dev)
-    lpws = torch.empty(24 * h * w * 10 * 2, device=dev)
+    lpws = torch.empty(96 * h * w * 10 * 2, device=dev)     # vfs_labelprop_workspace_bytes
     f = T - 1
     slots = [0] + list(range(max(0, f - 20), f))
     ks = (ctypes.c_int * len(slots))(*slots)

@@ -30,7 +30,7 @@ int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_bn_wide, vfs_option_bn_wide_min_mb;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
-extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target;
+extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target, vfs_option_lpx_wgs, vfs_option_lpx_minb;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -59,6 +59,8 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "igemm_onek")) { vfs_option_igemm_onek = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_tiles")) { vfs_option_igemm_ring_tiles = value; return VFS_OK; }
   if (!strcmp(name, "lpx_target")) { vfs_option_lpx_target = value; return VFS_OK; }
+  if (!strcmp(name, "lpx_wgs")) { vfs_option_lpx_wgs = value; return VFS_OK; }
+  if (!strcmp(name, "lpx_minb")) { vfs_option_lpx_minb = value; return VFS_OK; }
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_xcd")) { vfs_option_wgrad_xcd = value; return VFS_OK; }
@@ -516,6 +518,11 @@ int vfs_bf16_to_f32(const vfs_bf16* src, float* dst, long long n, vfs_stream_t s
 
 int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stream_t stream) {
   return vfs_l2norm_rows_launch(x, y, P, C, S(stream));
+}
+int vfs_labelprop_workspace_bytes(int H, int W, long long* bytes) {
+  if (!bytes || H <= 0 || W <= 0) return vfs_set_error(VFS_ERR_ARG, "labelprop_workspace_bytes: bad argument");
+  *bytes = (long long)LP_MAX_SPLIT * H * W * 10 * 8;
+  return VFS_OK;
 }
 int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
                   int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {

@@ -30,61 +30,71 @@ __device__ __forceinline__ f32x4 zerof4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; 
 // implicit-GEMM convolution, fp32 NHWC, any kernel size / stride / padding / dilation, Cin % 4 == 0
 // workgroup = 128 output pixels x 64 output channels, K in chunks of 16 (kh, kw, cin ascending);
 // wave (w&1, w>>1) owns 64 pixels x 32 channels = two 32x32x2 MFMA tiles (A = pixels, B = channels)
-// LDS image [k-pair][row][2]: lane (i = l&31, kk = l>>5) of MFMA step s reads element [s][row0+i][kk]
+// LDS image [k][row]: lane (i = l&31, kk = l>>5) of MFMA step s reads element [2s + kk][row0 + i]
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   constexpr int BM = 128, BN = 64, BK = 16;
-  __shared__ __attribute__((aligned(16))) float sA[BK / 2][BM][2];
-  __shared__ __attribute__((aligned(16))) float sB[BK / 2][BN][2];
+  // LDS planes [k][row] (+2 dwords of padding per plane): MFMA step s reads plane 2s + (lane >> 5), 32 consecutive dwords per
+  // half-wave - conflict-free, and so are the loaders' ds_write_b32 (8 rows x 4 float4 groups per half-wave: banks 8q + row)
+  constexpr int PA = BM + 2, PB = BN + 2;
+  __shared__ float sA[BK * PA];
+  __shared__ float sB[BK * PB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long long M = (long long)a.N * a.Ho * a.Wo;
   const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int C4 = a.Cin >> 2;
   const int K4 = a.KH * a.KW * C4;           // float4 groups along K
-  // A loader: pixel t&127, float4 groups (t>>7) and (t>>7)+2 of the chunk
-  const int ap = t & 127, aq = t >> 7;
-  const long long am = m0 + ap;
-  const bool a_ok = am < M;
-  int an = 0, iy0 = 0, ix0 = 0;
-  if (a_ok) {
-    const int hw = a.Ho * a.Wo;
-    an = (int)(am / hw);
-    const int rem = (int)(am - (long long)an * hw);
-    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
+  // loaders: FOUR CONSECUTIVE LANES read the 64 contiguous bytes one row has in a chunk (thread = row t>>2, float4 group t&3):
+  // a wave instruction touches 16 rows.  With one row per lane (64 different cache lines per instruction) the vector memory
+  // path needed ~156 clk per wave instruction (tools/probe_vmem_rate.hip) and bounded the kernel at half the MFMA rate.
+  const int lq = t & 3;
+  // A: pixels (t>>2) and (t>>2) + 64
+  const int ap = t >> 2;
+  bool a_ok[2];
+  int an[2], iy0[2], ix0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long long am = m0 + ap + 64 * i;
+    a_ok[i] = am < M;
+    an[i] = 0; iy0[i] = 0; ix0[i] = 0;
+    if (a_ok[i]) {
+      const int hw = a.Ho * a.Wo;
+      an[i] = (int)(am / hw);
+      const int rem = (int)(am - (long long)an[i] * hw);
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      iy0[i] = oy * a.stride - a.pad; ix0[i] = ox * a.stride - a.pad;
+    }
   }
-  // B loader: channel t&63, float4 group t>>6
-  const int bc = t & 63, bq = t >> 6;
+  // B: output channel t>>2
+  const int bc = t >> 2;
   const bool b_ok = n0 + bc < a.Cout;
   const float* wrow = a.w + (size_t)(b_ok ? n0 + bc : 0) * K4 * 4;
 
   f32x4 ra[2], rb;
   auto load = [&](int chunk) {
+    const int k4 = chunk * 4 + lq;
+    const bool k_ok = k4 < K4;
+    const int tap = k_ok ? k4 / C4 : 0, c = (k4 - tap * C4) * 4;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int k4 = chunk * 4 + aq + 2 * i;
       f32x4 v = zerof4();
-      if (a_ok && k4 < K4) {
-        const int tap = k4 / C4, c = (k4 - tap * C4) * 4;
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const int iy = iy0 + kh * a.dil, ix = ix0 + kw * a.dil;
+      if (a_ok[i] && k_ok) {
+        const int iy = iy0[i] + kh * a.dil, ix = ix0[i] + kw * a.dil;
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          v = ldf4(a.x + (((size_t)an * a.H + iy) * a.W + ix) * a.Cin + c);
+          v = ldf4(a.x + (((size_t)an[i] * a.H + iy) * a.W + ix) * a.Cin + c);
       }
       ra[i] = v;
     }
-    const int k4 = chunk * 4 + bq;
-    rb = (b_ok && k4 < K4) ? ldf4(wrow + (size_t)k4 * 4) : zerof4();
+    rb = (b_ok && k_ok) ? ldf4(wrow + (size_t)k4 * 4) : zerof4();
   };
   auto store = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = aq + 2 * i;
-      *reinterpret_cast<vfs_f32x2*>(&sA[2 * q][ap][0]) = (vfs_f32x2){ra[i][0], ra[i][1]};
-      *reinterpret_cast<vfs_f32x2*>(&sA[2 * q + 1][ap][0]) = (vfs_f32x2){ra[i][2], ra[i][3]};
+    for (int e = 0; e < 4; ++e) {
+      sA[(4 * lq + e) * PA + ap] = ra[0][e];
+      sA[(4 * lq + e) * PA + ap + 64] = ra[1][e];
+      sB[(4 * lq + e) * PB + bc] = rb[e];
     }
-    *reinterpret_cast<vfs_f32x2*>(&sB[2 * bq][bc][0]) = (vfs_f32x2){rb[0], rb[1]};
-    *reinterpret_cast<vfs_f32x2*>(&sB[2 * bq + 1][bc][0]) = (vfs_f32x2){rb[2], rb[3]};
   };
 
   f32x16 acc[2];
@@ -102,8 +112,8 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
     if (ch + 1 < nchunks) load(ch + 1);
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      const float b = sB[s][wc0 + li][lk];
-      const float a0 = sA[s][wp0 + li][lk], a1 = sA[s][wp0 + 32 + li][lk];
+      const float b = sB[(2 * s + lk) * PB + wc0 + li];
+      const float a0 = sA[(2 * s + lk) * PA + wp0 + li], a1 = sA[(2 * s + lk) * PA + wp0 + 32 + li];
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
     }
@@ -277,7 +287,7 @@ __device__ __forceinline__ void lpx_insert(float (&tv)[LPX_TOPK], int (&ti)[LPX_
 // (8 + 2(r-1))^2 window that can lie inside the circle, 64 keys per block, channels in stages of 32.
 // wave (w&1, w>>1) = 32 keys x 32 queries: ONE 32x32x2 MFMA tile (A = keys, B = queries), so a lane owns
 // 16 keys of one query; the four partial top-10 lists of a query (2 key halves x 2 lane halves) merge through LDS.
-__global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a) {
+__global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a, int nsub) {
   constexpr int BQ = 64, BKEY = 64, BC = 32;
   __shared__ __attribute__((aligned(16))) float sK[BC / 2][BKEY][2];
   __shared__ __attribute__((aligned(16))) float sQ[BC / 2][BQ][2];
@@ -324,8 +334,10 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a) 
     thr = fmaxf(m, __shfl_xor(m, 32));
   };
 
-  const int fpb = (a.nkeys + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int f_begin = (int)blockIdx.y * fpb, f_end = min(a.nkeys, f_begin + fpb);
+  // blockIdx.y = (key-frame split, sub-split): the 64-key blocks of a frame's window are dealt to nsub workgroups in contiguous runs
+  const int nfs = (int)gridDim.y / nsub, fs = (int)blockIdx.y / nsub, sub = (int)blockIdx.y - fs * nsub;
+  const int fpb = (a.nkeys + nfs - 1) / nfs;
+  const int f_begin = fs * fpb, f_end = min(a.nkeys, f_begin + fpb);
   for (int f = f_begin; f < f_end; ++f) {
     const int slot = a.kslot[f];
     // the first non_mask_len key frames are not masked (local_attention.py:303-309: with_first_neighbor=False)
@@ -336,8 +348,9 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a) 
       wx0 = max(0, qx0 - (r - 1)); wx1 = min(W - 1, qx0 + 7 + (r - 1));
     }
     const int ww = wx1 - wx0 + 1, nwin = (wy1 - wy0 + 1) * ww;
-    const int nkb = (nwin + BKEY - 1) / BKEY;
-    for (int kb = 0; kb < nkb; ++kb) {
+    const int nkb = (nwin + BKEY - 1) / BKEY, cpb = (nkb + nsub - 1) / nsub;
+    const int kb_end = min(nkb, (sub + 1) * cpb);
+    for (int kb = sub * cpb; kb < kb_end; ++kb) {
       const int kk = kb * BKEY + lrow;
       const bool k_ok = kk < nwin;
       const int ky = wy0 + (k_ok ? kk / ww : 0), kx = wx0 + (k_ok ? kk % ww : 0);
@@ -462,6 +475,9 @@ __global__ __launch_bounds__(256) void labelprop_f32_merge_kernel(LabelPropF32Ar
 }
 
 int vfs_option_lpx_target = 0;   // workgroups the key frames of a query tile are split into; 0 = auto (A/B knob)
+int vfs_option_lpx_wgs = 0;      // workgroups a launch should reach by ALSO splitting a key frame's window; 0 = auto (3072 for C >= 512:
+                                 // R50 5.33-5.39 vs 5.45-5.50 ms per frame; R18 is faster without: 1.48 vs 1.54), < 0 = never
+int vfs_option_lpx_minb = 4;     // ... with at least this many 64-key blocks per workgroup
 int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s) {
   if (a.C % 4) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: C % 4");
   if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 64");
@@ -476,10 +492,22 @@ int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s) {
   const int target = vfs_option_lpx_target > 0 ? vfs_option_lpx_target : (a.C >= 512 ? 2400 : 768);
   int nsplit = (target + tiles - 1) / tiles;
   if (nsplit > a.nkeys) nsplit = a.nkeys;
-  if (nsplit > LP_MAX_SPLIT) nsplit = LP_MAX_SPLIT;
+  if (nsplit > LP_MAX_FSPLIT) nsplit = LP_MAX_FSPLIT;
   const int fpb = (a.nkeys + nsplit - 1) / nsplit;
   nsplit = (a.nkeys + fpb - 1) / fpb;
-  hipLaunchKernelGGL(labelprop_f32_kernel, dim3(tiles, nsplit), dim3(256), 0, s, a);
+  // a workgroup of one key frame runs ~1 ms (R50, radius 18) and a launch has only 1-3 of them per slot (the first frames of
+  // a clip: fewer workgroups than CUs): the window's 64-key blocks are dealt to nsub workgroups as well
+  int nsub = 1;
+  const int wgs = vfs_option_lpx_wgs > 0 ? vfs_option_lpx_wgs : (vfs_option_lpx_wgs == 0 && a.C >= 512 ? 3072 : 0);
+  if (wgs > 0) {
+    const int wh = a.radius > 0 ? min(a.H, 8 + 2 * (a.radius - 1)) : a.H, ww = a.radius > 0 ? min(a.W, 8 + 2 * (a.radius - 1)) : a.W;
+    const int blocks = (wh * ww + 63) / 64;
+    nsub = (wgs + tiles * nsplit - 1) / (tiles * nsplit);
+    nsub = min(nsub, max(1, blocks / max(1, vfs_option_lpx_minb)));
+    nsub = max(1, min(nsub, LP_MAX_SPLIT / nsplit));
+  }
+  nsplit *= nsub;
+  hipLaunchKernelGGL(labelprop_f32_kernel, dim3(tiles, nsplit), dim3(256), 0, s, a, nsub);
   int rc = vfs_check_launch("labelprop_f32");
   if (rc) return rc;
   hipLaunchKernelGGL(labelprop_f32_merge_kernel, dim3((a.H * a.W + 255) / 256), dim3(256), 0, s, a, nsplit);

@@ -257,7 +257,7 @@ int vfs_labelprop_launch(const LabelPropArgs& a, hipStream_t s) {
   if (a.pval == nullptr || a.pidx == nullptr) return vfs_set_error(VFS_ERR_ARG, "labelprop: partial workspace missing");
   int nsplit = (768 + tiles - 1) / tiles;                 // ~3 workgroups per CU
   if (nsplit > a.nkeys) nsplit = a.nkeys;
-  if (nsplit > LP_MAX_SPLIT) nsplit = LP_MAX_SPLIT;
+  if (nsplit > LP_MAX_FSPLIT) nsplit = LP_MAX_FSPLIT;
   const int fpb = (a.nkeys + nsplit - 1) / nsplit;
   nsplit = (a.nkeys + fpb - 1) / fpb;
   hipLaunchKernelGGL(labelprop_kernel, dim3(tiles, nsplit), dim3(256), 0, s, a);

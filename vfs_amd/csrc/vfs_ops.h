@@ -217,7 +217,8 @@ int vfs_bf16_to_f32_launch(const bf16_t* src, float* dst, long long n, hipStream
 #define LP_MAX_KEYS 64      // key frames per propagation step (precede_frames + the first frame); round 3: 24 -> 64
 #define LP_MAX_CLASSES 256
 #define LP_POST_BLOCKS 64
-#define LP_MAX_SPLIT 24
+#define LP_MAX_SPLIT 96     // partial top-k lists per query (key-frame splits x window sub-splits): the workspace rows
+#define LP_MAX_FSPLIT 24    // key-frame splits
 struct LabelPropArgs {
   const bf16_t* fbank;  // [frames][H*W][C] L2-normalised bf16 features (the clip's feature bank)
   const float* sbank;   // [frames][H*W][CO] fp32 value logits (frame 0 = one-hot labels)

@@ -186,7 +186,9 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
             raise NotImplementedError('label propagation kernels: at most 256 classes')
         pairs = mask_pairs(h, w, radius)
         partial = eng.ws('ws.segpost', 64 * CO * 2, F32, dev)
-        lpws = eng.ws('ws.labelprop', 24 * h * w * 10 * 2, F32, dev)
+        nbytes = torch.zeros(1, dtype=torch.int64)
+        eng.lib.labelprop_workspace_bytes(h, w, nbytes)
+        lpws = eng.ws('ws.labelprop', int(nbytes.item()) // 4, F32, dev)
         for f in range(1, clip_len):
             key_start = max(0, f - precede)
             slots = list(range(key_start, f))
