@@ -1,15 +1,22 @@
 // The staging pipeline of labelprop_f32_kernel in isolation (no scoring / top-k): what does ONE structural change buy?
 // Same geometry as the product kernel on a DAVIS res4 map (60 x 107, C = 1024, 21 key frames, radius 18): a workgroup =
 // an 8x8 query tile x one key frame, 64-key blocks of the window, channels in stages of 32, one 32x32x2 MFMA tile per wave.
-// Every variant computes the same fma chains (the per-thread checksums must agree bit for bit).
-//   V0  the product kernel's loop (registers -> LDS stores -> barrier -> loads of the next stage -> operand reads + MFMAs -> barrier)
-//   V1  V0 with the LDS operand reads of MFMA pair p+1 requested before the MFMAs of pair p (explicit register double buffer)
-//   V2  V1 with unconditional loads (clamped rows; C % 32 == 0 assumed): no exec-mask branches around the loads
-//   V3  V2 with TWO register stages in flight (loads of stage st+2 issued during stage st)
-// hipcc --offload-arch=gfx950 -O3 tools/probe_lp_stage.hip -o /tmp/probe_lp_stage && /tmp/probe_lp_stage
+// Every structure computes the same fma chains: the checksums of V2.., coal, ring, ring3 must agree bit for bit (V0 / V1 zero-fill
+// the rows past the window instead of clamping them; ring2 has a known race in super blocks of ONE chunk, its timings stand).
+//   V0     the product kernel's loop (registers -> LDS stores -> barrier -> loads of the next stage -> operand reads + MFMAs -> barrier)
+//   V1     V0 with the operand reads of MFMA pair p+1 issued before the MFMAs of pair p (__builtin_amdgcn_sched_group_barrier)
+//   V2     V1 with unconditional loads (clamped rows; C % 32 == 0): no exec-mask branches around the loads
+//   V3     V2 with TWO register stages in flight
+//   coal   V2 with COALESCED loaders (8 consecutive lanes = one 128-byte line), LDS planes [s][row][2] (0) or [k][row] (1), padded
+//   ring   LDS-DMA ring of R stages (K + Q per stage), lane = (16-byte group, row): conflict-free ds_read2_b32 operand fetch
+//   ring2  micro-stage ring: the Q stage stays in LDS / registers for NA 64-key chunks, NA accumulators per wave
+//   ring3  LDS-DMA ring with coalesced transfers (XOR-swizzled inside the line), ds_read_b128 operand fetch + select
+// what-if bits (Args::skip) switch parts of a loop off; results: MEASUREMENTS.md (round 3), profiles/r03_probe_lp_stage_*.txt
+// hipcc --offload-arch=gfx950 -O3 -w tools/probe_lp_stage.hip -o tools/_build/probe_lp_stage && tools/_build/probe_lp_stage [suite]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string>
 #include <vector>
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -721,26 +728,33 @@ int main(int argc, char** argv) {
   const int tiles = ((H + 7) / 8) * ((W + 7) / 8);
   std::vector<float> host((size_t)tiles * 21 * 256);
   float* out; hipMalloc(&out, host.size() * 4);
-  for (int nk : {21}) {
-    Args a{bank, out, T - 1, nk, H, W, C, 18, 1, 0};
+  // suites: "summary" (default) every structure once, "v2" / "coal" / "ring" / "ring2" / "ring3": the what-if runs of one structure
+  const std::string suite = argc > 1 ? argv[1] : "summary";
+  Args a{bank, out, T - 1, 21, H, W, C, 18, 1, 0};
+  float* big; hipMalloc(&big, host.size() * 8 * 4);       // per-thread checksums of the sub-split runs (up to 8 workgroups per key frame)
+  const size_t nbig = host.size() * 8;
+  if (suite == "summary") {
     run<0>(a, tiles, host); run<1>(a, tiles, host); run<2>(a, tiles, host); run<3>(a, tiles, host);
-    a.skip = 0; run_ring<3, false>(a, tiles, host);
+    run_coal<0>(a, tiles, host); run_coal<1>(a, tiles, host);
+    run_ring<2, false>(a, tiles, host); run_ring<3, false>(a, tiles, host); run_ring<4, false>(a, tiles, host);
+    a.out = big;
+    run_ring3<2>(a, tiles, big, nbig); run_ring2<2>(a, tiles, big, nbig); run_ring2<4>(a, tiles, big, nbig);
+    a.nsub = 4;
+    run_ring3<2>(a, tiles, big, nbig); run_ring2<2>(a, tiles, big, nbig); run_ring2<4>(a, tiles, big, nbig);
+  } else if (suite == "v2") {
+    for (int sk : {0, 1, 2, 4, 8, 16, 3, 5, 6, 7, 11, 11 | 32, 64, 64 | 3, 64 | 11 | 32}) { a.skip = sk; run<2>(a, tiles, host); }
+  } else if (suite == "coal") {
     for (int sk : {0, 1 | 2, 2 | 4, 64}) { a.skip = sk; run_coal<0>(a, tiles, host); run_coal<1>(a, tiles, host); }
-    return 0;
-    float* out3; hipMalloc(&out3, host.size() * 8 * 4);
-    a.out = out3;
+  } else if (suite == "ring") {
+    for (int sk : {0, 1, 4, 16, 128, 128 | 16, 4 | 128 | 16, 64, 65, 68}) { a.skip = sk; run_ring<3, false>(a, tiles, host); run_ring<3, true>(a, tiles, host); }
+  } else if (suite == "ring2" || suite == "ring3") {
+    a.out = big;
     for (int ns : {1, 4}) {
       a.nsub = ns;
-      for (int sk : {0, 1, 4, 64}) { a.skip = sk; run_ring3<2>(a, tiles, out3, host.size() * 8); run_ring3<3>(a, tiles, out3, host.size() * 8); }
-    }
-    return 0;
-    float* out2; hipMalloc(&out2, host.size() * 8 * 4);
-    a.out = out2;
-    for (int ns : {1, 4}) {
-      a.nsub = ns;
-      for (int sk : {0, 1, 1 | 8, 1 | 32, 1 | 8 | 32, 64, 64 | 1, 64 | 1 | 8 | 32}) {
+      for (int sk : {0, 1, 4, 64, 64 | 1, 64 | 1 | 8 | 32}) {
         a.skip = sk;
-        run_ring2<2>(a, tiles, out2, host.size() * 8); run_ring2<4>(a, tiles, out2, host.size() * 8);
+        if (suite == "ring2") { run_ring2<2>(a, tiles, big, nbig); run_ring2<4>(a, tiles, big, nbig); }
+        else { run_ring3<2>(a, tiles, big, nbig); run_ring3<3>(a, tiles, big, nbig); }
       }
     }
   }

@@ -28,14 +28,18 @@ __device__ __forceinline__ f32x4 zerof4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; 
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution, fp32 NHWC, any kernel size / stride / padding / dilation, Cin % 4 == 0
-// workgroup = 128 output pixels x 64 output channels, K in chunks of 16 (kh, kw, cin ascending);
+// workgroup = 128 output pixels x 64 output channels, K in chunks of CONV_F32_BK (kh, kw, cin ascending);
 // wave (w&1, w>>1) owns 64 pixels x 32 channels = two 32x32x2 MFMA tiles (A = pixels, B = channels)
 // LDS image [k][row]: lane (i = l&31, kk = l>>5) of MFMA step s reads element [2s + kk][row0 + i]
+#ifndef CONV_F32_BK
+#define CONV_F32_BK 32     // channels per chunk: 32 MFMAs per wave between two barriers (16: DAVIS R50 5.21-5.22 vs 5.15-5.18 ms per frame, R18 1.45 vs 1.41)
+#endif
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
-  constexpr int BM = 128, BN = 64, BK = 16;
+  constexpr int BM = 128, BN = 64, BK = CONV_F32_BK, G = BK / 4, RPP = 256 / G;   // float4 groups per row and chunk, rows per loader pass
   // LDS planes [k][row] (+2 dwords of padding per plane): MFMA step s reads plane 2s + (lane >> 5), 32 consecutive dwords per
   // half-wave - conflict-free, and so are the loaders' ds_write_b32 (8 rows x 4 float4 groups per half-wave: banks 8q + row)
-  constexpr int PA = BM + 2, PB = BN + 2;
+  constexpr int PAD = CONV_F32_BK == 16 ? 2 : 1;       // banks of a store: (4 * group * (rows + PAD) + row) mod 32 - 8 * group + row (BK 16), 4 * group + row (BK 32)
+  constexpr int PA = BM + PAD, PB = BN + PAD;
   __shared__ float sA[BK * PA];
   __shared__ float sB[BK * PB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -44,17 +48,18 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   const int n0 = blockIdx.y * BN;
   const int C4 = a.Cin >> 2;
   const int K4 = a.KH * a.KW * C4;           // float4 groups along K
-  // loaders: FOUR CONSECUTIVE LANES read the 64 contiguous bytes one row has in a chunk (thread = row t>>2, float4 group t&3):
-  // a wave instruction touches 16 rows.  With one row per lane (64 different cache lines per instruction) the vector memory
+  // loaders: G CONSECUTIVE LANES read the 4 * BK contiguous bytes one row has in a chunk (thread = row t / G, float4 group t % G):
+  // a wave instruction touches 64 / G rows.  With one row per lane (64 different cache lines per instruction) the vector memory
   // path needed ~156 clk per wave instruction (tools/probe_vmem_rate.hip) and bounded the kernel at half the MFMA rate.
-  const int lq = t & 3;
-  // A: pixels (t>>2) and (t>>2) + 64
-  const int ap = t >> 2;
-  bool a_ok[2];
-  int an[2], iy0[2], ix0[2];
+  const int lq = t % G;
+  // A: pixels t / G + RPP * i
+  constexpr int NA = BM / RPP, NB = BN / RPP;
+  const int ap = t / G;
+  bool a_ok[NA];
+  int an[NA], iy0[NA], ix0[NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const long long am = m0 + ap + 64 * i;
+  for (int i = 0; i < NA; ++i) {
+    const long long am = m0 + ap + RPP * i;
     a_ok[i] = am < M;
     an[i] = 0; iy0[i] = 0; ix0[i] = 0;
     if (a_ok[i]) {
@@ -65,19 +70,24 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
       iy0[i] = oy * a.stride - a.pad; ix0[i] = ox * a.stride - a.pad;
     }
   }
-  // B: output channel t>>2
-  const int bc = t >> 2;
-  const bool b_ok = n0 + bc < a.Cout;
-  const float* wrow = a.w + (size_t)(b_ok ? n0 + bc : 0) * K4 * 4;
+  // B: output channels t / G + RPP * i
+  const int bc = t / G;
+  bool b_ok[NB];
+  const float* wrow[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    b_ok[i] = n0 + bc + RPP * i < a.Cout;
+    wrow[i] = a.w + (size_t)(b_ok[i] ? n0 + bc + RPP * i : 0) * K4 * 4;
+  }
 
-  f32x4 ra[2], rb;
+  f32x4 ra[NA], rb[NB];
   auto load = [&](int chunk) {
-    const int k4 = chunk * 4 + lq;
+    const int k4 = chunk * G + lq;
     const bool k_ok = k4 < K4;
     const int tap = k_ok ? k4 / C4 : 0, c = (k4 - tap * C4) * 4;
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       f32x4 v = zerof4();
       if (a_ok[i] && k_ok) {
         const int iy = iy0[i] + kh * a.dil, ix = ix0[i] + kw * a.dil;
@@ -86,14 +96,16 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
       }
       ra[i] = v;
     }
-    rb = (b_ok && k_ok) ? ldf4(wrow + (size_t)k4 * 4) : zerof4();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = (b_ok[i] && k_ok) ? ldf4(wrow[i] + (size_t)k4 * 4) : zerof4();
   };
   auto store = [&]() {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      sA[(4 * lq + e) * PA + ap] = ra[0][e];
-      sA[(4 * lq + e) * PA + ap + 64] = ra[1][e];
-      sB[(4 * lq + e) * PB + bc] = rb[e];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) sA[(4 * lq + e) * PA + ap + RPP * i] = ra[i][e];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) sB[(4 * lq + e) * PB + bc + RPP * i] = rb[i][e];
     }
   };
 
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   const int wp0 = (wave & 1) * 64, wc0 = (wave >> 1) * 32;
   const int li = lane & 31, lk = lane >> 5;
-  const int nchunks = (K4 + 3) >> 2;
+  const int nchunks = (K4 + G - 1) / G;
   load(0);
   for (int ch = 0; ch < nchunks; ++ch) {
     store();
