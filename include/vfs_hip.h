@@ -39,7 +39,9 @@ int vfs_abi_version(void);
  * "wgrad_lin" (linear-address path of the generic weight gradient for 1x1 / stride-1 problems, default 1),
  * "wgrad_xcd" / "halo_xcd" (XCD-aware block order of the weight-gradient kernels / the 3x3 halo kernels, default 1),
  * "halo_min_fill", "bn_chunk_rows", "bn_wide" / "bn_wide_min_mb" (plain BatchNorm apply passes on >= 128-channel tensors of at least
- * that many MB stream whole pixel rows per workgroup, default 1 / 8), "lpx_target" (workgroups of the fp32 label propagation; 0 = by channel count) */
+ * that many MB stream whole pixel rows per workgroup, default 1 / 8), "lpx_target" (workgroups the KEY FRAMES of the fp32 label propagation are split
+ * into; 0 = by channel count), "lpx_wgs" / "lpx_minb" (workgroups reached by also splitting a key frame's window, with at least
+ * lpx_minb 64-key blocks each; 0 = 3072 for C >= 512, < 0 = never; default minb 4) */
 int vfs_set_option(const char* name, int value);
 
 /* ---- input / parameter layout -------------------------------------------------------------
