@@ -33,6 +33,8 @@ CONV_CASES = [
     (2, 7, 9, 128, 256, 1, 2, 0, 1, False, False, True),     # strided 1x1 downsample, no ReLU
     (1, 10, 10, 64, 64, 3, 1, 2, 2, True, False, True),      # dilated (SiamFC backbone)
     (1, 6, 6, 256, 96, 1, 1, 0, 1, False, False, False),     # plain GEMM: no affine, Cout not a multiple of 64
+    (1, 5, 7, 20, 40, 3, 1, 1, 1, True, True, True),         # Cin % 32 != 0: a 32-channel chunk spans taps, K = 180 is ragged
+    (3, 4, 5, 8, 72, 2, 1, 0, 1, False, False, True),        # even kernel, two channel tiles with a ragged second one
 ]
 
 
