@@ -25,6 +25,18 @@ def test_library_exports_every_declared_symbol():
         assert f' T {name}' in syms, name
 
 
+def test_labelprop_workspace_query_is_host_only():
+    """vfs_labelprop_workspace_bytes: the size contract of the label propagation workspace (no GPU involved), and its argument check"""
+    lib = _lib.VfsLib(build.build_hip())
+    n = torch.zeros(1, dtype=torch.int64)
+    lib.labelprop_workspace_bytes(60, 107, n)
+    assert n.item() == 96 * 60 * 107 * 10 * 8
+    with pytest.raises(_lib.VfsError, match='labelprop_workspace_bytes'):
+        lib.labelprop_workspace_bytes(0, 107, n)
+    with pytest.raises(_lib.VfsError):
+        lib.labelprop_workspace_bytes(60, 107, None)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.VfsError):
         _lib.VfsLib(str(tmp_path / 'libvfs_hip.so'))
