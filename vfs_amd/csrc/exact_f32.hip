@@ -36,9 +36,10 @@ __device__ __forceinline__ f32x4 zerof4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; 
 #endif
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   constexpr int BM = 128, BN = 64, BK = CONV_F32_BK, G = BK / 4, RPP = 256 / G;   // float4 groups per row and chunk, rows per loader pass
-  // LDS planes [k][row] (+2 dwords of padding per plane): MFMA step s reads plane 2s + (lane >> 5), 32 consecutive dwords per
-  // half-wave - conflict-free, and so are the loaders' ds_write_b32 (8 rows x 4 float4 groups per half-wave: banks 8q + row)
-  constexpr int PAD = CONV_F32_BK == 16 ? 2 : 1;       // banks of a store: (4 * group * (rows + PAD) + row) mod 32 - 8 * group + row (BK 16), 4 * group + row (BK 32)
+  // LDS planes [k][row], PAD dwords of padding per plane: MFMA step s reads plane 2s + (lane >> 5), 32 consecutive dwords per
+  // half-wave - conflict-free; a half-wave of the loaders' ds_write_b32 covers 32 / G rows x G float4 groups at plane 4 * group + e:
+  // bank (4 * group * (rows + PAD) + row) mod 32 = 8 * group + row (BK 16, PAD 2) or 4 * group + row (BK 32, PAD 1) - 32 different
+  constexpr int PAD = CONV_F32_BK == 16 ? 2 : 1;
   constexpr int PA = BM + PAD, PB = BN + PAD;
   __shared__ float sA[BK * PA];
   __shared__ float sB[BK * PB];
