@@ -198,15 +198,22 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
         tot = sum(v[1] for v in agg.values())
         peak = PEAK_F32_TFLOPS if args.precision == 'fp32' else PEAK_BF16_TFLOPS
 
+        # HBM bytes per launch from the committed PMC passes of this workload (tools/gpu_pmc.sh <model> davis + make_traffic_json.py)
+        tclasses, tsource = {}, None
+        tpath = os.path.join(REPO, 'profiles', f'r03_traffic_davis_{args.model}.json')
+        if args.precision == 'fp32' and os.path.exists(tpath):
+            tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
+
         def family(kind):
             fl, tm, cnt, nb = agg[kind]
             hbm_bound = nb / (PEAK_HBM_GBS * 1e9) >= fl / (peak * 1e12)
             ach, pk, unit = (nb / tm / 1e9, PEAK_HBM_GBS, 'GB/s') if hbm_bound else (fl / tm / 1e12, peak, 'TFLOP/s')
             return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': pk, 'unit': unit, 'frac': ach / pk,
-                    'traffic': None, 'launches': cnt, 'avg_launch_ms': tm / cnt * 1e3, 'time_share_of_kernels': tm / tot,
+                    'traffic': tclasses.get(kind, {}).get('hbm_bytes_per_launch'), 'launches': cnt, 'avg_launch_ms': tm / cnt * 1e3, 'time_share_of_kernels': tm / tot,
                     'algorithmic_flop_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
         kind = max(agg, key=lambda k: agg[k][1])
         res['roofline'] = family(kind)
+        res['roofline']['traffic_source'] = tsource
         res['roofline']['note'] = ('FLOP = the affinity INSIDE the circular mask only (2 * C * in-mask (query, key) pairs per key frame; the '
                                    'dense T*HW x HW product the reference executes is not counted); peak = dense '
                                    + ('fp32-input MFMA (157.3 TFLOP/s)' if args.precision == 'fp32' else 'bf16 MFMA (2.5 PFLOP/s)'))

@@ -1,15 +1,18 @@
 #!/bin/bash
 # HBM traffic of the bench kernels from the L2 memory-side counters (separate passes per guide)
-MODEL=${1:-r18}
+# usage: tools/gpu_pmc.sh <r18|r50> [davis]   (davis: the fp32 DAVIS workload instead of the train step -> gpurun_out/pmc_davis_<model>.json)
+MODEL=${1:-r18}; WORK=${2:-train}
+if [ "$WORK" = davis ]; then BARGS="--workload davis --precision fp32 --steps 30 --warmup 0 --no-cpu-baseline --no-roofline"; OUT=davis_$MODEL
+else BARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-davis"; OUT=$MODEL; fi
 mkdir -p gpurun_out && cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-davis > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL $BARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
   echo "$C exit $?"
 done
 cd $GRAFT_REPO_ROOT
 ls gpurun_out/pmc_FETCH_SIZE | head
-python - $MODEL <<'PY'
+python - $OUT <<'PY'
 import csv, glob, collections, json, sys
 model = sys.argv[1]
 out = {}

@@ -23,7 +23,13 @@ CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels
     'bn_relu_maxpool': ('bn_relu_maxpool_kernel',),
     'pack_weights': ('pack_weights_kernel',),
     'sgd': ('sgd_kernel',),
+    # the fp32 DAVIS workload (bench.py --workload davis; `make_traffic_json.py davis_<model> <tag>`)
+    'labelprop_f32': ('labelprop_f32_kernel', 'labelprop_f32_merge_kernel'),
+    'conv_f32': ('conv_f32_kernel',),
+    'seg_postprocess': ('seg_minmax_exact_kernel', 'seg_argmax_exact_kernel'),
 }
+# families whose timed launch is SEVERAL kernels: bytes of all of them per launch of the first one
+LAUNCH_KERNEL = {'labelprop_f32': 'labelprop_f32_kernel', 'seg_postprocess': 'seg_minmax_exact_kernel'}
 NOT_A_LAUNCH = ()
 
 
@@ -34,7 +40,8 @@ def aggregate(kernels):
         for k, v in kernels.items():
             if any(n in k for n in names):
                 tot += (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) * v['calls']
-                launches += v['calls']
+                if cls not in LAUNCH_KERNEL or LAUNCH_KERNEL[cls] in k:
+                    launches += v['calls']
         if launches:
             classes[cls] = {'launches': launches, 'hbm_bytes_per_launch': tot / launches}
     return classes
@@ -57,8 +64,10 @@ def main():
         kernels[name] = {'calls': v['calls'], 'fetch_bytes_per_launch': 2.0 * v['sum'] * 1024 / v['calls'],
                          'write_bytes_per_launch': w['sum'] * 1024 / max(w['calls'], 1)}
     classes = aggregate(kernels)
-    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on '
-                     f'`VFS_GRAPHS=0 VFS_SIDE_STREAM=0 bench.py --model {model} --steps 3 --warmup 1` (tools/gpu_pmc.sh); '
+    cmd = (f'bench.py --workload davis --model {model[6:]} --precision fp32 --steps 30 --warmup 0` (tools/gpu_pmc.sh {model[6:]} davis: '
+           'every launch of the warm-up, the untimed and the timed pass over the 31-frame clip)' if model.startswith('davis_') else
+           f'VFS_GRAPHS=0 VFS_SIDE_STREAM=0 bench.py --model {model} --steps 3 --warmup 1` (tools/gpu_pmc.sh)')
+    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `' + cmd + '; '
                      'counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)',
            'kernels': kernels, 'classes': classes}
     path = os.path.join(repo, 'profiles', f'{tag}_traffic_{model}.json')
