@@ -697,15 +697,16 @@ static double run_coal(const Args& a, int tiles, std::vector<float>& host) {
   return best;
 }
 
+// ballast: dynamic LDS bytes that only lower the occupancy (36000: 3 workgroups per CU like the product kernel; 0: 8 per CU)
 template <int V>
-static double run(const Args& a, int tiles, std::vector<float>& host) {
+static double run(const Args& a, int tiles, std::vector<float>& host, unsigned ballast = 0) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(stage_kernel<V>, dim3(tiles, a.nkeys), dim3(256), 0, 0, a);
+  hipLaunchKernelGGL(stage_kernel<V>, dim3(tiles, a.nkeys), dim3(256), ballast, 0, a);
   hipDeviceSynchronize();
   float best = 1e9f;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(stage_kernel<V>, dim3(tiles, a.nkeys), dim3(256), 0, 0, a);
+    hipLaunchKernelGGL(stage_kernel<V>, dim3(tiles, a.nkeys), dim3(256), ballast, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     best = ms < best ? ms : best;
@@ -713,7 +714,7 @@ static double run(const Args& a, int tiles, std::vector<float>& host) {
   hipMemcpy(host.data(), a.out, host.size() * 4, hipMemcpyDeviceToHost);
   double s = 0.0;
   for (float v : host) s += (double)v;
-  printf("V%d nkeys %2d skip %2d: %.3f ms   checksum %.9e\n", V, a.nkeys, a.skip, best, s);
+  printf("V%d nkeys %2d skip %2d%s: %.3f ms   checksum %.9e\n", V, a.nkeys, a.skip, ballast ? " (3 workgroups per CU)" : "", best, s);
   return best;
 }
 
@@ -741,6 +742,9 @@ int main(int argc, char** argv) {
     run_ring3<2>(a, tiles, big, nbig); run_ring2<2>(a, tiles, big, nbig); run_ring2<4>(a, tiles, big, nbig);
     a.nsub = 4;
     run_ring3<2>(a, tiles, big, nbig); run_ring2<2>(a, tiles, big, nbig); run_ring2<4>(a, tiles, big, nbig);
+  } else if (suite == "occ") {
+    for (unsigned b : {0u, 36000u, 60000u}) { run<0>(a, tiles, host, b); run<2>(a, tiles, host, b); }
+    run_coal<0>(a, tiles, host); run_coal<1>(a, tiles, host);
   } else if (suite == "v2") {
     for (int sk : {0, 1, 2, 4, 8, 16, 3, 5, 6, 7, 11, 11 | 32, 64, 64 | 3, 64 | 11 | 32}) { a.skip = sk; run<2>(a, tiles, host); }
   } else if (suite == "coal") {

@@ -300,6 +300,10 @@ __device__ __forceinline__ void lpx_insert(float (&tv)[LPX_TOPK], int (&ti)[LPX_
 // (8 + 2(r-1))^2 window that can lie inside the circle, 64 keys per block, channels in stages of 32.
 // wave (w&1, w>>1) = 32 keys x 32 queries: ONE 32x32x2 MFMA tile (A = keys, B = queries), so a lane owns
 // 16 keys of one query; the four partial top-10 lists of a query (2 key halves x 2 lane halves) merge through LDS.
+// RAGGED = C % 32 != 0: the last channel stage is zero-filled lane by lane.  Otherwise every load is UNCONDITIONAL - rows past the
+// window / the map read a clamped (valid) row and their scores are masked below: the exec-mask branches and zero fills around
+// predicated loads cost 12-16 % of the stage loop (tools/probe_lp_stage.hip, V0 vs V2 at equal occupancy)
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a, int nsub) {
   constexpr int BQ = 64, BKEY = 64, BC = 32;
   __shared__ __attribute__((aligned(16))) float sK[BC / 2][BKEY][2];
@@ -366,7 +370,8 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a, 
     for (int kb = sub * cpb; kb < kb_end; ++kb) {
       const int kk = kb * BKEY + lrow;
       const bool k_ok = kk < nwin;
-      const int ky = wy0 + (k_ok ? kk / ww : 0), kx = wx0 + (k_ok ? kk % ww : 0);
+      const int kc = k_ok ? kk : nwin - 1;
+      const int ky = wy0 + kc / ww, kx = wx0 + kc % ww;
       const float* ksrc = a.fbank + ((size_t)slot * HW + (size_t)(ky * W + kx)) * C;
       if (lq == 0) sKC[lrow] = k_ok ? ((ky << 16) | kx) : -1;
       f32x4 rk[2], rq[2];
@@ -374,8 +379,13 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a, 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int c = st * BC + (lq + 4 * i) * 4;
-          rk[i] = (k_ok && c < C) ? ldf4(ksrc + c) : zerof4();
-          rq[i] = (lq_ok && c < C) ? ldf4(qsrc + c) : zerof4();
+          if (RAGGED) {
+            rk[i] = (k_ok && c < C) ? ldf4(ksrc + c) : zerof4();
+            rq[i] = (lq_ok && c < C) ? ldf4(qsrc + c) : zerof4();
+          } else {
+            rk[i] = ldf4(ksrc + c);
+            rq[i] = ldf4(qsrc + c);
+          }
         }
       };
       auto store = [&]() {
@@ -399,6 +409,14 @@ __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a, 
 #pragma unroll
         for (int s = 0; s < BC / 2; ++s)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[s][kh * 32 + li][lk], sQ[s][qh * 32 + li][lk], acc, 0, 0, 0);
+        // issue order: the operand reads of MFMA pair p+1 before the MFMAs of pair p (0x100 = DS read, 0x008 = MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int p = 0; p < BC / 4 - 2; ++p) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __syncthreads();
       }
       // scores -> circle mask -> streaming top-k: lane holds keys row(rg) = (rg&3) + 8*(rg>>2) + 4*lk of its query
@@ -520,7 +538,10 @@ int vfs_labelprop_f32_launch(const LabelPropF32Args& a, hipStream_t s) {
     nsub = max(1, min(nsub, LP_MAX_SPLIT / nsplit));
   }
   nsplit *= nsub;
-  hipLaunchKernelGGL(labelprop_f32_kernel, dim3(tiles, nsplit), dim3(256), 0, s, a, nsub);
+  if (a.C % 32)
+    hipLaunchKernelGGL(labelprop_f32_kernel<true>, dim3(tiles, nsplit), dim3(256), 0, s, a, nsub);
+  else
+    hipLaunchKernelGGL(labelprop_f32_kernel<false>, dim3(tiles, nsplit), dim3(256), 0, s, a, nsub);
   int rc = vfs_check_launch("labelprop_f32");
   if (rc) return rc;
   hipLaunchKernelGGL(labelprop_f32_merge_kernel, dim3((a.H * a.W + 255) / 256), dim3(256), 0, s, a, nsplit);
