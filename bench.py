@@ -2,7 +2,13 @@
 """Benchmark of the VFS training hot path on MI355X: frame-pairs/s of the SimSiam train step
 (forward_train + backward + SGD) on synthetic 256x256 clips.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: when the ranks are not there yet (no WORLD_SIZE in the environment) bench.py STARTS THEM ITSELF - it re-executes this
+command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL),
+the reference's tools/dist_train.sh:7-9 / apis/train.py:58-66 in one call; launched BY torch.distributed.run (the driver's
+form) it is a rank.  On a box with fewer than N devices the N ranks share cuda:0 ("shared-device" mode: gradients through gloo,
+SyncBN statistics through the IPC windows - a functional check of the N > 1 code path, NOT a scaling number; the JSON says so).
 
 One "step" = one pass of the hot path over one per-GPU batch: imgs [32, 2, 3, T, 256, 256].
 Default = the configuration BASELINE.json's metric is quoted on ("frame-pairs/sec (train) R50 256^2 at
@@ -39,6 +45,102 @@ WORK_PER_PAIR = {(50, 256): (64.2e9, 232e6), (50, 224): (49.2e9, 178e6), (50, 51
 
 def log(*a):
     print(f'[bench {time.strftime("%H:%M:%S")}]', *a, file=sys.stderr, flush=True)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without ranks: start N ranks of this very command (tools/dist_train.sh:7-9 of the reference does the same with
+    torch.distributed.launch).  Returns the launcher's exit code; rank 0's JSON line reaches stdout through the launcher."""
+    import subprocess
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL and the SyncBN windows between processes
+    if ndev < 1:
+        log(f'--gpus {args.gpus}: no GPU visible to this process')
+        return 2
+    if ndev < args.gpus:
+        log(f'--gpus {args.gpus} needs {args.gpus} devices, this box has {ndev}: running the {args.gpus} ranks in SHARED-DEVICE mode on '
+            'cuda:0 (gloo gradients staged through the host, SyncBN statistics through the IPC windows).  This exercises the N > 1 '
+            'code path; it is NOT a scaling measurement.')
+        env['VFS_BENCH_SHARED_DEVICE'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    log('starting the ranks:', ' '.join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def stage_cuda_collectives_through_host():
+    """shared-device mode only: RCCL refuses two ranks on one device, so the process group is gloo and its collectives on DEVICE
+    tensors (gradient buckets, the log values, broadcast of the initial weights) are staged through the host"""
+    orig_ar, orig_bc = dist.all_reduce, dist.broadcast
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if t.is_cuda:
+            h = t.detach().cpu()
+            orig_ar(h, op=op, group=group)
+            t.copy_(h)
+            return None
+        return orig_ar(t, op=op, group=group, async_op=async_op)
+
+    def broadcast(t, src=0, group=None, async_op=False):
+        if t.is_cuda:
+            h = t.detach().cpu()
+            orig_bc(h, src, group=group)
+            t.copy_(h)
+            return None
+        return orig_bc(t, src, group=group, async_op=async_op)
+    dist.all_reduce, dist.broadcast = all_reduce, broadcast
+
+
+# kernel name (prefix after "void ") -> bench.py's family label, for the committed rocprofv3 --stats CSV of the TIMED schedule
+KERNEL_FAMILY = (('conv_igemm_kernel', 'conv_igemm'), ('conv3x3_halo_kernel', 'conv3x3_halo'), ('stem_fwd_direct_kernel', 'stem_fwd'),
+                 ('conv_wgrad_kernel', 'conv_wgrad'), ('conv3x3_wgrad_halo_kernel', 'conv3x3_wgrad_halo'), ('stem_wgrad_fused_kernel', 'stem_wgrad'),
+                 ('wgrad_reduce_', 'wgrad_reduce'), ('bn_act_kernel', 'bn_act'), ('bn_bwd_apply_kernel', 'bn_bwd_apply'),
+                 ('bn_bwd_reduce_kernel', 'bn_bwd_reduce'), ('stem_pool_bn_bwd_reduce', 'bn_bwd_reduce'), ('bn_reduce_', 'bn_stats'),
+                 ('bn_stats_raw', 'bn_stats'), ('bn_finalize', 'bn_stats'), ('bn_relu_maxpool_kernel', 'bn_relu_maxpool'),
+                 ('pack_weights_kernel', 'pack_weights'), ('sgd_kernel', 'sgd'), ('labelprop_f32', 'labelprop_f32'),
+                 ('lp2_', 'labelprop_f32'), ('conv_f32_kernel', 'conv_f32'), ('seg_minmax_exact', 'seg_postprocess'),
+                 ('seg_argmax_exact', 'seg_postprocess'))
+
+
+def rocprof_families(tag):
+    """per-family kernel time of the TIMED schedule (command-tape replay, weight gradients on the side stream) from the committed
+    `rocprofv3 --kernel-trace --stats` summary of this command: profiles/<round>_<tag>_kernel_stats.csv + .meta.json
+    ({"passes": steps the profiled run executed, ...}; tools/gpu_evidence.sh writes both).  None when no summary is committed."""
+    import csv
+    import glob
+    cands = sorted(glob.glob(os.path.join(REPO, 'profiles', f'r[0-9][0-9]_{tag}_kernel_stats.csv')))
+    if not cands:
+        return None
+    path = cands[-1]
+    meta_path = path[:-4] + '.meta.json'
+    if not os.path.exists(meta_path):
+        return None
+    meta = json.load(open(meta_path))
+    passes = float(meta['passes'])
+    fams, total = {}, 0.0
+    for r in csv.DictReader(open(path)):
+        name = r['Name'].replace('void ', '')
+        fam = next((f for k, f in KERNEL_FAMILY if name.startswith(k)), None)
+        ns, calls = float(r['TotalDurationNs']), int(r['Calls'])
+        total += ns
+        if fam is None:
+            continue
+        a = fams.setdefault(fam, [0.0, 0])
+        a[0] += ns
+        a[1] += calls
+    return {'source': os.path.relpath(path, REPO), 'passes': passes, 'command': meta.get('command'),
+            'kernel_ms_per_pass_all': total / passes / 1e6,
+            'families': {f: {'kernel_ms_per_pass': v[0] / passes / 1e6, 'launches_per_pass': v[1] / passes, 'avg_launch_us': v[0] / v[1] / 1e3}
+                         for f, v in sorted(fams.items(), key=lambda kv: -kv[1][0])}}
 
 
 def cpu_baseline_subprocess(depth, size, threads, timeout=240):
@@ -200,16 +302,19 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
 
         # HBM bytes per launch from the committed PMC passes of this workload (tools/gpu_pmc.sh <model> davis + make_traffic_json.py)
         tclasses, tsource = {}, None
-        tpath = os.path.join(REPO, 'profiles', f'r03_traffic_davis_{args.model}.json')
-        if args.precision == 'fp32' and os.path.exists(tpath):
-            tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
+        for tag in ('r04', 'r03'):
+            tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_davis_{args.model}.json')
+            if args.precision == 'fp32' and os.path.exists(tpath):
+                tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
+                break
 
         def family(kind):
             fl, tm, cnt, nb = agg[kind]
             hbm_bound = nb / (PEAK_HBM_GBS * 1e9) >= fl / (peak * 1e12)
             ach, pk, unit = (nb / tm / 1e9, PEAK_HBM_GBS, 'GB/s') if hbm_bound else (fl / tm / 1e12, peak, 'TFLOP/s')
+            tr = tclasses.get(kind, {}).get('hbm_bytes_per_launch')
             return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': pk, 'unit': unit, 'frac': ach / pk,
-                    'traffic': tclasses.get(kind, {}).get('hbm_bytes_per_launch'), 'launches': cnt, 'avg_launch_ms': tm / cnt * 1e3, 'time_share_of_kernels': tm / tot,
+                    'traffic': tr, 'traffic_ratio': (tr / (nb / cnt)) if (tr and nb) else None, 'launches': cnt, 'avg_launch_ms': tm / cnt * 1e3, 'time_share_of_kernels': tm / tot,
                     'algorithmic_flop_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
         kind = max(agg, key=lambda k: agg[k][1])
         res['roofline'] = family(kind)
@@ -249,12 +354,24 @@ def main():
     ap.add_argument('--no-davis', action='store_true', help='train workload: skip the DAVIS leg appended to the JSON line (N = 1 only)')
     ap.add_argument('--davis-frames', type=int, default=30, help='propagated frames of the appended DAVIS leg')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--min-seconds', type=float, default=0.0,
+                    help='make the timed region at least this long: the number of timed steps is raised to ceil(min_seconds / step time) '
+                         '(a lease-side GPU-busy monitor sampling every few seconds can then corroborate the figure); the JSON reports '
+                         'the steps actually timed')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:      # no ranks yet: start them (the reference's tools/dist_train.sh in one call)
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        log(f'--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus {args.gpus}` without a launcher (it starts the ranks '
+            f'itself), or launch {args.gpus} ranks')
+        sys.exit(2)
+    shared_dev = world > 1 and os.environ.get('VFS_BENCH_SHARED_DEVICE') == '1'      # more ranks than devices: every rank on cuda:0
+    if shared_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     force_coll = os.environ.get('VFS_FORCE_COLLECTIVES') == '1'   # 1-rank RCCL group: exercises the collective calls
@@ -262,7 +379,11 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        if shared_dev:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            stage_cuda_collectives_through_host()
+        else:
+            dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     import vfs_amd
     from vfs_amd.engine import shared_engine
@@ -350,6 +471,11 @@ def main():
     import gc
     gc.collect()           # benchmark hygiene: no full collection of the warm-up's garbage inside the timed region
     gc.freeze()
+    if args.min_seconds > 0:
+        import math
+        est, _ = timed(3)                                        # untimed estimate (max over the ranks: every rank gets the same count)
+        args.steps = max(args.steps, int(math.ceil(args.min_seconds / (est / 3))))
+        log(f'--min-seconds {args.min_seconds}: timing {args.steps} steps')
     dt, out = timed(args.steps)
     log(f'{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step')
     if phases is not None:
@@ -397,6 +523,33 @@ def main():
                         else 'command-tape replay (recorded C-ABI calls + stream waits / collectives)' if os.environ.get('VFS_TAPE', '1') == '1'
                         else 'eager'),
     }
+    if world > 1 or force_coll:
+        # how the N ranks talk: collective backend, how the SyncBN statistics travelled, what a gradient bucket costs
+        bucket = int(model.grad_bucket_bytes)
+        g = flat['grads']
+        n = min(g.numel(), max(1, bucket // 4))
+        times = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            dist.all_reduce(g[:n])
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        g.zero_()
+        res['distributed'] = {
+            'ranks': world, 'devices_visible': torch.cuda.device_count(),
+            'collective_backend': 'gloo, device tensors staged through the host (shared-device mode)' if shared_dev else 'nccl (RCCL)',
+            'shared_device': bool(shared_dev),
+            'syncbn_statistics': 'IPC-window exchange (csrc/p2p.hip)' if eng._p2p is not None else 'collective-library all-reduce',
+            'syncbn_exchanges': int(eng._p2p.state[0].item()) if eng._p2p is not None else 0,
+            'gradient_bytes': int(g.numel()) * 4, 'gradient_bucket_bytes': bucket,
+            'allreduce_ms_per_bucket': {'bytes': n * 4, 'min': min(times), 'median': sorted(times)[len(times) // 2],
+                                        'note': 'blocking all-reduce of one bucket on an idle GPU, host-timed; in the step the buckets '
+                                                'overlap the backward chain'}}
+        if shared_dev:
+            res['config']['parallelism'] = (f'dp{world}: {world} ranks SHARING one device (functional check of the N > 1 code path, '
+                                            'not a scaling measurement)')
     if rank == 0 and prof:
         agg = {}
         for kind, flops, e0, e1, nbytes in prof:
@@ -408,7 +561,7 @@ def main():
         # HBM bytes per launch of every family from the committed PMC passes (tools/gpu_pmc.sh + make_traffic_json.py:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as the guide prescribes for gfx950)
         tclasses, tsource = {}, None
-        for tag in ('r03', 'r02', 'r01'):
+        for tag in ('r04', 'r03', 'r02', 'r01'):
             tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_{args.model}.json')
             if os.path.exists(tpath):
                 tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
@@ -439,6 +592,21 @@ def main():
         res['roofline']['families'] = [family(k) for k in fams if agg[k][1] / dt_prof >= 0.03]
         res['roofline']['small_families_time_share'] = sum(agg[k][1] for k in fams if agg[k][1] / dt_prof < 0.03) / dt_prof
         res['roofline']['unlabelled_time_share'] = max(0.0, 1.0 - sum(v[1] for v in agg.values()) / dt_prof)
+        # the same families on the schedule that was TIMED (tape replay, two streams): the committed rocprofv3 --stats summary of
+        # this command, when the round has one; `live_over_rocprof` = this run's eager event time / that summary's kernel time
+        rp = rocprof_families(f'bench_{args.model}')
+        if rp is not None:
+            for f, v in rp['families'].items():
+                if f in agg:
+                    v['live_over_rocprof'] = (agg[f][1] / args.steps * 1e3) / v['kernel_ms_per_pass']
+                    nb, fl = agg[f][3] / args.steps, agg[f][0] / args.steps
+                    v['GB/s'], v['TFLOP/s'] = nb / v['kernel_ms_per_pass'] / 1e6, fl / v['kernel_ms_per_pass'] / 1e9
+            res['roofline']['rocprof_timed_schedule'] = rp
+        # step-level HBM traffic of the committed PMC passes (every kernel of one step) for step_roofline below
+        if tsource:
+            per_pass = json.load(open(os.path.join(REPO, tsource))).get('step_total_bytes')
+            if per_pass:
+                res['roofline']['step_traffic'] = {'hbm_bytes_per_step': per_pass, 'source': tsource}
     work = WORK_PER_PAIR.get((depth, args.size))
     if rank == 0 and work:
         # step level: algorithmic FLOP (3 x forward) and ideal-fusion bytes per frame-pair
@@ -446,6 +614,12 @@ def main():
         res['step_roofline'] = {'flop_per_pair': work[0], 'ideal_bytes_per_pair': work[1], 'TFLOP/s_per_gpu': pps * work[0] / 1e12,
                                 'frac_of_mfma_peak': pps * work[0] / 1e12 / PEAK_BF16_TFLOPS, 'GB/s_per_gpu': pps * work[1] / 1e9,
                                 'frac_of_hbm_peak': pps * work[1] / 1e9 / PEAK_HBM_GBS}
+        st = res.get('roofline', {}).get('step_traffic')
+        if st:      # PMC bytes of one step / ideal-fusion bytes of one step, and the rate those bytes moved at in the timed step
+            ideal = work[1] * pairs_per_step / world
+            res['step_roofline'].update({'traffic_bytes_per_step': st['hbm_bytes_per_step'], 'ideal_bytes_per_step': ideal,
+                                         'traffic_ratio': st['hbm_bytes_per_step'] / ideal,
+                                         'moved_TB/s': st['hbm_bytes_per_step'] / (dt / args.steps) / 1e12})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample) ...')
         res['cpu_baseline'] = cpu_baseline_subprocess(depth, args.size, min(os.cpu_count() or 1, 64))

@@ -299,8 +299,11 @@ int vfs_p2p_allreduce_f64(double* buf, int n, const void* peers, int rank, int w
                           long long spin_limit, vfs_stream_t stream);
 
 /* ---- optimizer: torch.optim.SGD(lr, momentum, weight_decay) (configs/r*_*.py:134) on flat arenas --- */
+/* skip_flag: NULL, or a device word (8 bytes) read when the kernel RUNS: non-zero -> the step changes nothing.  The trackers pass
+ * the error word of the SyncBN window exchange (vfs_p2p_allreduce_f64's state[1]): a step whose statistics were poisoned by a
+ * peer that never arrived must not reach the weights or the momentum (the host learns of it with the step's log values). */
 int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
-                 float momentum, float weight_decay, vfs_stream_t stream);
+                 float momentum, float weight_decay, const void* skip_flag, vfs_stream_t stream);
 int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream);
 /* bf16 gradient buckets for the data-parallel all-reduce (opt-in, VFS_GRAD_BF16=1; the reference's DDP - apis/train.py:62-66 -
  * reduces fp32): dst = bf16(src * scale) before the collective, dst = float(src) after it; buffers 16-byte aligned */
@@ -316,11 +319,12 @@ int vfs_l2norm_rows(const vfs_bf16* x, vfs_bf16* y, long long P, int C, vfs_stre
  * fp32; key frames kslot[0..nkeys) in the reference's order (first frame first, duplicates
  * allowed); out [H*W][CO].  radius = neighbor_range // 2 (<= 0: no mask), the first non_mask_len
  * key frames are never masked (test_cfg.with_first_neighbor=False -> 1), topk <= 10, nkeys <= 64,
- * C % 64 == 0.  workspace: vfs_labelprop_workspace_bytes (= 96*H*W*10*8: per-split partial top-k lists - key frames,
+ * C % 64 == 0.  workspace: at least vfs_labelprop_workspace_bytes(H, W) bytes (per-split partial top-k lists - key frames,
  * and for vfs_labelprop_f32 the 64-key blocks of a frame's window as well, are split over workgroups because a DAVIS
- * frame has only 8x14 query tiles) */
+ * frame has only 8x14 query tiles); workspace_bytes = what the caller allocated: a smaller buffer is REFUSED
+ * (VFS_ERR_ARG) instead of written past (the size grew between library versions - ABI version 2) */
 int vfs_labelprop_workspace_bytes(int H, int W, long long* bytes);
-int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe,
+int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, long long workspace_bytes, int qframe,
                   const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len,
                   int topk, float temperature, vfs_stream_t stream);
 /* bilinear upsample (align_corners=False) + per-channel min-max normalisation where max > 0 +
@@ -360,9 +364,9 @@ int vfs_l2norm_rows_f32(const float* x, float* y, long long P, int C, vfs_stream
 /* vfs_labelprop on an fp32 bank: score = chain(key . query) / temperature, top-k by (score desc, candidate id asc) with
  * id = key_position * H*W + pixel, softmax weights exp(s - s_max) / sum in sorted order; the first non_mask_len key
  * frames are not masked (test_cfg.with_first_neighbor=False -> 1, local_attention.py:303-309); workspace as vfs_labelprop */
-int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot,
-                      int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature,
-                      vfs_stream_t stream);
+int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, long long workspace_bytes, int qframe,
+                      const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len, int topk,
+                      float temperature, vfs_stream_t stream);
 /* F.interpolate(mode='bilinear', align_corners=False) of a C-channel fp32 map between layouts (NCHW [C][H][W] or NHWC
  * [H][W][C], chosen per side): one-hot reference maps -> feature resolution, soft label maps -> original resolution
  * (vanilla_tracker.py:101-111,162-166 when ref_seg_map is 4-D) */

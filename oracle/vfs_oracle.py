@@ -73,6 +73,29 @@ def _act_round(x, on):
     return _RoundBoth.apply(x) if on else x
 
 
+class _BNGivenStats(torch.autograd.Function):
+    """y = gamma * (x - mean) * invstd + beta with GIVEN batch statistics; backward = the batch-norm formula evaluated with x^ from
+    x and those statistics.  bf16-storage emulation only: the HIP engine takes the statistics of most conv outputs from the GEMM
+    epilogue's fp32 accumulators (vfs_amd/engine.py conv_fwd: `fused` rows) and normalises the bf16-STORED tensor with them."""
+
+    @staticmethod
+    def forward(ctx, x, mean, invstd, gamma, beta):
+        sh = [1, -1] + [1] * (x.dim() - 2)
+        xh = (x - mean.view(sh)) * invstd.view(sh)
+        ctx.save_for_backward(xh, invstd, gamma)
+        return xh * gamma.view(sh) + beta.view(sh)
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, invstd, gamma = ctx.saved_tensors
+        dims = [0] + list(range(2, g.dim()))
+        sh = [1, -1] + [1] * (g.dim() - 2)
+        n = g.numel() / g.shape[1]
+        sg, sgx = g.sum(dims), (g * xh).sum(dims)
+        dx = (gamma * invstd).view(sh) * (g - (sg / n).view(sh) - xh * (sgx / n).view(sh))
+        return dx, None, None, sgx, sg
+
+
 def _w_round(w, on):
     return _RoundFwd.apply(w) if on else w
 
@@ -93,6 +116,10 @@ class ConvBN(nn.Module):
         self.bn = nn.BatchNorm2d(cout)  # eps 1e-5, momentum 0.1 (torch defaults, as mmcv)
         self.relu = relu
         self.emulate_bf16 = False
+        # where the bf16-storage emulation takes the batch statistics from (one of several equally valid DRAWS of the rounding
+        # noise, tests/test_cfg1_golden.py): 'stored' = the rounded conv output; 'engine' = the fp32 accumulators where the HIP
+        # engine has them (rows per BatchNorm batch % 128 == 0 or > 2048), the stored output elsewhere; 'acc' = accumulators always
+        self.emulate_stats = 'stored'
         # mmcv ConvModule ctor: kaiming_init(conv) + constant_init(bn, 1)
         nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
         nn.init.constant_(self.bn.weight, 1)
@@ -107,9 +134,26 @@ class ConvBN(nn.Module):
         y = F.conv2d(x, _w_round(self.conv.weight, e), None, self.conv.stride, self.conv.padding, self.conv.dilation)
         return _act_round(y, e)
 
+    def raw_bn(self, x):
+        """bn(raw(x)); with emulate_stats != 'stored' (bf16 emulation, training) the batch statistics come from the UNROUNDED conv
+        output while the rounded one is normalised (running statistics are not updated in that mode: gradient studies only)"""
+        e = self.emulate_bf16
+        if not (e and self.bn.training and self.emulate_stats != 'stored'):
+            return self.bn(self.raw(x))
+        yu = F.conv2d(x, _w_round(self.conv.weight, e), None, self.conv.stride, self.conv.padding, self.conv.dilation)
+        yr = _act_round(yu, e)
+        rows = yu.shape[0] * yu.shape[2] * yu.shape[3]
+        if self.emulate_stats == 'engine' and not (rows % 128 == 0 or rows > 2048):
+            return self.bn(yr)
+        with torch.no_grad():
+            d = yu.detach().double()
+            mean, var = d.mean([0, 2, 3]), d.var([0, 2, 3], unbiased=False)
+            invstd = (1.0 / torch.sqrt(var + self.bn.eps)).float()
+        return _BNGivenStats.apply(yr, mean.float(), invstd, self.bn.weight, self.bn.bias)
+
     def forward(self, x, residual=None):
         e = self.emulate_bf16
-        y = self.bn(self.raw(x))
+        y = self.raw_bn(x)
         if residual is not None:
             y = y + residual
         if self.relu or residual is not None:
@@ -119,7 +163,7 @@ class ConvBN(nn.Module):
     def forward_noact(self, x):
         """conv -> bn without rounding/activation (downsample branch: the HIP
         path keeps the raw conv output and applies this BN inside the consumer)."""
-        return self.bn(self.raw(x))
+        return self.raw_bn(x)
 
 
 class BasicBlock(nn.Module):
@@ -333,10 +377,13 @@ class SimSiamTracker(nn.Module):
         self.intra_video = intra_video
         self.register_buffer('iteration', torch.tensor(0, dtype=torch.float))  # base.py:39
 
-    def set_emulate_bf16(self, on=True):
+    def set_emulate_bf16(self, on=True, stats='stored'):
+        assert stats in ('stored', 'engine', 'acc')
         for m in self.modules():
             if hasattr(m, 'emulate_bf16'):
                 m.emulate_bf16 = on
+            if hasattr(m, 'emulate_stats'):
+                m.emulate_stats = stats
         return self
 
     def forward_img_head(self, x1, x2, clip_len):                # sim_siam_base_tracker.py:31-56

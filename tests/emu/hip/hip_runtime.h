@@ -52,6 +52,7 @@ struct hipIpcMemHandle_t { char reserved[64]; };
 static const unsigned hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1;
 inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 2; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h, &p, sizeof(p)); return hipSuccess; }
 inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, &h, sizeof(*p)); return hipSuccess; }

@@ -203,8 +203,14 @@ def test_avgpool_bias_loss_sgd(backend):
         gr = torch.randn(n, generator=g)
         pr.grad = gr.clone()
         opt.step()
-        lib.sgd_step(p, gr, buf, n, 0.05, 0.9, 1e-4, None)
+        lib.sgd_step(p, gr, buf, n, 0.05, 0.9, 1e-4, None, None)
     assert relerr(p, pr.detach()) < 1e-6
+    # the device-side guard: a non-zero skip word (the SyncBN exchange's error flag) leaves weights and momentum untouched
+    before, bbefore = p.clone(), buf.clone()
+    lib.sgd_step(p, gr, buf, n, 0.05, 0.9, 1e-4, torch.ones(1, dtype=torch.int64, device=p.device), None)
+    assert torch.equal(p, before) and torch.equal(buf, bbefore)
+    lib.sgd_step(p, gr, buf, n, 0.05, 0.9, 1e-4, torch.zeros(1, dtype=torch.int64, device=p.device), None)
+    assert not torch.equal(p, before)
 
 
 def test_bn_reduce_partials_two_stage(backend):

@@ -31,7 +31,7 @@ def run_labelprop_case(be, T, H, W, C, CO, radius, slots, qframe, topk=10, seed=
     out = torch.full((H * W, CO), float('nan'))
     ks = (ctypes.c_int * len(slots))(*slots)
     ws = torch.zeros(96 * H * W * 10 * 2)       # vfs_labelprop_workspace_bytes
-    lib.labelprop(fb, seg, out, ws, qframe, ks, len(slots), H, W, C, CO, radius, 0, topk, 0.07, None)
+    lib.labelprop(fb, seg, out, ws, ws.numel() * ws.element_size(), qframe, ks, len(slots), H, W, C, CO, radius, 0, topk, 0.07, None)
     # oracle on the SAME normalised bf16 features (normalize=False), reference tensor layout, fp64
     fn = fb.double()
     q = fn[qframe].t().reshape(1, C, H, W)

@@ -134,7 +134,7 @@ def run_labelprop_f32(be, T, H, W, C, CO, radius, slots, qframe, topk=10, non_ma
     out = torch.full((H * W, CO), float('nan'))
     ks = (ctypes.c_int * len(slots))(*slots)
     ws = torch.zeros(lp_workspace_floats(lib, H, W))
-    lib.labelprop_f32(fb, seg, out, ws, qframe, ks, len(slots), H, W, C, CO, radius, non_mask_len, topk, 0.07, None)
+    lib.labelprop_f32(fb, seg, out, ws, ws.numel() * ws.element_size(), qframe, ks, len(slots), H, W, C, CO, radius, non_mask_len, topk, 0.07, None)
     want = X.labelprop(fb.numpy(), seg.numpy(), qframe, slots, H, W, radius, topk, 0.07, non_mask_len=non_mask_len)
     assert same_bits(out.numpy(), want), float(np.abs(out.numpy() - want).max())
     return fb, seg, out

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     protos = _lib.parse_header()
     assert len(protos) >= 25 and 'vfs_conv_fwd' in protos and 'vfs_last_error' in protos
     lib = _lib.VfsLib(path)                     # resolves every prototype or raises
-    assert lib.dll.vfs_abi_version() == 1
+    assert lib.dll.vfs_abi_version() == 2
     import subprocess
     syms = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout
     for name in protos:

@@ -69,6 +69,43 @@ def test_protocol_two_threads_emulator(emu_backend):
     lone = torch.ones(4, dtype=torch.float64)
     lib.p2p_allreduce_f64(lone, 4, peers, 0, world, states[0], 3, 1000, None)
     assert int(states[0][1]) == 1
+    assert torch.isnan(lone).all()      # the sums of a failed exchange are poisoned, not left as plausible garbage
+    for w in wins:
+        lib.p2p_free(w)
+
+
+def test_protocol_eight_threads_emulator(emu_backend):
+    """the largest configuration the windows hold: 8 ranks (P2P_MAXW) x 8192 doubles (P2P_MAXN), more exchanges than ring slots,
+    every rank's result bit-equal to the rank-ordered sum"""
+    lib = emu_backend.lib
+    world = 8
+    wins, mapped = _windows(lib, world)
+    peers = torch.tensor(mapped, dtype=torch.int64)
+    sizes = [8192, 1, 8192, 4097, 8192, 63, 8192]
+    g = torch.Generator().manual_seed(8)
+    data = [[torch.randn(n, generator=g, dtype=torch.float64) for n in sizes] for _ in range(world)]
+    results = [[None] * len(sizes) for _ in range(world)]
+    states = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+
+    def rank_main(r):
+        for k, n in enumerate(sizes):
+            t = data[r][k].clone()
+            lib.p2p_allreduce_f64(t, n, peers, r, world, states[r], 3, 1 << 40, None)
+            results[r][k] = t
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for k in range(len(sizes)):
+        want = data[0][k].clone()
+        for r in range(1, world):
+            want = want + data[r][k]
+        for r in range(world):
+            assert torch.equal(results[r][k], want), (r, k)
+    for st in states:
+        assert int(st[0]) == len(sizes) and int(st[1]) == 0
     for w in wins:
         lib.p2p_free(w)
 

@@ -79,10 +79,10 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lp = eng.lib.labelprop_f32 if args.precision == 'fp32' else eng.lib.labelprop
     for _ in range(2):
-        lp(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
+        lp(bank, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
     e0.record()
     for _ in range(5):
-        lp(bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
+        lp(bank, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks, len(slots), h, w, C, CO, radius, 0, 10, 0.07, s)
     e1.record()
     torch.cuda.synchronize()
     t_lp = e0.elapsed_time(e1) / 5 * 1e-3

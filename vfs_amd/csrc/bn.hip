@@ -67,6 +67,14 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const TIN* __restri
   if (x.peers) bn_xchg_tail(x, out, (int)(gridDim.y * 2 * C), gridDim.x * gridDim.y);      // (only launched with nchunks == 1: out = sums)
 }
 
+// running = (1 - momentum) * running + momentum * statistic (unbiased variance).  A NaN statistic - the poison a failed SyncBN
+// window exchange writes into its sums (vfs_p2p.h) - must not reach the running statistics: they outlive the step (checkpoints).
+__device__ __forceinline__ void bn_running_update(float& rm, float& rv, float momentum, double mean, double unbiased) {
+  if (mean != mean || unbiased != unbiased) return;
+  rm = (1.f - momentum) * rm + momentum * (float)mean;
+  rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+}
+
 // sums[G][2][C] (sum x, sum x^2; already all-reduced across ranks for SyncBN) + count ->
 // bnp, and the running statistics updated group after group (each group is one BN call of the
 // reference: running = (1-momentum)*running + momentum*stat, unbiased variance).
@@ -89,8 +97,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     o[2 * C + c] = (float)mean;
     o[3 * C + c] = invstd;
     const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    rm = (1.f - momentum) * rm + momentum * (float)mean;
-    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    bn_running_update(rm, rv, momentum, mean, unbiased);
   }
   if (running_mean) running_mean[c] = rm;
   if (running_var) running_var[c] = rv;
@@ -143,8 +150,7 @@ __global__ __launch_bounds__(256) void bn_reduce_fused_kernel(const TIN* __restr
         o[2 * C + c] = (float)mean;
         o[3 * C + c] = invstd;
         const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        rm = (1.f - momentum) * rm + momentum * (float)mean;
-        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+        bn_running_update(rm, rv, momentum, mean, unbiased);
       } else {
         g1 += r0; g2 += r1;
       }
@@ -204,8 +210,7 @@ __global__ __launch_bounds__(256) void bn_stats_raw_kernel(const bf16_t* __restr
       o[2 * C + c] = (float)mean;
       o[3 * C + c] = invstd;
       const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-      rm = (1.f - momentum) * rm + momentum * (float)mean;
-      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      bn_running_update(rm, rv, momentum, mean, unbiased);
     }
   }
   if (sl == 0 && c < C) {
@@ -320,8 +325,7 @@ __global__ __launch_bounds__(256) void bn_reduce_ticket_kernel(const float* __re
         o[2 * C + c] = (float)mean;
         o[3 * C + c] = invstd;
         const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        rm = (1.f - momentum) * rm + momentum * (float)mean;
-        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+        bn_running_update(rm, rv, momentum, mean, unbiased);
       } else if (MODE == 1) {
         g1 += r0; g2 += r1;
       }
@@ -480,8 +484,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
             f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
           }
           const double unbiased = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
-          rm = (1.f - f.momentum) * rm + f.momentum * (float)mean;
-          rv = (1.f - f.momentum) * rv + f.momentum * (float)unbiased;
+          bn_running_update(rm, rv, f.momentum, mean, unbiased);
         }
       }
     }

@@ -43,7 +43,7 @@ static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, in
 extern "C" {
 
 const char* vfs_last_error(void) { return g_err; }
-int vfs_abi_version(void) { return 1; }
+int vfs_abi_version(void) { return 2; }      // 2: vfs_sgd_step(skip_flag), vfs_labelprop*(workspace_bytes)
 int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo")) { vfs_option_halo = value; return VFS_OK; }
   if (!strcmp(name, "halo_min_fill")) { vfs_option_halo_min_fill = value; return VFS_OK; }
@@ -507,8 +507,8 @@ int vfs_simloss_norm_bwd(const float* x, const float* inv, const float* d, float
 }
 
 int vfs_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
-                 float weight_decay, vfs_stream_t stream) {
-  return vfs_sgd_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, S(stream));
+                 float weight_decay, const void* skip_flag, vfs_stream_t stream) {
+  return vfs_sgd_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, static_cast<const unsigned long long*>(skip_flag), S(stream));
 }
 int vfs_scale(float* x, long long n, float scale, vfs_stream_t stream) { return vfs_scale_launch(x, n, scale, S(stream)); }
 int vfs_f32_to_bf16(const float* src, vfs_bf16* dst, long long n, float scale, vfs_stream_t stream) {
@@ -524,9 +524,17 @@ int vfs_labelprop_workspace_bytes(int H, int W, long long* bytes) {
   *bytes = (long long)LP_MAX_SPLIT * H * W * 10 * 8;
   return VFS_OK;
 }
-int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
-                  int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {
+static int lp_workspace_ok(const void* workspace, long long workspace_bytes, int H, int W) {
+  long long need = 0;
+  if (vfs_labelprop_workspace_bytes(H, W, &need) != VFS_OK) return 0;
+  return workspace != nullptr && workspace_bytes >= need;
+}
+int vfs_labelprop(const vfs_bf16* fbank, const float* sbank, float* out, void* workspace, long long workspace_bytes, int qframe,
+                  const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature,
+                  vfs_stream_t stream) {
   if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop: 1 <= nkeys <= 64");
+  if (!lp_workspace_ok(workspace, workspace_bytes, H, W))
+    return vfs_set_error(VFS_ERR_ARG, "labelprop: workspace smaller than vfs_labelprop_workspace_bytes(H, W)");
   if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop: 0 <= non_mask_len < nkeys");
   LabelPropArgs a;
   a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;
@@ -564,9 +572,12 @@ int vfs_maxpool_f32(const float* x, float* y, int N, int H, int W, int C, int Ho
 int vfs_l2norm_rows_f32(const float* x, float* y, long long P, int C, vfs_stream_t stream) {
   return vfs_l2norm_rows_f32_launch(x, y, P, C, S(stream));
 }
-int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, int qframe, const int* kslot, int nkeys,
-                      int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature, vfs_stream_t stream) {
+int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, long long workspace_bytes, int qframe,
+                      const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len, int topk, float temperature,
+                      vfs_stream_t stream) {
   if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32: 1 <= nkeys <= 64");
+  if (!lp_workspace_ok(workspace, workspace_bytes, H, W))
+    return vfs_set_error(VFS_ERR_ARG, "labelprop_f32: workspace smaller than vfs_labelprop_workspace_bytes(H, W)");
   if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32: 0 <= non_mask_len < nkeys");
   LabelPropF32Args a;
   a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;

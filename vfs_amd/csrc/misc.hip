@@ -312,7 +312,9 @@ int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s) {
 // torch.optim.SGD (configs/*:134): g += wd*p ; buf = momentum*buf + g ; p -= lr*buf
 // (a zero-initialised buf reproduces torch's "buf = g" on the first step)
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  long long n, float lr, float momentum, float wd) {
+                                                  long long n, float lr, float momentum, float wd,
+                                                  const unsigned long long* __restrict__ skip) {
+  if (skip && *skip) return;      // a poisoned step (failed SyncBN exchange, vfs_p2p.h) leaves weights and momentum alone
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
@@ -334,9 +336,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     p[i] -= lr * buf[i];
   }
 }
-int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, hipStream_t s) {
+int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, const unsigned long long* skip,
+                   hipStream_t s) {
   long long b = ((n >> 2) + 255) / 256;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd);
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, skip);
   return vfs_check_launch("sgd");
 }
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ p, long long n, float scale) {

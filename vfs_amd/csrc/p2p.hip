@@ -41,7 +41,12 @@ int vfs_p2p_alloc_host(void** ptr) {
   // fine-grained: stores from a peer (another process, another GPU) become visible to a RUNNING kernel of this one
   if (hipExtMallocWithFlags(&p, p2p_window_bytes(), hipDeviceMallocFinegrained) != hipSuccess || !p)
     return vfs_set_error(VFS_ERR_LAUNCH, "p2p_alloc: hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed");
-  if (hipMemset(p, 0, p2p_window_bytes()) != hipSuccess) return vfs_set_error(VFS_ERR_LAUNCH, "p2p_alloc: hipMemset failed");
+  // the zero fill must have LANDED before the handle leaves this process: hipMemset is asynchronous, and a peer's first push
+  // arriving before it would have its flag or data cleared (time-out in the self-test -> silent fall-back for the whole run)
+  if (hipMemset(p, 0, p2p_window_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(p);
+    return vfs_set_error(VFS_ERR_LAUNCH, "p2p_alloc: hipMemset / hipDeviceSynchronize failed");
+  }
   *ptr = p;
   return VFS_OK;
 }

@@ -42,11 +42,12 @@ struct SimFwdArgs {
 // tile (linear) and reduce it to one number each; partial[b][tile] = the four numbers added in wave order
 __global__ __launch_bounds__(256) void simloss_pair_fwd_kernel(SimFwdArgs p) {
   __shared__ float red[4];
-  const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  // diagonal mode (pairwise = 0): the grid holds the DIAGONAL tiles only (gridDim.x == 1, j0 = i0)
+  const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = p.pairwise ? blockIdx.x * 32 : i0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
   const int tile = blockIdx.y * gridDim.x + blockIdx.x;
   float tot = 0.f;
-  if (p.pairwise || i0 == j0) {      // (diagonal mode: off-diagonal tiles contribute nothing)
+  {
     const float* ab = p.a + (size_t)b * p.C * p.Sa;
     const float* lb = p.l + (size_t)b * p.C * p.Sl;
     const bool va = i0 + li < p.Sa, vl = j0 + li < p.Sl;
@@ -170,11 +171,14 @@ int vfs_simloss_fwd_launch(const float* a, const float* l, const float* inva, co
   SimFwdArgs p;
   p.a = a; p.l = l; p.inva = inva; p.invl = invl; p.mask = mask; p.partial = partial; p.C = C; p.Sa = Sa; p.Sl = Sl; p.pairwise = pairwise;
   const int ti = (Sa + 31) / 32, tj = (Sl + 31) / 32;
-  hipLaunchKernelGGL(simloss_pair_fwd_kernel, dim3(tj, ti, B), dim3(256), 0, s, p);
+  // diagonal mode: only the ti diagonal tiles exist (the full ti x tj grid was ~98x the work at S = 56 * 56, and the finish kernel
+  // walked ti * tj partials per sample)
+  const int gx = pairwise ? tj : 1;
+  hipLaunchKernelGGL(simloss_pair_fwd_kernel, dim3(gx, ti, B), dim3(256), 0, s, p);
   int rc = vfs_check_launch("simloss_pair_fwd");
   if (rc) return rc;
   const double count = pairwise ? (double)Sa * Sl : (double)Sa;
-  hipLaunchKernelGGL(simloss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)partial, loss, B, ti * tj, count, negative, weight);
+  hipLaunchKernelGGL(simloss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)partial, loss, B, ti * gx, count, negative, weight);
   return vfs_check_launch("simloss_finish");
 }
 

@@ -208,7 +208,8 @@ int vfs_loss_means_launch(const float* loss, float* means, int K, int N, hipStre
 int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);
 
 // fused SGD over the flat parameter arena (torch.optim.SGD, dampening 0, no nesterov)
-int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, hipStream_t s);
+int vfs_sgd_launch(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, const unsigned long long* skip,
+                   hipStream_t s);
 int vfs_scale_launch(float* p, long long n, float scale, hipStream_t s);
 int vfs_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, float scale, hipStream_t s);
 int vfs_bf16_to_f32_launch(const bf16_t* src, float* dst, long long n, hipStream_t s);

@@ -64,6 +64,10 @@ __device__ __forceinline__ void p2p_exchange_body(double* __restrict__ buf, int 
       }
     }
     __syncthreads();
+    // a peer that never arrived: the sums are POISONED with NaN instead of left as garbage - the statistics, the loss and
+    // every gradient of the step become NaN (visible), NaN statistics are kept out of the running statistics (bn.hip) and
+    // the guarded optimizer step (vfs_sgd_step's skip word = state[1]) leaves the weights alone
+    const bool poisoned = *s_failed != 0;
     if (world > 1) {
       const double* src = p2p_data(peers[rank]) + (size_t)slot * P2P_MAXW * P2P_MAXN;
       for (int base = tid; base < n; base += 256 * PB) {
@@ -83,7 +87,7 @@ __device__ __forceinline__ void p2p_exchange_body(double* __restrict__ buf, int 
 #pragma unroll
           for (int q = 1; q < P2P_MAXW; ++q)
             if (q < world) acc += v[q][j];
-          buf[i] = acc;
+          buf[i] = poisoned ? __builtin_nan("") : acc;
         }
       }
     }

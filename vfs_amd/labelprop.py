@@ -199,7 +199,7 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
             nmask = len(slots) - non_mask_len
             work = (2.0 * C * (nmask * pairs + non_mask_len * float(h * w) ** 2),          # in-mask affinity FLOP
                     float(bank.element_size()) * (len(set(slots)) + 1) * h * w * C)         # every key / query row once
-            eng.timed('labelprop_f32' if exact else 'labelprop', work, dev, lp, bank, sbank, sbank[f], lpws, f, ks, len(slots), h, w,
+            eng.timed('labelprop_f32' if exact else 'labelprop', work, dev, lp, bank, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks, len(slots), h, w,
                       C, CO, radius, non_mask_len, topk, temp, s)
             if input_onehot:
                 eng.lib.bilinear_resize_f32(sbank[f], preds[f], CO, h, w, out_h, out_w, 1, 0, s)

@@ -57,9 +57,13 @@ class SGD(torch.optim.Optimizer):
         grp = self.param_groups[0]
         eng = shared_engine()
         bump_params_epoch()      # raw-pointer update: caches derived from the parameters (vfs_amd/exact.py) must refresh
+        # data parallel with the SyncBN window exchange: its error word gates the update on the device (a peer that never arrived
+        # poisons the step's statistics with NaN; the host only learns of it when it reads the log values)
+        x = eng._p2p
+        skip = x.state[1:2] if x is not None and x.state.device == flat.device else None
         for lo, hi in segs:
             eng.timed('sgd', (0.0, 20.0 * (hi - lo)), flat.device, eng.lib.sgd_step, flat[lo:hi], g[lo:hi], self._buf[lo:hi], hi - lo,
-                      float(grp['lr']), float(grp['momentum']), float(grp['weight_decay']), eng.stream(flat.device))
+                      float(grp['lr']), float(grp['momentum']), float(grp['weight_decay']), skip, eng.stream(flat.device))
 
     def load_state_dict(self, state_dict):
         """torch's loader replaces the state tensors by copies: put them back into the momentum arena"""

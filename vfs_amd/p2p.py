@@ -27,22 +27,40 @@ class P2PExchange:
         self.window_bytes, self.max_doubles, self.max_world = int(meta[0]), int(i32[0]), int(i32[1])
         if self.world > self.max_world:
             raise RuntimeError(f'P2PExchange: {self.world} ranks > {self.max_world} (one node)')
+        # Local part first (allocation, export) - it can fail on ONE rank only (out of fine-grained memory, IPC refused).  Every rank
+        # then takes part in the SAME all_gather whatever happened locally, and peers' windows are only mapped when every rank
+        # reported success: a rank that raised before the collective used to leave the others blocked in it.
+        self.window, self._imported = 0, []
         out = torch.zeros(1, dtype=torch.int64)
-        lib.p2p_alloc(out)
-        self.window = int(out[0])
-        handle = torch.zeros(64, dtype=torch.uint8)
-        lib.p2p_export(self.window, handle)
+        handle, err = None, None
+        try:
+            lib.p2p_alloc(out)
+            self.window = int(out[0])
+            hb = torch.zeros(64, dtype=torch.uint8)
+            lib.p2p_export(self.window, hb)
+            handle = bytes(hb.numpy().tobytes())
+        except Exception as e:      # noqa: BLE001 - reported to the peers below, raised after the collective
+            err = e
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (self.rank, os.getpid(), bytes(handle.numpy().tobytes())), group=group)
-        ptrs, self._imported = [], []
-        for r, pid, hb in gathered:
-            if r == self.rank:
-                ptrs.append(self.window)
-                continue
-            h = torch.frombuffer(bytearray(hb), dtype=torch.uint8)
-            lib.p2p_import(h, out)
-            ptrs.append(int(out[0]))
-            self._imported.append(int(out[0]))
+        dist.all_gather_object(gathered, (self.rank, os.getpid(), handle), group=group)
+        try:
+            if err is not None:
+                raise err
+            bad = [r for r, _, hb in gathered if hb is None]
+            if bad:
+                raise RuntimeError(f'P2PExchange: window set-up failed on rank(s) {bad}')
+            ptrs = []
+            for r, pid, hb in gathered:
+                if r == self.rank:
+                    ptrs.append(self.window)
+                    continue
+                h = torch.frombuffer(bytearray(hb), dtype=torch.uint8)
+                lib.p2p_import(h, out)
+                ptrs.append(int(out[0]))
+                self._imported.append(int(out[0]))
+        except Exception:
+            self.close()            # the window and whatever was mapped so far
+            raise
         self.peers = torch.tensor(ptrs, dtype=torch.int64, device=dev)
         self.state = torch.zeros(4, dtype=torch.int64, device=dev)      # {exchange counter, error flag, ticket of the fused reductions, -}
 

@@ -71,7 +71,7 @@ class ParamSGD(torch.optim.Optimizer):
                 if 'momentum_buffer' not in st:
                     st['momentum_buffer'] = torch.zeros_like(p)
                 eng.lib.sgd_step(p.data, p.grad, st['momentum_buffer'], p.numel(), float(grp['lr']), float(grp['momentum']),
-                                 float(grp['weight_decay']), eng.stream(p.device))
+                                 float(grp['weight_decay']), None, eng.stream(p.device))
 
 
 def create_labels(size, r_pos, r_neg, total_stride, device):

@@ -74,7 +74,7 @@ class _SpatialSimLossFn(torch.autograd.Function):
             invl = torch.empty(B, Sl, dtype=torch.float32, device=dev)
             lib.simloss_colnorm(a3, inva, B, C, Sa, s)
             lib.simloss_colnorm(l3, invl, B, C, Sl, s)
-        tiles = ((Sa + 31) // 32) * ((Sl + 31) // 32)
+        tiles = ((Sa + 31) // 32) * (((Sl + 31) // 32) if pairwise else 1)      # diagonal mode: the diagonal tiles only
         partial = torch.empty(B * tiles, dtype=torch.float32, device=dev)
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         lib.simloss_fwd(a3, l3, inva, invl, m3, partial, loss, B, C, Sa, Sl, int(pairwise), int(negative), 1.0, s)

@@ -613,6 +613,9 @@ class SimSiamBaseTracker(BaseTracker):
             log_vars = LazyLogVars(keys, packed)
         else:
             log_vars = OrderedDict(zip(keys, packed.tolist()))
+            x = shared_engine()._p2p
+            if x is not None:                 # the read above drained the forward chain: its exchanges have run
+                x.raise_if_failed()
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['imgs']))
 
     def forward_train(self, imgs, grids=None, label=None):
