@@ -582,6 +582,17 @@ def main():
                     'time_share_of_step': tm / dt, 'time_share_of_eager_step': tm / dt_prof,
                     'algorithmic_bytes_per_launch': nb / cnt,
                     'algorithmic_flop_per_launch': fl / cnt, 'GB/s': nb / tm / 1e9, 'TFLOP/s': fl / tm / 1e12}
+        if os.environ.get('VFS_BENCH_SHAPES'):      # diagnostics: every distinct (family, work) launch of the eager leg with its rate
+            shapes = {}
+            for k, flops, e0, e1, nbytes in prof:
+                a = shapes.setdefault((k, flops, nbytes), [0.0, 0])
+                a[0] += e0.elapsed_time(e1) * 1e-3
+                a[1] += 1
+            with open(os.environ['VFS_BENCH_SHAPES'], 'w') as fsh:
+                fsh.write(f'per-launch table of the eager single-stream leg, {args.steps} steps; sorted by time per step\n')
+                for (k, flops, nbytes), (tm, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                    fsh.write(f'{k:20s} {cnt / args.steps:5.1f}/step  avg {tm / cnt * 1e6:8.1f} us  per-step {tm / args.steps * 1e3:7.3f} ms  '
+                              f'{nbytes / 1e6:8.1f} MB  {nbytes / (tm / cnt) / 1e12:5.2f} TB/s  {flops / 1e9:8.2f} GFLOP  {flops / (tm / cnt) / 1e12:7.1f} TFLOP/s\n')
         kind = max(agg, key=lambda k: agg[k][1])
         res['roofline'] = family(kind)
         res['roofline']['traffic_source'] = tsource

@@ -142,7 +142,8 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, extr
 # Bars of the per-stage comparison.  TOY: a BN channel sees 16-64 samples per view, so ONE ReLU-mask flip of a near-zero bf16
 # activation (engine vs oracle rounding) moves a dgamma / dbeta entry by a few percent; five Linear+BN layers with a BN batch of
 # Nv samples compound rounding noise to a few percent.
-TOY_BARS = dict(loss=1e-4, dp=1e-2, head_p=2e-2, head_gfeat=0.1, head_pgrad=0.1, out=1.2e-2, out_l2=1.2e-2, gin=3e-2, pgrad=4e-2)
+TOY_BARS = dict(loss=1e-4, dp=1e-2, head_p=2e-2, head_gfeat=0.1, head_pgrad=0.1, out=1.2e-2, out_l2=1.2e-2, gin=3e-2, pgrad=4e-2,
+                head_layer_out=1.2e-2, head_layer_grad=5e-2)
 
 
 def _every_stage(backend, depth, shape, extra, bars, size=None):
@@ -242,6 +243,32 @@ def _every_stage(backend, depth, shape, extra, bars, size=None):
     chk('head: feature-gradient rel-L2', _l2rel(_nchw(B['img_head.gfeat']), gfeat), bars['head_gfeat'])
     check_param_grads('img_head', ref.img_head, bars['head_pgrad'])
 
+    # ---- the head LAYER BY LAYER (as one stage a 7 % parameter-gradient bar cannot see a wrong 1/N or a
+    # dropped bias term in one layer): every Linear [+ BatchNorm1d [+ ReLU]] unit is fed the ENGINE'S OWN input and the engine's
+    # own incoming gradient, exactly as the residual blocks below are
+    hctx = ctx['hctx']
+    g_out = dp
+    for ui in range(len(model.img_head.units) - 1, -1, -1):
+        u = model.img_head.units[ui]
+        seq, li, bi, _ = model.img_head._plan[ui]
+        lin = getattr(ref.img_head, seq)[li]
+        bn = getattr(ref.img_head, seq)[bi] if bi is not None else None
+        ref.zero_grad()
+
+        def layer(xv, lin=lin, bn=bn):
+            y = lin(xv)
+            return bn(y) if bn is not None else y
+        out, gx = two_views(layer, hctx['ins'][ui].float().cpu(), g_out)
+        tag = f'head layer {ui} ({seq}.{li})'
+        chk(f'{tag}: out rel-L2', _l2rel(hctx['acts'][ui].float().cpu(), out), bars['head_layer_out'])
+        chk(f'{tag}: out max-rel', _maxrel(hctx['acts'][ui].float().cpu(), out), bars['out'])
+        mine_gx = B[f'{u.name}.gin'].float().cpu().view(gx.shape)
+        chk(f'{tag}: input-gradient rel-L2', _l2rel(mine_gx, gx), bars['head_layer_grad'])
+        check_param_grads(f'img_head.{seq}.{li}', lin, bars['head_layer_grad'])
+        if bn is not None:
+            check_param_grads(f'img_head.{seq}.{bi}', bn, bars['head_layer_grad'])
+        g_out = mine_gx
+
     # ---- residual blocks, last to first
     names = []
     for lname in model.backbone.res_layers:
@@ -313,7 +340,8 @@ def _keep_parity_table(size, depth, shape, bars, table):
 # Measured (profiles/r03_parity_per_stage_*.json, worst over the five sizes): block outputs max-rel 5.6e-3 / rel-L2 8.0e-4, input
 # gradients 1.2e-2, backbone parameter gradients 2.5e-2; the head (FIVE Linear+BN layers compared as one stage): p 6.8e-3,
 # feature gradient 5.7e-2, parameter gradients 7.0e-2; d loss / d p 1.7e-3; loss rows 1.2e-7.
-FULL_BARS = dict(loss=1e-6, dp=2.2e-3, head_p=8.5e-3, head_gfeat=7e-2, head_pgrad=8.5e-2, out=7e-3, out_l2=1e-3, gin=1.5e-2, pgrad=3e-2)
+FULL_BARS = dict(loss=1e-6, dp=2.2e-3, head_p=8.5e-3, head_gfeat=7e-2, head_pgrad=8.5e-2, out=7e-3, out_l2=1e-3, gin=1.5e-2, pgrad=3e-2,
+                 head_layer_out=1e-3, head_layer_grad=2e-2)      # per head layer: VERDICT r03 next #4
 
 
 @pytest.mark.gpu
