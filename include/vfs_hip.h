@@ -367,6 +367,19 @@ int vfs_l2norm_rows_f32(const float* x, float* y, long long P, int C, vfs_stream
 int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* workspace, long long workspace_bytes, int qframe,
                       const int* kslot, int nkeys, int H, int W, int C, int CO, int radius, int non_mask_len, int topk,
                       float temperature, vfs_stream_t stream);
+/* Two-pass form of vfs_labelprop_f32 with IDENTICAL results (csrc/labelprop2.hip): every in-window candidate is first scored on the
+ * bf16 matrix path from a split copy of the bank (x = hi + lo, three products; |s~ - s| <= 3 * 2^-16 + 4 * C * 2^-24 for unit
+ * rows), the candidates within twice that bound of the query's 10th-best s~ - the only ones that can be in the exact top 10 -
+ * are rescored with the defining fp32 chain and go through the same total order / softmax / value sum.
+ *   vfs_split_rows_bf16x2: hl [P][C/16][16 hi | 16 lo] bf16 from unit rows x [P][C] fp32 (C % 16 == 0), once per frame;
+ *   vfs_labelprop_f32_2pass: hlbank = the split copy of fbank (same frame indexing).  unit_rows = 0 (test_cfg.with_norm=False),
+ *   hlbank = NULL or C not in {256, 512, 1024} -> the dense kernel; a candidate list that overflows -> the dense kernel redoes
+ *   the frame, decided on the device.  workspace: at least vfs_labelprop_f32_2pass_workspace_bytes(H, W) */
+int vfs_split_rows_bf16x2(const float* x, vfs_bf16* hl, long long P, int C, vfs_stream_t stream);
+int vfs_labelprop_f32_2pass_workspace_bytes(int H, int W, long long* bytes);
+int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const float* sbank, float* out, void* workspace,
+                            long long workspace_bytes, int qframe, const int* kslot, int nkeys, int H, int W, int C, int CO,
+                            int radius, int non_mask_len, int topk, float temperature, int unit_rows, vfs_stream_t stream);
 /* F.interpolate(mode='bilinear', align_corners=False) of a C-channel fp32 map between layouts (NCHW [C][H][W] or NHWC
  * [H][W][C], chosen per side): one-hot reference maps -> feature resolution, soft label maps -> original resolution
  * (vanilla_tracker.py:101-111,162-166 when ref_seg_map is 4-D) */

@@ -1,0 +1,174 @@
+"""Two-pass exact label propagation (csrc/labelprop2.hip) == the dense fp32 kernel == oracle/exact_oracle.c, BIT FOR BIT.
+
+masked_attention_efficient (mmaction/models/common/local_attention.py:277-335) keeps the ten best keys of every query; the dense
+kernel scores every in-window candidate with the defining fp32 chain.  The two-pass form scores them on the bf16 matrix path from
+a hi / lo split of the bank (|s~ - s| <= 3 * 2^-16 + 4 * C * 2^-24 for unit rows), lists what can still be in the top ten and
+rescores only that with the defining chain - so every test of the dense kernel applies unchanged, plus:
+  * candidates packed INSIDE the prefilter's margin around the 10th-best score (adversarial near-ties, exact duplicates);
+  * list overflow -> the dense kernel redoes the frame (decided on the device), same bits;
+  * the prefilter's error against its bound, measured on the scores themselves."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import exact_oracle as X
+
+
+def same_bits(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+def _ws(lib, H, W):
+    n = torch.zeros(1, dtype=torch.int64)
+    lib.labelprop_f32_2pass_workspace_bytes(H, W, n)
+    dense = torch.zeros(1, dtype=torch.int64)
+    lib.labelprop_workspace_bytes(H, W, dense)
+    assert n.item() > dense.item()
+    return torch.zeros((int(n.item()) + 3) // 4), int(dense.item())
+
+
+def _unit_bank(lib, feats):
+    T, HW, C = feats.shape
+    fb = torch.empty(T, HW, C)
+    lib.l2norm_rows_f32(feats.reshape(-1, C).contiguous(), fb, T * HW, C, None)
+    hl = torch.empty(T, HW, 2 * C, dtype=torch.bfloat16)
+    lib.split_rows_bf16x2(fb, hl, T * HW, C, None)
+    return fb, hl
+
+
+def _features(T, H, W, C, CO, seed, smooth=0.0):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(T, H * W, C, generator=g)
+    feats = feats + 2.0 * torch.randn(1, 1, C, generator=g) + torch.linspace(0, 3, H * W)[None, :, None] * torch.randn(1, 1, C, generator=g)
+    if smooth:      # post-ReLU-like features with a strong common component: cosine scores crowd together (bench.py's clip does)
+        feats = feats.abs() + smooth
+    seg = torch.rand(T, H * W, CO, generator=g)
+    return feats, seg
+
+
+def run_2pass(be, feats, seg, H, W, radius, slots, qframe, topk=10, non_mask_len=0, expect_fallback=None):
+    lib = be.hostlib
+    T, HW, C = feats.shape
+    CO = seg.shape[-1]
+    fb, hl = _unit_bank(lib, feats)
+    out = torch.full((HW, CO), float('nan'))
+    ks = (ctypes.c_int * len(slots))(*slots)
+    ws, dense_bytes = _ws(lib, H, W)
+    lib.labelprop_f32_2pass(fb, hl, seg, out, ws, ws.numel() * 4, qframe, ks, len(slots), H, W, C, CO, radius, non_mask_len, topk, 0.07, 1, None)
+    want = X.labelprop(fb.numpy(), seg.numpy(), qframe, slots, H, W, radius, topk, 0.07, non_mask_len=non_mask_len)
+    assert same_bits(out.numpy(), want), float(np.abs(out.numpy() - want).max())
+    # the device-side flag: 0 = the lists held everything, 1 = the dense kernel redid the frame
+    n = torch.zeros(1, dtype=torch.int64)
+    lib.labelprop_f32_2pass_workspace_bytes(H, W, n)
+    flag = int(ws.view(torch.int32)[(int(n.item()) - 16) // 4])
+    if expect_fallback is not None:
+        assert flag == (1 if expect_fallback else 0), flag
+    return fb, hl, out, flag
+
+
+CASES = [
+    dict(T=6, H=12, W=16, C=256, CO=3, radius=4, slots=[0, 1, 2, 3, 4], qframe=5),
+    dict(T=4, H=9, W=13, C=256, CO=5, radius=3, slots=[0, 0, 1, 2], qframe=3),           # duplicated first frame: exact ties
+    dict(T=3, H=8, W=8, C=256, CO=2, radius=0, slots=[0, 1], qframe=2, topk=5),           # no spatial mask: the window is the map
+    dict(T=3, H=20, W=28, C=256, CO=3, radius=6, slots=[0, 1], qframe=2),                 # several key blocks, ragged last block
+    dict(T=4, H=9, W=13, C=256, CO=3, radius=3, slots=[0, 1, 2], qframe=3, non_mask_len=1),   # with_first_neighbor=False
+    dict(T=3, H=10, W=12, C=512, CO=3, radius=4, slots=[0, 1], qframe=2),                 # 8 channel groups per wave
+    dict(T=12, H=9, W=9, C=256, CO=3, radius=3, slots=list(range(11)), qframe=11),        # more key frames than splits
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_two_pass_equals_oracle(backend, case):
+    c = dict(case)
+    feats, seg = _features(c.pop('T'), c['H'], c['W'], c.pop('C'), c.pop('CO'), seed=7)
+    run_2pass(backend, feats, seg, expect_fallback=False, **c)
+
+
+def test_two_pass_crowded_scores(backend):
+    """scores crowded like the bench's synthetic clip (post-ReLU features with a common component: the bf16-rounded scores of
+    hundreds of candidates lie within 2^-7 of the 10th best - a single-bf16 prefilter would keep them all)"""
+    feats, seg = _features(5, 16, 20, 256, 3, seed=3, smooth=4.0)
+    run_2pass(backend, feats, seg, 16, 20, 6, [0, 0, 1, 2, 3], 4, expect_fallback=False)
+
+
+def test_two_pass_adversarial_near_ties(backend):
+    """candidates packed INSIDE the prefilter's margin of the 10th best: every key row of the window is the query's own row plus a
+    perturbation of a few fp32 ulps (exact scores differ in the last bits, the split-bf16 scores mostly not at all), some rows
+    exact duplicates.  The exact top ten and their order under (score desc, id asc) must survive."""
+    T, H, W, C, CO = 3, 8, 10, 256, 4
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(C, generator=g)
+    feats = base[None, None, :].repeat(T, H * W, 1)
+    jitter = torch.randint(-3, 4, feats.shape, generator=g).float() * 2.0 ** -21      # a few ulps of values of size ~1
+    feats = feats * (1.0 + jitter)
+    feats[1, 5] = feats[1, 4]                  # exact duplicates among the keys
+    feats[0, 17] = feats[1, 17]
+    seg = torch.rand(T, H * W, CO, generator=g)
+    # radius 3: 21 .. 25 in-circle keys per frame and query, two key frames -> ~50 candidates, all inside the margin
+    run_2pass(backend, feats, seg, H, W, 3, [0, 1], 2, expect_fallback=False)
+
+
+def test_list_overflow_falls_back_to_dense(backend):
+    """a list capacity of 16 entries per (split, query) cannot hold the candidates of the first key block: the overflow flag is
+    raised on the device and the dense kernel (launched behind the two passes, idle otherwise) redoes the frame - same bits"""
+    lib = backend.hostlib
+    feats, seg = _features(4, 12, 16, 256, 3, seed=5, smooth=4.0)
+    try:
+        lib.set_option(b'lp2_cap', 16)
+        run_2pass(backend, feats, seg, 12, 16, 5, [0, 1, 2], 3, expect_fallback=True)
+    finally:
+        lib.set_option(b'lp2_cap', 256)
+    run_2pass(backend, feats, seg, 12, 16, 5, [0, 1, 2], 3, expect_fallback=False)
+
+
+def test_dense_paths_of_the_entry_point(backend):
+    """unit_rows = 0, hlbank = NULL or an uncovered channel count: the entry point is the dense kernel"""
+    lib = backend.hostlib
+    H, W, CO = 9, 12, 3
+    for C, unit, with_hl in ((64, 1, True), (256, 0, True), (256, 1, False)):
+        feats, seg = _features(3, H, W, C, CO, seed=2)
+        fb = torch.empty_like(feats)
+        lib.l2norm_rows_f32(feats.reshape(-1, C).contiguous(), fb, feats.shape[0] * H * W, C, None)
+        hl = torch.empty(3, H * W, 2 * C, dtype=torch.bfloat16)
+        if C % 16 == 0:
+            lib.split_rows_bf16x2(fb, hl, 3 * H * W, C, None)
+        out = torch.full((H * W, CO), float('nan'))
+        ks = (ctypes.c_int * 2)(0, 1)
+        ws, _ = _ws(lib, H, W)
+        lib.labelprop_f32_2pass(fb, hl if with_hl else None, seg, out, ws, ws.numel() * 4, 2, ks, 2, H, W, C, CO, 4, 0, 10, 0.07, unit, None)
+        want = X.labelprop(fb.numpy(), seg.numpy(), 2, [0, 1], H, W, 4, 10, 0.07)
+        assert same_bits(out.numpy(), want)
+
+
+def test_split_rows_and_prefilter_bound(backend):
+    """x = hi + lo to 2^-16 relative (hi = bf16(x), lo = bf16(x - hi)), in the interleaved [16 hi | 16 lo] layout; and the three-product
+    score of unit rows stays within the bound the kernel's margin is built on (3 * 2^-16 + 4 * C * 2^-24), measured against fp64"""
+    lib = backend.hostlib
+    C = 256
+    feats, _ = _features(2, 6, 8, C, 2, seed=9, smooth=1.0)
+    fb, hl = _unit_bank(lib, feats)
+    x = fb.reshape(-1, C)
+    h = hl.reshape(-1, C // 16, 2, 16).float()
+    hi, lo = h[:, :, 0].reshape(-1, C), h[:, :, 1].reshape(-1, C)
+    assert torch.equal(hi, x.to(torch.bfloat16).float())
+    assert torch.equal(lo, (x - hi).to(torch.bfloat16).float())
+    assert ((x - hi - lo).abs() <= 2.0 ** -16 * x.abs() + 1e-38).all()
+    q, k = slice(0, 48), slice(48, 96)
+    s3 = (hi[q].double() @ hi[k].double().t() + hi[q].double() @ lo[k].double().t() + lo[q].double() @ hi[k].double().t())
+    exact = x[q].double() @ x[k].double().t()
+    assert float((s3 - exact).abs().max()) <= 3 * 2.0 ** -16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,radius', [(256, 12), (1024, 18)])
+def test_two_pass_davis_size_bit_exact(gpu_backend, C, radius):
+    """DAVIS feature size 60x107, R18 (C=256, r=12) and R50 (C=1024, r=18) settings, duplicated first frame.  With EXTREMELY crowded
+    scores (every cosine within ~1e-3: more near-ties per query than the lists or the refinement hold) the device may hand the
+    frame to the dense kernel - the bits are the same either way; the plain case must stay on the two-pass path."""
+    feats, seg = _features(5, 60, 107, C, 4, seed=0, smooth=3.0)
+    _, _, _, flag = run_2pass(gpu_backend, feats, seg, 60, 107, radius, [0, 0, 1, 2, 3], 4)
+    print('crowded case: dense fallback flag', flag)
+    feats, seg = _features(5, 60, 107, C, 4, seed=1)
+    run_2pass(gpu_backend, feats, seg, 60, 107, radius, [0, 0, 1, 2, 3], 4, expect_fallback=False)

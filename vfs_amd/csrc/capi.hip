@@ -30,7 +30,7 @@ int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_bn_wide, vfs_option_bn_wide_min_mb;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
-extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target, vfs_option_lpx_wgs, vfs_option_lpx_minb;
+extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target, vfs_option_lpx_wgs, vfs_option_lpx_minb, vfs_option_lp2, vfs_option_lp2_wgs, vfs_option_lp2_cap, vfs_option_lp2_xcd;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -61,6 +61,10 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "lpx_target")) { vfs_option_lpx_target = value; return VFS_OK; }
   if (!strcmp(name, "lpx_wgs")) { vfs_option_lpx_wgs = value; return VFS_OK; }
   if (!strcmp(name, "lpx_minb")) { vfs_option_lpx_minb = value; return VFS_OK; }
+  if (!strcmp(name, "lp2")) { vfs_option_lp2 = value; return VFS_OK; }
+  if (!strcmp(name, "lp2_wgs")) { vfs_option_lp2_wgs = value; return VFS_OK; }
+  if (!strcmp(name, "lp2_xcd")) { vfs_option_lp2_xcd = value; return VFS_OK; }
+  if (!strcmp(name, "lp2_cap")) { vfs_option_lp2_cap = value < 16 ? 16 : (value > LP2_MAX_CAP ? LP2_MAX_CAP : value); return VFS_OK; }
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_xcd")) { vfs_option_wgrad_xcd = value; return VFS_OK; }
@@ -586,6 +590,53 @@ int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* 
   for (int i = 0; i < LP_MAX_KEYS; ++i) a.kslot[i] = i < nkeys ? kslot[i] : 0;   // kslot is a HOST array
   a.H = H; a.W = W; a.C = C; a.CO = CO; a.radius = radius; a.topk = topk; a.temperature = temperature;
   a.non_mask_len = non_mask_len;
+  return vfs_labelprop_f32_launch(a, S(stream));
+}
+int vfs_split_rows_bf16x2(const float* x, vfs_bf16* hl, long long P, int C, vfs_stream_t stream) {
+  if (!x || !hl) return vfs_set_error(VFS_ERR_ARG, "split_rows_bf16x2: null buffer");
+  return vfs_split_rows_bf16x2_launch(x, hl, P, C, S(stream));
+}
+static long long lp2_lists_bytes(int H, int W) { return (long long)LP2_MAX_SPLIT * H * W * LP2_MAX_CAP * 8; }
+static long long lp2_counts_bytes(int H, int W) { return ((long long)(LP2_MAX_SPLIT + 1) * H * W * 4 + 15) / 16 * 16; }      // counts + thresholds
+int vfs_labelprop_f32_2pass_workspace_bytes(int H, int W, long long* bytes) {
+  long long dense = 0;
+  if (!bytes || vfs_labelprop_workspace_bytes(H, W, &dense) != VFS_OK) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass_workspace_bytes: bad argument");
+  *bytes = dense + lp2_lists_bytes(H, W) + lp2_counts_bytes(H, W) + 16;
+  return VFS_OK;
+}
+int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const float* sbank, float* out, void* workspace,
+                            long long workspace_bytes, int qframe, const int* kslot, int nkeys, int H, int W, int C, int CO, int radius,
+                            int non_mask_len, int topk, float temperature, int unit_rows, vfs_stream_t stream) {
+  if (!hlbank || !unit_rows || !vfs_lp2_eligible(C))
+    return vfs_labelprop_f32(fbank, sbank, out, workspace, workspace_bytes, qframe, kslot, nkeys, H, W, C, CO, radius, non_mask_len, topk,
+                             temperature, stream);
+  if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: 1 <= nkeys <= 64");
+  if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: 0 <= non_mask_len < nkeys");
+  long long need = 0, dense = 0;
+  if (vfs_labelprop_f32_2pass_workspace_bytes(H, W, &need) != VFS_OK || vfs_labelprop_workspace_bytes(H, W, &dense) != VFS_OK || !workspace ||
+      workspace_bytes < need)
+    return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: workspace smaller than vfs_labelprop_f32_2pass_workspace_bytes(H, W)");
+  Lp2Args p;
+  p.fbank = fbank; p.hl = hlbank; p.sbank = sbank; p.out = out;
+  char* ws = (char*)workspace + dense;
+  p.lists = (unsigned long long*)ws;
+  p.counts = (int*)(ws + lp2_lists_bytes(H, W));
+  p.gthr = p.counts + (size_t)LP2_MAX_SPLIT * H * W;
+  p.flags = (int*)(ws + lp2_lists_bytes(H, W) + lp2_counts_bytes(H, W));
+  p.qframe = qframe; p.nkeys = nkeys;
+  for (int i = 0; i < LP_MAX_KEYS; ++i) p.kslot[i] = i < nkeys ? kslot[i] : 0;
+  p.H = H; p.W = W; p.C = C; p.CO = CO; p.radius = radius; p.topk = topk; p.non_mask_len = non_mask_len; p.temperature = temperature;
+  p.margin = 0.f; p.cap = 0; p.nsplit = 0; p.xcd_order = 0;
+  int rc = vfs_labelprop_f32_2pass_launch(p, S(stream));
+  if (rc) return rc;
+  // the dense kernel as the overflow fallback: its workgroups read the flag and leave when no list overflowed
+  LabelPropF32Args a;
+  a.fbank = fbank; a.sbank = sbank; a.out = out; a.qframe = qframe; a.nkeys = nkeys;
+  a.pval = (float*)workspace;
+  a.pidx = (int*)((float*)workspace + (size_t)LP_MAX_SPLIT * H * W * 10);
+  for (int i = 0; i < LP_MAX_KEYS; ++i) a.kslot[i] = p.kslot[i];
+  a.H = H; a.W = W; a.C = C; a.CO = CO; a.radius = radius; a.topk = topk; a.temperature = temperature; a.non_mask_len = non_mask_len;
+  a.run_flag = p.flags;
   return vfs_labelprop_f32_launch(a, S(stream));
 }
 int vfs_bilinear_resize_f32(const float* src, float* dst, int C, int H, int W, int Ho, int Wo, int src_nhwc, int dst_nhwc,

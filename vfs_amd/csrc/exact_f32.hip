@@ -260,41 +260,7 @@ int vfs_l2norm_rows_f32_launch(const float* x, float* y, long long P, int C, hip
   return vfs_check_launch("l2norm_rows_f32");
 }
 
-// ---------------------------------------------------------------------------------------------
-// exp(x), x <= 0 (oracle: xo_exp): n = rint(x log2 e), r = x - n ln2 (two fmaf), degree-6 Horner, 2^n scaling
-__device__ __forceinline__ float vexp(float x) {
-  if (x < -87.0f) return 0.0f;
-  const float n = __builtin_rintf(x * 1.44269504088896341f);
-  float r = __builtin_fmaf(n, -0.693359375f, x);
-  r = __builtin_fmaf(n, 2.12194440e-4f, r);
-  float p = 1.9875691500e-4f;
-  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-  p = __builtin_fmaf(p, r * r, r);
-  p = p + 1.0f;
-  return ldexpf(p, (int)n);
-}
-
-#define LPX_TOPK 10
-#define LPX_QCAP 8
-typedef __attribute__((ext_vector_type(2))) unsigned int vfs_u32x2q;
-#define LPX_NONE 0x7fffffff
-// total order of the top-k: larger score first, equal scores: smaller candidate id first
-__device__ __forceinline__ bool lpx_better(float s, int id, float ts, int tid) { return s > ts || (s == ts && id < tid); }
-__device__ __forceinline__ void lpx_insert(float (&tv)[LPX_TOPK], int (&ti)[LPX_TOPK], float s, int id) {
-  if (lpx_better(s, id, tv[LPX_TOPK - 1], ti[LPX_TOPK - 1])) { tv[LPX_TOPK - 1] = s; ti[LPX_TOPK - 1] = id; }
-#pragma unroll
-  for (int j = LPX_TOPK - 1; j > 0; --j) {
-    const bool sw = lpx_better(tv[j], ti[j], tv[j - 1], ti[j - 1]);
-    const float a = tv[j - 1], b = tv[j];
-    const int ia = ti[j - 1], ib = ti[j];
-    tv[j - 1] = sw ? b : a; tv[j] = sw ? a : b;
-    ti[j - 1] = sw ? ib : ia; ti[j] = sw ? ia : ib;
-  }
-}
+#include "vfs_lpx.h"
 
 // one workgroup = an 8x8 tile of queries x the key frames [f_begin, f_end) of its split; per key frame only the
 // (8 + 2(r-1))^2 window that can lie inside the circle, 64 keys per block, channels in stages of 32.
@@ -306,6 +272,7 @@ __device__ __forceinline__ void lpx_insert(float (&tv)[LPX_TOPK], int (&ti)[LPX_
 template <bool RAGGED>
 __global__ __launch_bounds__(256) void labelprop_f32_kernel(LabelPropF32Args a, int nsub) {
   constexpr int BQ = 64, BKEY = 64, BC = 32;
+  if (a.run_flag && *a.run_flag == 0) return;      // fallback launch of the two-pass path (labelprop2.hip): nothing overflowed
   __shared__ __attribute__((aligned(16))) float sK[BC / 2][BKEY][2];
   __shared__ __attribute__((aligned(16))) float sQ[BC / 2][BQ][2];
   __shared__ int sKC[BKEY];
@@ -472,6 +439,7 @@ __global__ __launch_bounds__(256) void labelprop_f32_merge_kernel(LabelPropF32Ar
   const int HW = a.H * a.W;
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= HW) return;
+  if (a.run_flag && *a.run_flag == 0) return;
   float bv[LPX_TOPK];
   int bi[LPX_TOPK];
 #pragma unroll

@@ -1,0 +1,597 @@
+// Two-pass EXACT label propagation for gfx950: the top-10 of masked_attention_efficient (mmaction/models/common/local_attention.py:
+// 277-335) with the bits of the dense fp32 kernel (exact_f32.hip / oracle/exact_oracle.c), at a fraction of its fp32 work.
+//
+//   pass 1  (lp2_score_kernel)   every in-window candidate is scored on the bf16 MATRIX path (v_mfma_f32_32x32x16_bf16, 16x the fp32
+//           rate) from a SPLIT copy of the bank: x = hi + lo + e, hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-16 |x|, and
+//               s~ = hi_q.hi_k + hi_q.lo_k + lo_q.hi_k          (three MFMAs per 16 channels; lo.lo <= 2^-16 is dropped)
+//           For unit vectors |s~ - s| <= EPS = 3 * 2^-16 + 4 * C * 2^-24 (representation: Cauchy-Schwarz on the dropped terms;
+//           accumulation: C roundings of the exact chain + the matrix unit's internal sums, both bounded by their worst case).
+//           Every candidate with s~ >= (running lower bound of the query's 10th-best s~) - 2 EPS is appended to the query's list.
+//           The bound starts from a SEED (lp2_seed_kernel: the query's own position in every key frame - in a video the best
+//           matches - scored exactly, 10th best minus EPS), follows the query's true running 10th best inside a workgroup and is
+//           shared between the workgroups that split a query's key frames through a device-scope atomic max: the lists hold a
+//           few dozen entries, not the thousands a cold start lists before its threshold has risen.
+//   pass 2  (lp2_refine_kernel)  per query: t = the 10th largest s~ of its list (= of ALL its candidates: the ten best are always
+//           listed), survivors = {s~ >= t - 2 EPS}.  A candidate outside the survivors has ten candidates whose s~ exceeds its own
+//           by more than 2 EPS, hence whose EXACT score is strictly larger: it cannot be in the exact top 10 under any tie rule.
+//           The survivors (a few dozen) are rescored with the defining arithmetic - one ascending chain acc = fma(k_c, q_c, acc)
+//           per pair, bitwise what v_mfma_f32_32x32x2_f32 computes in the dense kernel - and go through the same total order
+//           (score desc, candidate id asc), softmax (vexp) and value sum as labelprop_f32_merge_kernel: identical bits, by
+//           construction, whatever pass 1's rounding did.
+//   Anything the lists cannot hold (capacity overflow), a bank that is not unit-norm (test_cfg.with_norm=False) or a channel count
+//   the register-resident query tile does not cover falls back to the dense kernel; the overflow case WITHOUT a host round trip
+//   (the dense launches read a device flag and exit at once when it is clear).
+//
+// Pass-1 work shape (what round 3's probes asked for, MEASUREMENTS.md "What bounds the fp32 evaluation kernels"): the 8x8 query
+// tile lives in REGISTERS for the whole workgroup - wave w holds channels [w C/4, (w+1) C/4) of all 64 queries as MFMA B
+// operands (2 x C/64 x 8 VGPRs) - so only KEY rows stream: every wave pulls ITS channel quarter of a 64-key block through its own
+// three-stage LDS ring by LDS-DMA (buffer_load ... lds, whole 128-byte lines: the split bank interleaves hi / lo per 16 channels),
+// no barrier and no cross-wave traffic inside the channel loop; the four partial 64x64 score tiles meet in LDS once per key block.
+#include "vfs_lpx.h"
+
+#pragma clang fp contract(off)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---------------------------------------------------------------------------------------------
+// x [P][C] fp32 -> hl [P][C/16][hi k0..7 | hi k8..15 | lo k0..7 | lo k8..15] bf16: one thread per 8 channels
+__global__ __launch_bounds__(256) void split_rows_bf16x2_kernel(const float* __restrict__ x, bf16_t* __restrict__ hl, long long P, int C) {
+  const int c8n = C >> 3;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P * c8n) return;
+  const long long row = i / c8n;
+  const int c8 = (int)(i - row * c8n);
+  const float* src = x + (size_t)row * C + c8 * 8;
+  const f32x4 v0 = lpx_ldf4(src), v1 = lpx_ldf4(src + 4);
+  float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, lo[8];
+  u32x4 hv, lv;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lo[j] = v[j] - round_bf(v[j]);      // exact in fp32
+  hv = pack8(v);
+  lv = pack8(lo);
+  bf16_t* dst = hl + (size_t)row * 2 * C + (c8 >> 1) * 32 + (c8 & 1) * 8;
+  st16(dst, hv);
+  st16(dst + 16, lv);
+}
+int vfs_split_rows_bf16x2_launch(const float* x, bf16_t* hl, long long P, int C, hipStream_t s) {
+  if (C % 16) return vfs_set_error(VFS_ERR_SHAPE, "split_rows_bf16x2: C % 16");
+  const long long total = P * (C / 8);
+  hipLaunchKernelGGL(split_rows_bf16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, hl, P, C);
+  return vfs_check_launch("split_rows_bf16x2");
+}
+
+// ---------------------------------------------------------------------------------------------
+// monotone float <-> int (for an LDS atomic max over floats of either sign)
+__device__ __forceinline__ int lp2_enc(float f) {
+  const int b = __builtin_bit_cast(int, f);
+  return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float lp2_dec(int e) { return __builtin_bit_cast(float, e >= 0 ? e : e ^ 0x7fffffff); }
+
+// sorted insertion of a value into a descending list of 10 (pass 1 only needs thresholds, not ids)
+__device__ __forceinline__ void lp2_insert_val(float (&tv)[LPX_TOPK], float s) {
+  if (s > tv[LPX_TOPK - 1]) tv[LPX_TOPK - 1] = s;
+#pragma unroll
+  for (int j = LPX_TOPK - 1; j > 0; --j) {
+    const float a = tv[j - 1], b = tv[j];
+    tv[j - 1] = b > a ? b : a;
+    tv[j] = b > a ? a : b;
+  }
+}
+
+// the window of one key frame for this query tile, and the centre-out order of its 64-key blocks (the best matches of a video
+// sit near the query's own position: visiting those rows first lets the running threshold rise at once, so few candidates
+// are listed before it has)
+struct Lp2Window {
+  int slot, r, wy0, wx0, ww, nwin, nkb;
+};
+__device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0, int qx0) {
+  Lp2Window w;
+  w.slot = a.kslot[f];
+  w.r = f < a.non_mask_len ? 0 : a.radius;
+  int wy1 = a.H - 1, wx1 = a.W - 1;
+  w.wy0 = 0; w.wx0 = 0;
+  if (w.r > 0) {
+    w.wy0 = max(0, qy0 - (w.r - 1)); wy1 = min(a.H - 1, qy0 + 7 + (w.r - 1));
+    w.wx0 = max(0, qx0 - (w.r - 1)); wx1 = min(a.W - 1, qx0 + 7 + (w.r - 1));
+  }
+  w.ww = wx1 - w.wx0 + 1;
+  w.nwin = (wy1 - w.wy0 + 1) * w.ww;
+  w.nkb = (w.nwin + 63) >> 6;
+  return w;
+}
+__device__ __forceinline__ int lp2_block_of(int i, int nkb) {      // i-th block in centre-out order
+  const int mid = (nkb - 1) >> 1, off = (i + 1) >> 1;
+  return (i & 1) ? mid + off : mid - off;
+}
+
+// Seed of the running threshold: one wave per query scores the query's OWN pixel in every key frame (plus its four neighbours while
+// there are fewer than ten key frames) with an fp32 dot product; gthr[q] = (10th best - EPS) is a valid lower bound of the 10th
+// best s~ pass 1 will see (|dot - s~| <= EPS for every candidate, and the 10th best over a subset never exceeds the 10th best
+// over all).  -inf when fewer than ten seeds exist.
+__global__ __launch_bounds__(256) void lp2_seed_kernel(Lp2Args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H, W = a.W, C = a.C, HW = H * W;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= HW) return;
+  const int qy = q / W, qx = q - qy * W;
+  const float* qrow = a.fbank + ((size_t)a.qframe * HW + q) * C;
+  f32x4 qv[4];      // C <= 1024: channels 256 j + 4 lane .. + 3
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qv[j] = 256 * j < C ? lpx_ldf4(qrow + 256 * j + 4 * lane) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  float tv[LPX_TOPK];
+#pragma unroll
+  for (int i = 0; i < LPX_TOPK; ++i) tv[i] = -INFINITY;
+  const int noff = a.nkeys < LPX_TOPK ? 5 : 1;
+  for (int f = 0; f < a.nkeys; ++f) {
+    const int r = f < a.non_mask_len ? 0 : a.radius;
+    const float* frame = a.fbank + (size_t)a.kslot[f] * HW * C;
+    for (int o = 0; o < noff; ++o) {
+      const int dy = o == 3 ? 1 : (o == 4 ? -1 : 0), dx = o == 1 ? 1 : (o == 2 ? -1 : 0);
+      const int ky = qy + dy, kx = qx + dx;
+      if (ky < 0 || ky >= H || kx < 0 || kx >= W) continue;
+      if (r > 0 && dy * dy + dx * dx >= r * r) continue;
+      const float* krow = frame + (size_t)(ky * W + kx) * C;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (256 * j < C) {
+          const f32x4 kv = lpx_ldf4(krow + 256 * j + 4 * lane);
+          acc = __builtin_fmaf(kv[0], qv[j][0], acc); acc = __builtin_fmaf(kv[1], qv[j][1], acc);
+          acc = __builtin_fmaf(kv[2], qv[j][2], acc); acc = __builtin_fmaf(kv[3], qv[j][3], acc);
+        }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc = acc + __shfl_xor(acc, d);
+      lp2_insert_val(tv, acc);
+    }
+  }
+  if (lane == 0) a.gthr[q] = lp2_enc(tv[LPX_TOPK - 1] - 0.5f * a.margin);
+}
+
+struct Lp2Off { unsigned v[8]; };      // byte offsets of the eight DMA pieces of a key block (by value: stays in registers)
+__device__ __forceinline__ Lp2Off lp2_offsets(const Lp2Window& w, int kb, int lane, int W, unsigned rowb, unsigned lane_off) {
+  Lp2Off o;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = 8 * p + (lane >> 3);
+    const int kk = min(kb * 64 + r, w.nwin - 1);
+    const int ky = w.wy0 + kk / w.ww, kx = w.wx0 + kk % w.ww;
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    o.v[p] = (unsigned)(ky * W + kx) * rowb + lane_off + (unsigned)c * 16u;
+  }
+  return o;
+}
+// Key stages travel by LDS-DMA (buffer_load ... lds): RING - 1 stages of 8 KB in flight per wave, no VGPR staging.  (Measured on
+// the MI355X against buffer_load_dwordx4 -> VGPR -> ds_write_b128 with one 8 KB stage in flight per wave: 2.15 vs 2.6 ms for the
+// ResNet-50 frame - with one wave per SIMD the loop is bound by bytes in flight x memory latency, not by the issue path.)
+__device__ __forceinline__ vfs_rsrc_words lp2_frame_rsrc(const bf16_t* hl, int slot, int HW, unsigned rowb) {
+  return vfs_make_rsrc_words(reinterpret_cast<const unsigned char*>(hl) + (size_t)slot * HW * rowb, (unsigned)HW * rowb);
+}
+__device__ __forceinline__ void lp2_issue(const vfs_rsrc_words& rs, const Lp2Off& o, unsigned char* dst, unsigned soff) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) vfs_dma16_async(rs, dst + p * 1024, o.v[p], soff);
+}
+__device__ __forceinline__ void lp2_park(float* dst, const f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[r * 64] = v[r];
+}
+
+// NG = 16-channel groups per wave = C / 64 (4: C = 256, 8: 512, 16: 1024)
+template <int NG>
+__global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
+  constexpr int RING = LP2_RING, NST = NG / 2, SBYTES = 64 * 128;
+  static_assert(RING >= 3 && RING - 1 <= NST, "the requests run at most one key block ahead");      // a stage = 32 channels (hi + lo) of 64 key rows = 8 KB per wave
+  __shared__ __attribute__((aligned(16))) unsigned char sRing[4][RING][SBYTES];
+  __shared__ float sRed[4][3][16][64];      // [owner wave][source rank][accumulator register][lane]
+  __shared__ int sKC[64], sThr[64], sCnt[64], sEn[64];
+  __shared__ float sEq[64][LP2_BLOCK_QUEUE];      // scores listed for a query in the current key block (feed its running top 10)
+  __shared__ float sTop[LPX_TOPK][64];            // the queries' running top 10 of s~ (in LDS: the 512 registers of a lane are taken)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, kgrp = lane >> 5;
+  const int H = a.H, W = a.W, C = a.C, HW = H * W;
+  const int tiles_x = (W + 7) >> 3;
+  // Work order (a speed matter only): the key rows a workgroup streams are wanted by the ~5 x 5 query tiles whose windows contain
+  // them.  Hardware workgroup b runs on XCD b % 8, each XCD behind its own 4 MB L2: every XCD gets a CONTIGUOUS range of the
+  // logical order (tile row, key-frame split, tile column), so the workgroups resident on an XCD are the neighbouring tiles of ONE
+  // tile row on the SAME key frames, walking their windows (centre-out, same order) in step - PMC: 7.6 GB fetched per ResNet-50
+  // frame instead of 12.4 GB (bijective remap, any grid).
+  int lb = blockIdx.x;
+  if (a.xcd_order) {
+    const int nb = gridDim.x, qn = nb >> 3, rn = nb & 7, xcd = lb & 7;
+    lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lb >> 3);
+  }
+  const int trow = lb / (a.nsplit * tiles_x), rem = lb - trow * (a.nsplit * tiles_x);
+  const int split = rem / tiles_x, tcol = rem - split * tiles_x;
+  const int qy0 = trow * 8, qx0 = tcol * 8;
+  const int fpb = (a.nkeys + a.nsplit - 1) / a.nsplit;
+  const int f_begin = split * fpb, f_end = min(a.nkeys, f_begin + fpb);
+  const unsigned rowb = (unsigned)C * 4u;      // bytes of one split row (hi + lo)
+
+  // ---- the query tile, resident: B fragments (16 channels x 32 queries) of this wave's channel quarter, hi and lo
+  bf16x8 qh0[NG], qh1[NG], ql0[NG], ql1[NG];
+  {
+    const int qa = li, qb = 32 + li;
+    const int ya = min(qy0 + (qa >> 3), H - 1), xa = min(qx0 + (qa & 7), W - 1);      // rows past the map: a valid row, masked below
+    const int yb = min(qy0 + (qb >> 3), H - 1), xb = min(qx0 + (qb & 7), W - 1);
+    const bf16_t* ba = a.hl + ((size_t)a.qframe * HW + (size_t)(ya * W + xa)) * 2 * C + (size_t)wave * NG * 32 + kgrp * 8;
+    const bf16_t* bb = a.hl + ((size_t)a.qframe * HW + (size_t)(yb * W + xb)) * 2 * C + (size_t)wave * NG * 32 + kgrp * 8;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      qh0[g] = *reinterpret_cast<const bf16x8*>(ba + g * 32);
+      ql0[g] = *reinterpret_cast<const bf16x8*>(ba + g * 32 + 16);
+      qh1[g] = *reinterpret_cast<const bf16x8*>(bb + g * 32);
+      ql1[g] = *reinterpret_cast<const bf16x8*>(bb + g * 32 + 16);
+    }
+  }
+  // the query's running top 10 of s~ (sTop, maintained by lane t of wave 0); its 10th entry, the seed and what the other
+  // key-frame splits of this tile have reached (a.gthr, device-scope atomic max) give the listing threshold sThr
+  int tq_pix = -1, gseen = lp2_enc(-INFINITY);
+  if (t < 64) {
+    const int y = qy0 + (t >> 3), x = qx0 + (t & 7);
+    if (y < H && x < W) { tq_pix = y * W + x; gseen = a.gthr[tq_pix]; }
+    sThr[t] = gseen; sCnt[t] = 0; sEn[t] = 0;
+#pragma unroll
+    for (int i = 0; i < LPX_TOPK; ++i) sTop[i][t] = -INFINITY;
+  }
+
+  // the wave's part in the epilogue: scores of 32 keys (half kh) x 32 queries (half qh); the lane's query
+  const int kh = wave & 1, qhh = wave >> 1;
+  const int myq = qhh * 32 + li;
+  const int qy = qy0 + (myq >> 3), qx = qx0 + (myq & 7);
+  const bool q_in = qy < H && qx < W;
+  const int qpix = q_in ? qy * W + qx : 0;
+  unsigned long long* mylist = a.lists + ((size_t)split * HW + qpix) * a.cap;
+
+  // ---- block sequence: key frames newest first, blocks centre-out.  (cf, ci) = the block being computed, (nf, ni) = the next one
+  int total_blocks = 0;
+  for (int f = f_begin; f < f_end; ++f) total_blocks += lp2_window(a, f, qy0, qx0).nkb;
+  if (total_blocks == 0) return;      // (uniform; cannot happen for a non-empty split)
+  // DMA addressing of a block: lane l of piece p fetches chunk c = (l & 7) ^ ((r >> 1) & 7) of key row r = 8 p + (l >> 3), so that
+  // the piece lands linearly (piece base + 16 l) in the XOR-swizzled layout the conflict-free fragment reads below expect
+  const unsigned lane_off = (unsigned)wave * NG * 64u;
+  int cf = f_end - 1, ci = 0, nf = cf, ni = 1;
+  Lp2Window cw = lp2_window(a, cf, qy0, qx0), nw = cw;
+  // ONE set of row offsets (`off`, `rs`): it names the block whose stages are being REQUESTED - the current block until its last
+  // stage has been requested (two stages before its end), the next block from then on
+  Lp2Off off = lp2_offsets(cw, lp2_block_of(0, cw.nkb), lane, W, rowb, lane_off);
+  vfs_rsrc_words rs = lp2_frame_rsrc(a.hl, cw.slot, HW, rowb);
+  bool has_next = true;
+  if (ni >= nw.nkb) {
+    nf -= 1; ni = 0;
+    if (nf < f_begin) has_next = false;
+    else nw = lp2_window(a, nf, qy0, qx0);
+  }
+  unsigned char* ring = &sRing[wave][0][0];
+  // Pipeline per wave (its own channel quarter, no cross-wave traffic, no barrier): flat stage counter S, stage S lives in ring slot
+  // S % RING, RING - 1 stages are in flight.  `req` counts the stages of the block `off` names that have been requested.
+  int req = 0;
+#pragma unroll
+  for (int d = 0; d < RING - 1; ++d) {      // (NST >= 2 and the prologue stays inside the first block: RING - 1 <= NST is asserted at launch)
+    lp2_issue(rs, off, ring + d * SBYTES, (unsigned)d * 128u);
+    ++req;
+  }
+  int slot = 0;                      // ring slot of the stage about to be consumed
+  __syncthreads();                   // sThr / sCnt initialised
+
+  for (int blk = 0; blk < total_blocks; ++blk) {
+    f32x16 a00, a01, a10, a11;      // [key half][query half] partial scores over this wave's channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a00[r] = 0.f; a01[r] = 0.f; a10[r] = 0.f; a11[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      // stage (blk, s) has landed once at most the stages requested after it are still in flight: RING - 2 of them, fewer at the end
+      {
+        const int left = (NST - 1 - s) + (has_next ? RING : 0);      // stages after this one that exist (capped below)
+        if (left >= RING - 2) vfs_dma_wait<8 * (RING - 2)>();
+        else if (RING > 3 && left == 1) vfs_dma_wait<8>();
+        else vfs_dma_wait<0>();
+      }
+      // refill the slot the previous stage used (its fragment reads fed that stage's MFMAs): stage S + RING - 1
+      if (req == NST && has_next) {      // the current block is fully requested: the next request is the NEXT block's first stage
+        off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb), lane, W, rowb, lane_off);
+        rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
+        req = 0;
+      }
+      if (req < NST) {
+        lp2_issue(rs, off, ring + (slot == 0 ? RING - 1 : slot - 1) * SBYTES, (unsigned)req * 128u);
+        ++req;
+      }
+      const unsigned char* st = ring + slot * SBYTES;
+      const int R0 = li, R1 = 32 + li, sw0 = (R0 >> 1) & 7, sw1 = (R1 >> 1) & 7;
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = 2 * s + gg;
+        const bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((gg * 4 + kgrp) ^ sw0) << 4));
+        const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((gg * 4 + 2 + kgrp) ^ sw0) << 4));
+        const bf16x8 ka1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((gg * 4 + kgrp) ^ sw1) << 4));
+        const bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((gg * 4 + 2 + kgrp) ^ sw1) << 4));
+        // the three products of every tile, four independent accumulators between two MFMAs on the same one
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qh1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ql0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ql1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ql0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ql1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh1[g], a11, 0, 0, 0);
+      }
+      slot = slot == RING - 1 ? 0 : slot + 1;
+      __builtin_amdgcn_sched_barrier(0);      // no motion across stages: the register file is full (Q tile 256 + scores 64 + the stage in flight 32)
+    }
+
+    // ---- the four channel quarters of the 64 x 64 score block meet: tile (kt, qt) belongs to wave kt + 2 qt
+    const int kb = lp2_block_of(ci, cw.nkb);
+    if (t < 64) {
+      const int kk = kb * 64 + t;
+      sKC[t] = kk < cw.nwin ? (((cw.wy0 + kk / cw.ww) << 16) | (cw.wx0 + kk % cw.ww)) : -1;
+    }
+    if (wave != 0) lp2_park(&sRed[0][wave - 1][0][lane], a00);
+    if (wave != 1) lp2_park(&sRed[1][wave < 1 ? wave : wave - 1][0][lane], a10);
+    if (wave != 2) lp2_park(&sRed[2][wave < 2 ? wave : wave - 1][0][lane], a01);
+    if (wave != 3) lp2_park(&sRed[3][wave][0][lane], a11);
+    __syncthreads();
+    f32x16 tot = wave == 0 ? a00 : (wave == 1 ? a10 : (wave == 2 ? a01 : a11));
+#pragma unroll
+    for (int src = 0; src < 3; ++src)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[r] = tot[r] + sRed[wave][src][r][lane];
+    // ---- candidates: circle mask, list everything that may still be in the query's top 10, keep the threshold rising
+    const float thr_e = lp2_dec(sThr[myq]) - a.margin;
+    const int fid = cf * HW;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int pk = sKC[kh * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgrp];
+      const int cy = pk >> 16, cx = pk & 0xffff;
+      bool ok = pk >= 0 && q_in;
+      if (cw.r > 0) {
+        const int dy = cy - qy, dx = cx - qx;
+        ok = ok && (dy * dy + dx * dx < cw.r * cw.r);
+      }
+      const float s = tot[rg];
+      if (ok && s >= thr_e) {
+        const int idx = atomicAdd(&sCnt[myq], 1);
+        if (idx < a.cap)
+          mylist[idx] = ((unsigned long long)(unsigned)(fid + cy * W + cx) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, s);
+        const int e = atomicAdd(&sEn[myq], 1);
+        if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = s;      // (a full queue only delays the threshold: it stays a lower bound)
+      }
+    }
+    __syncthreads();      // sRed / sKC are rewritten by the next block; the block's listed scores are complete
+    if (t < 64 && tq_pix >= 0) {
+      const int n = min(sEn[t], LP2_BLOCK_QUEUE);
+      if (n > 0) {
+        float tv[LPX_TOPK];
+#pragma unroll
+        for (int i = 0; i < LPX_TOPK; ++i) tv[i] = sTop[i][t];
+        for (int e = 0; e < n; ++e) lp2_insert_val(tv, sEq[t][e]);
+#pragma unroll
+        for (int i = 0; i < LPX_TOPK; ++i) sTop[i][t] = tv[i];
+        sEn[t] = 0;
+      }
+      const int mine = lp2_enc(sTop[LPX_TOPK - 1][t]);
+      const int best = max(mine, gseen);
+      // share with the workgroups of the other key-frame splits; what they had reached comes back for the NEXT block (the
+      // returned value is first used one iteration later: the atomic's round trip hides behind a block of MFMAs)
+      if (mine > gseen) gseen = max(best, atomicMax(&a.gthr[tq_pix], mine));
+      else gseen = max(gseen, __hip_atomic_load(&a.gthr[tq_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      sThr[t] = best;      // (ordered before the next epilogue's read by the barrier behind the next block's reduction stores)
+    }
+
+    // ---- advance: (cf, ci) <- (nf, ni), then name the block after it
+    if (blk + 1 < total_blocks) {
+      cf = nf; ci = ni; cw = nw;
+      ni += 1;
+      if (ni >= nw.nkb) {
+        nf -= 1; ni = 0;
+        if (nf < f_begin) has_next = false;
+        else nw = lp2_window(a, nf, qy0, qx0);
+      }
+    }
+  }
+  if (t < 64) {
+    const int y = qy0 + (t >> 3), x = qx0 + (t & 7);
+    if (y < H && x < W) {
+      const int n = sCnt[t];
+      a.counts[(size_t)split * HW + y * W + x] = min(n, a.cap);
+      if (n > a.cap) atomicOr(a.flags, 1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: one WAVE per query (no workgroup barrier: the four waves of a workgroup are independent)
+#define LP2_SURV_CAP 256
+__device__ __forceinline__ void lp2_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
+  __shared__ __attribute__((aligned(16))) float sK[4][64][36];      // 64 survivor rows x a 32-channel chunk (+16 bytes: conflict-free b128 reads)
+  __shared__ __attribute__((aligned(16))) float sQ[4][32];
+  __shared__ unsigned long long sSurv[4][LP2_SURV_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int HW = a.H * a.W, C = a.C;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= HW) return;      // wave-uniform
+  // ---- 1. t = the 10th largest listed s~ (ties count as separate candidates)
+  float tv[LPX_TOPK];
+#pragma unroll
+  for (int i = 0; i < LPX_TOPK; ++i) tv[i] = -INFINITY;
+  for (int sp = 0; sp < a.nsplit; ++sp) {
+    const int n = a.counts[(size_t)sp * HW + q];
+    const unsigned long long* L = a.lists + ((size_t)sp * HW + q) * a.cap;
+    for (int e = lane; e < n; e += 64) lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)L[e]));
+  }
+  float t10 = -INFINITY;
+  for (int k = 0; k < LPX_TOPK; ++k) {
+    float m = tv[0];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d); m = o > m ? o : m; }
+    t10 = m;
+    const unsigned long long holders = __ballot(tv[0] == m && m > -INFINITY);
+    const bool pop = holders != 0 && lane == (int)__ffsll((unsigned long long)holders) - 1;
+#pragma unroll
+    for (int i = 0; i < LPX_TOPK - 1; ++i) tv[i] = pop ? tv[i + 1] : tv[i];
+    tv[LPX_TOPK - 1] = pop ? -INFINITY : tv[LPX_TOPK - 1];
+  }
+  const float thr = t10 - a.margin;      // (fewer than ten candidates: -inf, everything survives)
+  // ---- 2. survivors -> LDS (wave-wide compaction)
+  int nsurv = 0;
+  for (int sp = 0; sp < a.nsplit; ++sp) {
+    const int n = a.counts[(size_t)sp * HW + q];
+    const unsigned long long* L = a.lists + ((size_t)sp * HW + q) * a.cap;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+      const int e = e0 + lane;
+      const unsigned long long ent = e < n ? L[e] : 0ull;
+      const bool keep = e < n && __builtin_bit_cast(float, (unsigned)ent) >= thr;
+      const unsigned long long m = __ballot(keep);
+      const int pos = nsurv + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep && pos < LP2_SURV_CAP) sSurv[wave][pos] = ent;
+      nsurv += __popcll(m);
+    }
+  }
+  if (nsurv > LP2_SURV_CAP) {      // more near-ties than the refinement holds: the dense kernel redoes the frame
+    if (lane == 0) atomicOr(a.flags, 1);
+    return;
+  }
+  lp2_wave_sync();
+  // ---- 3. exact scores: lane j <- survivor j of a batch of 64; rows staged through LDS in 32-channel chunks (8 lanes fetch the
+  // 128 contiguous bytes a row has in a chunk), each lane then runs the defining chain over ITS row
+  float ev[LPX_TOPK];
+  int ei[LPX_TOPK];
+#pragma unroll
+  for (int i = 0; i < LPX_TOPK; ++i) { ev[i] = -INFINITY; ei[i] = LPX_NONE; }
+  const float* qrow = a.fbank + ((size_t)a.qframe * HW + q) * C;
+  for (int b0 = 0; b0 < nsurv; b0 += 64) {
+    const int nb = min(64, nsurv - b0);
+    const int id = lane < nb ? (int)(sSurv[wave][b0 + lane] >> 32) : LPX_NONE;
+    float acc = 0.f;
+    // the rows this lane helps to stage: survivor (8 i + lane / 8) of the batch, i = 0..7
+    const float* srow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 8 * i + (lane >> 3);
+      const int rid = row < nb ? (int)(sSurv[wave][b0 + row] >> 32) : 0;
+      const int fr = rid / HW, px = rid - fr * HW;
+      srow[i] = a.fbank + ((size_t)a.kslot[fr] * HW + px) * C + (lane & 7) * 4;
+    }
+    // the next chunk's rows are requested before the current one is staged and consumed (one global round trip per chunk would
+    // otherwise sit on the wave's critical path: 32 of them per batch for C = 1024)
+    f32x4 v[8], nv[8], qv4, nq4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = lpx_ldf4(srow[i]);      // (rows past the batch: survivor 0's row, never read back)
+    qv4 = lpx_ldf4(qrow + (lane & 7) * 4);
+    for (int c0 = 0; c0 < C; c0 += 32) {
+      const int cn = c0 + 32 < C ? c0 + 32 : c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) nv[i] = lpx_ldf4(srow[i] + cn);
+      nq4 = lpx_ldf4(qrow + cn + (lane & 7) * 4);
+      lp2_wave_sync();      // the previous chunk has been consumed
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&sK[wave][8 * i + (lane >> 3)][(lane & 7) * 4]) = v[i];
+      if (lane < 8) *reinterpret_cast<f32x4*>(&sQ[wave][lane * 4]) = qv4;
+      lp2_wave_sync();
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(&sK[wave][lane][c]);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(&sQ[wave][c]);
+        acc = __builtin_fmaf(kv[0], qv[0], acc);
+        acc = __builtin_fmaf(kv[1], qv[1], acc);
+        acc = __builtin_fmaf(kv[2], qv[2], acc);
+        acc = __builtin_fmaf(kv[3], qv[3], acc);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = nv[i];
+      qv4 = nq4;
+    }
+    if (lane < nb) lpx_insert(ev, ei, acc / a.temperature, id);
+  }
+  // ---- 4. the query's top 10 under the total order (score desc, candidate id asc): ten rounds of a wave-wide arg-best over
+  // the lanes' heads (every lane ends up holding the whole sorted list)
+  float bv[LPX_TOPK];
+  int bi[LPX_TOPK];
+#pragma unroll
+  for (int k = 0; k < LPX_TOPK; ++k) {
+    float mv = ev[0];
+    int mi = ei[0];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ov = __shfl_xor(mv, d);
+      const int oi = __shfl_xor(mi, d);
+      if (lpx_better(ov, oi, mv, mi)) { mv = ov; mi = oi; }
+    }
+    bv[k] = mv; bi[k] = mi;
+    const bool pop = mi != LPX_NONE && ev[0] == mv && ei[0] == mi;      // candidate ids are unique: exactly one lane pops
+#pragma unroll
+    for (int i = 0; i < LPX_TOPK - 1; ++i) { ev[i] = pop ? ev[i + 1] : ev[i]; ei[i] = pop ? ei[i + 1] : ei[i]; }
+    if (pop) { ev[LPX_TOPK - 1] = -INFINITY; ei[LPX_TOPK - 1] = LPX_NONE; }
+  }
+  // ---- 5. softmax over the top-k in sorted order, weighted sum of the values (the arithmetic of labelprop_f32_merge_kernel)
+  float e[LPX_TOPK], z = 0.f;
+#pragma unroll
+  for (int k = 0; k < LPX_TOPK; ++k) {
+    e[k] = (k < a.topk && bi[k] != LPX_NONE && bv[k] > -INFINITY) ? vexp(bv[k] - bv[0]) : 0.f;
+    z = z + e[k];
+  }
+  float* o = a.out + (size_t)q * a.CO;
+  for (int c = lane; c < a.CO; c += 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LPX_TOPK; ++k) {
+      if (e[k] > 0.f) {
+        const int fr = bi[k] / HW, px = bi[k] - fr * HW;
+        s = __builtin_fmaf(e[k] / z, a.sbank[((size_t)a.kslot[fr] * HW + px) * a.CO + c], s);
+      }
+    }
+    o[c] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
+int vfs_option_lp2_wgs = 1024;     // pass 1: workgroups a launch should reach by splitting the key frames (one 1-wave-per-SIMD workgroup per CU)
+int vfs_option_lp2_cap = 256;      // list entries per (key-frame split, query)
+int vfs_option_lp2_xcd = 0;        // pass 1: XCD-aware work order (A/B knob; MI355X: 7.6 instead of 12.4 GB fetched per ResNet-50 frame, but 2.50 vs 2.28 ms)
+
+int vfs_lp2_splits(int H, int W, int nkeys) {
+  const int tiles = ((H + 7) / 8) * ((W + 7) / 8);
+  int nsplit = (vfs_option_lp2_wgs + tiles - 1) / tiles;
+  nsplit = max(1, min(nsplit, min(nkeys, LP2_MAX_SPLIT)));
+  const int fpb = (nkeys + nsplit - 1) / nsplit;
+  return (nkeys + fpb - 1) / fpb;
+}
+
+bool vfs_lp2_eligible(int C) { return vfs_option_lp2 && (C == 256 || C == 512 || C == 1024); }
+
+int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
+  if (!vfs_lp2_eligible(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: C must be 256, 512 or 1024");
+  if (a.nkeys < 1 || a.nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: 1 <= nkeys <= 64");
+  if (a.topk < 1 || a.topk > LPX_TOPK) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: 1 <= topk <= 10");
+  if (a.H >= 32768 || a.W >= 65536 || (long long)a.nkeys * a.H * a.W >= 0x7fffffffLL || (long long)a.H * a.W * a.C * 4 >= 0xFFFFFFF0LL)
+    return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: map too large");
+  if (!(a.temperature > 0.f)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: temperature > 0");
+  // |s~ - s| <= EPS for unit rows: 3 * 2^-16 (the dropped lo.lo product and the two representation remainders, Cauchy-Schwarz) +
+  // 4 * C * 2^-24 (C roundings of the exact chain, <= 3 C of the matrix unit's partial sums); margin = 2 EPS
+  a.margin = 2.0f * (3.0f / 65536.0f + 4.0f * (float)a.C / 16777216.0f);
+  a.cap = vfs_option_lp2_cap;
+  a.nsplit = vfs_lp2_splits(a.H, a.W, a.nkeys);
+  const int tiles = ((a.H + 7) / 8) * ((a.W + 7) / 8);
+  if (hipMemsetAsync(a.flags, 0, sizeof(int), s) != hipSuccess) return vfs_set_error(VFS_ERR_LAUNCH, "labelprop_f32_2pass: hipMemsetAsync");
+  hipLaunchKernelGGL(lp2_seed_kernel, dim3((a.H * a.W + 3) / 4), dim3(256), 0, s, a);
+  int rcs = vfs_check_launch("lp2_seed");
+  if (rcs) return rcs;
+  a.xcd_order = vfs_option_lp2_xcd;
+  if (a.C == 256) hipLaunchKernelGGL(lp2_score_kernel<4>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
+  else if (a.C == 512) hipLaunchKernelGGL(lp2_score_kernel<8>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lp2_score_kernel<16>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
+  int rc = vfs_check_launch("lp2_score");
+  if (rc) return rc;
+  hipLaunchKernelGGL(lp2_refine_kernel, dim3((a.H * a.W + 3) / 4), dim3(256), 0, s, a);
+  return vfs_check_launch("lp2_refine");
+}

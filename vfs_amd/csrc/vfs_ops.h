@@ -262,7 +262,31 @@ struct LabelPropF32Args {
   int H, W, C, CO, radius, topk;
   int non_mask_len;    // leading key frames WITHOUT the spatial mask (with_first_neighbor=False: 1)
   float temperature;
+  const int* run_flag = nullptr;   // device word: when given and zero, the dense kernels exit at once (fallback of the two-pass path)
 };
+// two-pass exact label propagation (labelprop2.hip): bf16 hi/lo prefilter on the matrix cores + exact rescoring of the survivors
+#define LP2_MAX_SPLIT 8      // key-frame splits of pass 1 (= candidate lists per query)
+#define LP2_MAX_CAP 256      // list entries per (split, query): the workspace is sized for this
+#define LP2_RING 3           // LDS stages per wave of pass 1 (RING - 1 in flight)
+#define LP2_BLOCK_QUEUE 16   // scores of one key block queued per query for its running top 10
+struct Lp2Args {
+  const float* fbank;        // [frames][H*W][C] unit rows, fp32 (pass 2: the defining arithmetic)
+  const bf16_t* hl;          // [frames][H*W][C/16][hi 16 | lo 16] bf16 split copy of fbank (vfs_split_rows_bf16x2)
+  const float* sbank;
+  float* out;
+  unsigned long long* lists; // [nsplit][H*W][cap] {score bits (low), candidate id (high)}
+  int* counts;               // [nsplit][H*W]
+  int* flags;                // [0]: != 0 -> a list overflowed, the dense kernel redoes the frame
+  int* gthr;                 // [H*W] running lower bound of every query's 10th-best s~ (monotone int code of the float), shared by the splits
+  int qframe, nkeys;
+  int kslot[LP_MAX_KEYS];
+  int H, W, C, CO, radius, topk, non_mask_len;
+  float temperature, margin;
+  int cap, nsplit, xcd_order;
+};
+int vfs_split_rows_bf16x2_launch(const float* x, bf16_t* hl, long long P, int C, hipStream_t s);
+int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s);
+bool vfs_lp2_eligible(int C);
 int vfs_conv_f32_launch(const ConvF32Args& a, hipStream_t s);
 int vfs_imgs_to_nhwc4_f32_launch(const float* imgs, float* out, int B, int V, int T, int H, int W, hipStream_t s);
 int vfs_maxpool_f32_launch(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);

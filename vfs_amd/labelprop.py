@@ -76,10 +76,18 @@ def _block_feats(bb, ctx_blocks, stages):
     return sel
 
 
-def extract_features(tracker, eng, frames_ncthw, batch_step, all_blocks=False, precision='bf16', with_norm=True):
+def two_pass_ok(precision, with_norm, C):
+    """the two-pass exact label propagation (csrc/labelprop2.hip: bf16 hi/lo prefilter + exact rescoring, same bits as the dense
+    kernel) needs the fp32 path, unit rows and a channel count its register-resident query tile covers; VFS_LP_TWO_PASS=0 keeps
+    the dense kernel (A/B)"""
+    return precision == 'fp32' and with_norm and C in (256, 512, 1024) and os.environ.get('VFS_LP_TWO_PASS', '1') == '1'
+
+
+def extract_features(tracker, eng, frames_ncthw, batch_step, all_blocks=False, precision='bf16', with_norm=True, split_banks=None):
     """imgs [1,3,T,H,W] fp32 -> feature bank [T, h*w, C] of the evaluated stage, L2-normalised over the
     channels unless with_norm=False (bf16 or fp32 by `precision`); with all_blocks (vanilla_tracker.py:32-45,
-    README.md:76) a LIST of banks, one per residual block of every stage in test_cfg.out_indices."""
+    README.md:76) a LIST of banks, one per residual block of every stage in test_cfg.out_indices.
+    split_banks: a list that receives, per bank, its bf16 hi / lo split copy [T, h*w, 2C] (or None) for the two-pass kernels."""
     bb = tracker.backbone
     dev = frames_ncthw.device
     _, _, T, H, W = frames_ncthw.shape
@@ -115,11 +123,17 @@ def extract_features(tracker, eng, frames_ncthw, batch_step, all_blocks=False, p
         if banks is None:
             banks = [torch.empty(T, h * w, C, dtype=F32 if exact else BF16, device=dev) for (_, h, w, C) in feats]
             shapes = [(h, w, C) for (_, h, w, C) in feats]
-        for bank, (feat, h, w, C) in zip(banks, feats):
+            hls = [torch.empty(T, h * w, 2 * C, dtype=BF16, device=dev) if two_pass_ok(precision, with_norm, C) else None
+                   for (_, h, w, C) in feats]
+            if split_banks is not None:
+                split_banks.extend(hls)
+        for bank, hl, (feat, h, w, C) in zip(banks, hls, feats):
             if not with_norm:
                 bank[t0:t0 + n].copy_(feat.reshape(n, h * w, C))
             elif exact:
                 eng.lib.l2norm_rows_f32(feat, bank[t0:t0 + n], n * h * w, C, s)
+                if hl is not None:      # x = hi + lo (bf16 each) of the unit rows: the operands of the two-pass kernel's matrix pass
+                    eng.lib.split_rows_bf16x2(bank[t0:t0 + n], hl[t0:t0 + n], n * h * w, C, s)
             else:
                 eng.lib.l2norm_rows(feat, bank[t0:t0 + n], n * h * w, C, s)
     if all_blocks:
@@ -149,10 +163,11 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
     if topk > 10 or precede + (1 if with_first else 0) > 64:
         raise NotImplementedError(f'label propagation kernels: topk <= 10 (got {topk}), precede_frames + first frame <= 64 '
                                   f'(got {precede + (1 if with_first else 0)})')
+    hls = []
     if all_blocks:
-        banks, shapes = extract_features(tracker, eng, imgs, int(tc.get('batch_step', 10)), True, precision, with_norm)
+        banks, shapes = extract_features(tracker, eng, imgs, int(tc.get('batch_step', 10)), True, precision, with_norm, hls)
     else:
-        bank, h, w, C = extract_features(tracker, eng, imgs, int(tc.get('batch_step', 10)), False, precision, with_norm)
+        bank, h, w, C = extract_features(tracker, eng, imgs, int(tc.get('batch_step', 10)), False, precision, with_norm, hls)
         banks, shapes = [bank], [(h, w, C)]
     s = eng.stream(dev)
     out_h, out_w = img_meta[0]['original_shape'][:2]
@@ -164,7 +179,7 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
     lp = eng.lib.labelprop_f32 if exact else eng.lib.labelprop
     post = eng.lib.seg_postprocess_exact if exact else eng.lib.seg_postprocess
     all_preds = []
-    for bank, (h, w, C) in zip(banks, shapes):
+    for bank, hl, (h, w, C) in zip(banks, hls, shapes):
         if input_onehot:
             # bilinear to the feature size (values) and to the original size (frame 0 of the output); the soft maps of
             # the later frames are returned as they are, without min-max / argmax (vanilla_tracker.py:101-111,167)
@@ -187,8 +202,8 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
         pairs = mask_pairs(h, w, radius)
         partial = eng.ws('ws.segpost', 64 * CO * 2, F32, dev)
         nbytes = torch.zeros(1, dtype=torch.int64)
-        eng.lib.labelprop_workspace_bytes(h, w, nbytes)
-        lpws = eng.ws('ws.labelprop', int(nbytes.item()) // 4, F32, dev)
+        (eng.lib.labelprop_f32_2pass_workspace_bytes if hl is not None else eng.lib.labelprop_workspace_bytes)(h, w, nbytes)
+        lpws = eng.ws('ws.labelprop', (int(nbytes.item()) + 3) // 4, F32, dev)
         for f in range(1, clip_len):
             key_start = max(0, f - precede)
             slots = list(range(key_start, f))
@@ -199,8 +214,12 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
             nmask = len(slots) - non_mask_len
             work = (2.0 * C * (nmask * pairs + non_mask_len * float(h * w) ** 2),          # in-mask affinity FLOP
                     float(bank.element_size()) * (len(set(slots)) + 1) * h * w * C)         # every key / query row once
-            eng.timed('labelprop_f32' if exact else 'labelprop', work, dev, lp, bank, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks, len(slots), h, w,
-                      C, CO, radius, non_mask_len, topk, temp, s)
+            if hl is not None:      # same label maps, bit for bit (csrc/labelprop2.hip)
+                eng.timed('labelprop_f32', work, dev, eng.lib.labelprop_f32_2pass, bank, hl, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks,
+                          len(slots), h, w, C, CO, radius, non_mask_len, topk, temp, 1, s)
+            else:
+                eng.timed('labelprop_f32' if exact else 'labelprop', work, dev, lp, bank, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks, len(slots), h, w,
+                          C, CO, radius, non_mask_len, topk, temp, s)
             if input_onehot:
                 eng.lib.bilinear_resize_f32(sbank[f], preds[f], CO, h, w, out_h, out_w, 1, 0, s)
             else:
