@@ -72,8 +72,8 @@ two()
 torch.cuda.synchronize()
 print('bit-equal to the dense kernel:', bool(torch.equal(out1.view(torch.int32), out2.view(torch.int32))))
 HW = h * w
-lists_bytes = 8 * HW * 256 * 8
-counts = ws.view(torch.int32)[(int(dense.item()) + lists_bytes) // 4:(int(dense.item()) + lists_bytes) // 4 + 8 * HW].reshape(8, HW)
+lists_bytes = 24 * HW * 192 * 8
+counts = ws.view(torch.int32)[(int(dense.item()) + lists_bytes) // 4:(int(dense.item()) + lists_bytes) // 4 + 24 * HW].reshape(24, HW)
 flag = int(ws.view(torch.int32)[(int(n.item()) - 16) // 4])
 per_q = counts.sum(0).float()
 print('overflow flag', flag, '| listed per query: mean %.0f max %d | per (split, query): max %d | splits used %d'

@@ -150,14 +150,21 @@ __global__ __launch_bounds__(256) void lp2_seed_kernel(Lp2Args a) {
 
 struct Lp2Off { unsigned v[8]; };      // byte offsets of the eight DMA pieces of a key block (by value: stays in registers)
 __device__ __forceinline__ Lp2Off lp2_offsets(const Lp2Window& w, int kb, int lane, int W, unsigned rowb, unsigned lane_off) {
+  // the lane's rows are 8 window positions apart: ONE division, then steps of 8 columns (with one wave per SIMD every VALU
+  // instruction of the skeleton is on the critical path - sixteen integer divisions per key block were ~4 k cycles of it)
   Lp2Off o;
+  const int kk0 = kb * 64 + (lane >> 3), last = w.nwin - 1;
+  int ky = kk0 / w.ww, kx = kk0 - ky * w.ww;
+  const int ly = last / w.ww, lx = last - ly * w.ww;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int r = 8 * p + (lane >> 3);
-    const int kk = min(kb * 64 + r, w.nwin - 1);
-    const int ky = w.wy0 + kk / w.ww, kx = w.wx0 + kk % w.ww;
+    const bool past = kk0 + 8 * p > last;      // rows past the window: its last key (their scores are masked)
+    const int yy = w.wy0 + (past ? ly : ky), xx = w.wx0 + (past ? lx : kx);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    o.v[p] = (unsigned)(ky * W + kx) * rowb + lane_off + (unsigned)c * 16u;
+    o.v[p] = (unsigned)(yy * W + xx) * rowb + lane_off + (unsigned)c * 16u;
+    kx += 8;
+    while (kx >= w.ww) { kx -= w.ww; ky += 1; }      // (one iteration unless the window is narrower than 8 columns)
   }
   return o;
 }
@@ -171,18 +178,22 @@ __device__ __forceinline__ void lp2_issue(const vfs_rsrc_words& rs, const Lp2Off
 #pragma unroll
   for (int p = 0; p < 8; ++p) vfs_dma16_async(rs, dst + p * 1024, o.v[p], soff);
 }
-__device__ __forceinline__ void lp2_park(float* dst, const f32x16& v) {
+template <int RH>
+__device__ __forceinline__ void lp2_park(float* dst, const f32x16& v, int r0) {      // dst -> [RH / 4][64 lanes][4]: 16-byte stores
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dst[r * 64] = v[r];
+  for (int r = 0; r < RH; r += 4) *reinterpret_cast<f32x4*>(dst + r * 64) = (f32x4){v[r0 + r], v[r0 + r + 1], v[r0 + r + 2], v[r0 + r + 3]};
 }
 
 // NG = 16-channel groups per wave = C / 64 (4: C = 256, 8: 512, 16: 1024)
 template <int NG>
 __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
-  constexpr int RING = LP2_RING, NST = NG / 2, SBYTES = 64 * 128;
+  // ring depth: with one wave per SIMD the loop runs at (bytes in flight) / (memory latency); three stages in flight for the long
+  // channel loops (C >= 512), two for C = 256 (a key block is two stages; requests run at most one block ahead)
+  constexpr int RING = NG >= 8 ? 4 : 3, NST = NG / 2, SBYTES = 64 * 128;
+  constexpr int RH = RING == 4 ? 8 : 16;      // accumulator registers parked per reduction round (4 stages of ring: LDS for half a tile)
   static_assert(RING >= 3 && RING - 1 <= NST, "the requests run at most one key block ahead");      // a stage = 32 channels (hi + lo) of 64 key rows = 8 KB per wave
   __shared__ __attribute__((aligned(16))) unsigned char sRing[4][RING][SBYTES];
-  __shared__ float sRed[4][3][16][64];      // [owner wave][source rank][accumulator register][lane]
+  __shared__ __attribute__((aligned(16))) float sRed[4][3][RH / 4][64][4];      // [owner wave][source rank][register quad (of a round)][lane][4]
   __shared__ int sKC[64], sThr[64], sCnt[64], sEn[64];
   __shared__ float sEq[64][LP2_BLOCK_QUEUE];      // scores listed for a query in the current key block (feed its running top 10)
   __shared__ float sTop[LPX_TOPK][64];            // the queries' running top 10 of s~ (in LDS: the 512 registers of a lane are taken)
@@ -330,16 +341,24 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       const int kk = kb * 64 + t;
       sKC[t] = kk < cw.nwin ? (((cw.wy0 + kk / cw.ww) << 16) | (cw.wx0 + kk % cw.ww)) : -1;
     }
-    if (wave != 0) lp2_park(&sRed[0][wave - 1][0][lane], a00);
-    if (wave != 1) lp2_park(&sRed[1][wave < 1 ? wave : wave - 1][0][lane], a10);
-    if (wave != 2) lp2_park(&sRed[2][wave < 2 ? wave : wave - 1][0][lane], a01);
-    if (wave != 3) lp2_park(&sRed[3][wave][0][lane], a11);
-    __syncthreads();
     f32x16 tot = wave == 0 ? a00 : (wave == 1 ? a10 : (wave == 2 ? a01 : a11));
 #pragma unroll
-    for (int src = 0; src < 3; ++src)
+    for (int r0 = 0; r0 < 16; r0 += RH) {
+      if (r0 > 0) __syncthreads();      // the previous round has been read
+      if (wave != 0) lp2_park<RH>(&sRed[0][wave - 1][0][lane][0], a00, r0);
+      if (wave != 1) lp2_park<RH>(&sRed[1][wave < 1 ? wave : wave - 1][0][lane][0], a10, r0);
+      if (wave != 2) lp2_park<RH>(&sRed[2][wave < 2 ? wave : wave - 1][0][lane][0], a01, r0);
+      if (wave != 3) lp2_park<RH>(&sRed[3][wave][0][lane][0], a11, r0);
+      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot[r] = tot[r] + sRed[wave][src][r][lane];
+      for (int src = 0; src < 3; ++src)
+#pragma unroll
+        for (int r = 0; r < RH; r += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&sRed[wave][src][r >> 2][lane][0]);
+          tot[r0 + r] = tot[r0 + r] + v[0]; tot[r0 + r + 1] = tot[r0 + r + 1] + v[1];
+          tot[r0 + r + 2] = tot[r0 + r + 2] + v[2]; tot[r0 + r + 3] = tot[r0 + r + 3] + v[3];
+        }
+    }
     // ---- candidates: circle mask, list everything that may still be in the query's top 10, keep the threshold rising
     const float thr_e = lp2_dec(sThr[myq]) - a.margin;
     const int fid = cf * HW;
@@ -405,29 +424,45 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
 
 // ---------------------------------------------------------------------------------------------
 // pass 2: one WAVE per query (no workgroup barrier: the four waves of a workgroup are independent)
-#define LP2_SURV_CAP 256
+#define LP2_ALL_CAP 1024      // listed entries of one query the refinement stages in LDS
 __device__ __forceinline__ void lp2_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
-  __shared__ __attribute__((aligned(16))) float sK[4][64][36];      // 64 survivor rows x a 32-channel chunk (+16 bytes: conflict-free b128 reads)
-  __shared__ __attribute__((aligned(16))) float sQ[4][32];
-  __shared__ unsigned long long sSurv[4][LP2_SURV_CAP];
+  __shared__ __attribute__((aligned(16))) float sQ[4][1024];      // the query row (C <= 1024)
+  __shared__ unsigned long long sSurv[4][LP2_ALL_CAP];      // the query's listed entries, then (compacted in place) its survivors
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W, C = a.C;
   const int q = blockIdx.x * 4 + wave;
   if (q >= HW) return;      // wave-uniform
-  // ---- 1. t = the 10th largest listed s~ (ties count as separate candidates)
+  // ---- 1. all listed entries of the query -> LDS.  Lane l owns the list of key-frame split l: the counts arrive in ONE parallel
+  // load and every lane copies its own few entries (a loop over the splits with a dependent count load each cost a memory round
+  // trip per split and sweep: ~0.1 ms of this kernel)
+  const int cnt = lane < a.nsplit ? a.counts[(size_t)lane * HW + q] : 0;
+  int base = cnt;      // inclusive prefix sum over the lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(base, d);
+    if (lane >= d) base += o;
+  }
+  const int total = __shfl(base, 63);
+  base -= cnt;
+  if (total > LP2_ALL_CAP) {      // more listed candidates than the refinement stages: the dense kernel redoes the frame
+    if (lane == 0) atomicOr(a.flags, 1);
+    return;
+  }
+  {
+    const unsigned long long* L = a.lists + ((size_t)lane * HW + q) * a.cap;
+    for (int e = 0; e < cnt; ++e) sSurv[wave][base + e] = L[e];
+  }
+  lp2_wave_sync();
+  // ---- 2. t = the 10th largest listed s~ (ties count as separate candidates); survivors = {s~ >= t - margin}, compacted in place
   float tv[LPX_TOPK];
 #pragma unroll
   for (int i = 0; i < LPX_TOPK; ++i) tv[i] = -INFINITY;
-  for (int sp = 0; sp < a.nsplit; ++sp) {
-    const int n = a.counts[(size_t)sp * HW + q];
-    const unsigned long long* L = a.lists + ((size_t)sp * HW + q) * a.cap;
-    for (int e = lane; e < n; e += 64) lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)L[e]));
-  }
+  for (int e = lane; e < total; e += 64) lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)sSurv[wave][e]));
   float t10 = -INFINITY;
   for (int k = 0; k < LPX_TOPK; ++k) {
     float m = tv[0];
@@ -441,76 +476,48 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
     tv[LPX_TOPK - 1] = pop ? -INFINITY : tv[LPX_TOPK - 1];
   }
   const float thr = t10 - a.margin;      // (fewer than ten candidates: -inf, everything survives)
-  // ---- 2. survivors -> LDS (wave-wide compaction)
   int nsurv = 0;
-  for (int sp = 0; sp < a.nsplit; ++sp) {
-    const int n = a.counts[(size_t)sp * HW + q];
-    const unsigned long long* L = a.lists + ((size_t)sp * HW + q) * a.cap;
-    for (int e0 = 0; e0 < n; e0 += 64) {
-      const int e = e0 + lane;
-      const unsigned long long ent = e < n ? L[e] : 0ull;
-      const bool keep = e < n && __builtin_bit_cast(float, (unsigned)ent) >= thr;
-      const unsigned long long m = __ballot(keep);
-      const int pos = nsurv + __popcll(m & ((1ull << lane) - 1ull));
-      if (keep && pos < LP2_SURV_CAP) sSurv[wave][pos] = ent;
-      nsurv += __popcll(m);
-    }
+  for (int e0 = 0; e0 < total; e0 += 64) {      // chunk by chunk: a chunk's survivors land at or before the chunk's own positions
+    const int e = e0 + lane;
+    const unsigned long long ent = e < total ? sSurv[wave][e] : 0ull;
+    const bool keep = e < total && __builtin_bit_cast(float, (unsigned)ent) >= thr;
+    const unsigned long long m = __ballot(keep);
+    lp2_wave_sync();      // everybody has read its entry of this chunk
+    if (keep) sSurv[wave][nsurv + __popcll(m & ((1ull << lane) - 1ull))] = ent;
+    nsurv += __popcll(m);
+    lp2_wave_sync();
   }
-  if (nsurv > LP2_SURV_CAP) {      // more near-ties than the refinement holds: the dense kernel redoes the frame
-    if (lane == 0) atomicOr(a.flags, 1);
-    return;
-  }
-  lp2_wave_sync();
-  // ---- 3. exact scores: lane j <- survivor j of a batch of 64; rows staged through LDS in 32-channel chunks (8 lanes fetch the
-  // 128 contiguous bytes a row has in a chunk), each lane then runs the defining chain over ITS row
+  // ---- 3. exact scores: lane j <- survivor j of a batch of 64.  Every lane streams ITS OWN key row - 32 independent 16-byte loads
+  // (128 channels) in flight per lane - and runs the defining chain over it; the query row sits in LDS (broadcast reads).  A
+  // wave-cooperative, LDS-transposed staging of the rows (coalesced, 32 channels per step) was a chain of 32 dependent memory
+  // round trips per batch: 65 us per wave for 21 survivors; the rows are few, latency - not coalescing - is what costs here.
   float ev[LPX_TOPK];
   int ei[LPX_TOPK];
 #pragma unroll
   for (int i = 0; i < LPX_TOPK; ++i) { ev[i] = -INFINITY; ei[i] = LPX_NONE; }
   const float* qrow = a.fbank + ((size_t)a.qframe * HW + q) * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(&sQ[wave][c]) = lpx_ldf4(qrow + c);
+  lp2_wave_sync();
   for (int b0 = 0; b0 < nsurv; b0 += 64) {
-    const int nb = min(64, nsurv - b0);
-    const int id = lane < nb ? (int)(sSurv[wave][b0 + lane] >> 32) : LPX_NONE;
+    const bool on = b0 + lane < nsurv;
+    const int id = on ? (int)(sSurv[wave][b0 + lane] >> 32) : 0;      // (idle lanes: candidate 0's row, result dropped)
+    const int fr = id / HW, px = id - fr * HW;
+    const float* krow = a.fbank + ((size_t)a.kslot[fr] * HW + px) * C;
     float acc = 0.f;
-    // the rows this lane helps to stage: survivor (8 i + lane / 8) of the batch, i = 0..7
-    const float* srow[8];
+    for (int c0 = 0; c0 < C; c0 += 128) {
+      f32x4 kv[32];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 8 * i + (lane >> 3);
-      const int rid = row < nb ? (int)(sSurv[wave][b0 + row] >> 32) : 0;
-      const int fr = rid / HW, px = rid - fr * HW;
-      srow[i] = a.fbank + ((size_t)a.kslot[fr] * HW + px) * C + (lane & 7) * 4;
-    }
-    // the next chunk's rows are requested before the current one is staged and consumed (one global round trip per chunk would
-    // otherwise sit on the wave's critical path: 32 of them per batch for C = 1024)
-    f32x4 v[8], nv[8], qv4, nq4;
+      for (int i = 0; i < 32; ++i) kv[i] = lpx_ldf4(krow + c0 + 4 * i);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = lpx_ldf4(srow[i]);      // (rows past the batch: survivor 0's row, never read back)
-    qv4 = lpx_ldf4(qrow + (lane & 7) * 4);
-    for (int c0 = 0; c0 < C; c0 += 32) {
-      const int cn = c0 + 32 < C ? c0 + 32 : c0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) nv[i] = lpx_ldf4(srow[i] + cn);
-      nq4 = lpx_ldf4(qrow + cn + (lane & 7) * 4);
-      lp2_wave_sync();      // the previous chunk has been consumed
-#pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&sK[wave][8 * i + (lane >> 3)][(lane & 7) * 4]) = v[i];
-      if (lane < 8) *reinterpret_cast<f32x4*>(&sQ[wave][lane * 4]) = qv4;
-      lp2_wave_sync();
-#pragma unroll
-      for (int c = 0; c < 32; c += 4) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(&sK[wave][lane][c]);
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(&sQ[wave][c]);
-        acc = __builtin_fmaf(kv[0], qv[0], acc);
-        acc = __builtin_fmaf(kv[1], qv[1], acc);
-        acc = __builtin_fmaf(kv[2], qv[2], acc);
-        acc = __builtin_fmaf(kv[3], qv[3], acc);
+      for (int i = 0; i < 32; ++i) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(&sQ[wave][c0 + 4 * i]);
+        acc = __builtin_fmaf(kv[i][0], qv[0], acc);
+        acc = __builtin_fmaf(kv[i][1], qv[1], acc);
+        acc = __builtin_fmaf(kv[i][2], qv[2], acc);
+        acc = __builtin_fmaf(kv[i][3], qv[3], acc);
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = nv[i];
-      qv4 = nq4;
     }
-    if (lane < nb) lpx_insert(ev, ei, acc / a.temperature, id);
+    if (on) lpx_insert(ev, ei, acc / a.temperature, id);
   }
   // ---- 4. the query's top 10 under the total order (score desc, candidate id asc): ten rounds of a wave-wide arg-best over
   // the lanes' heads (every lane ends up holding the whole sorted list)
@@ -555,15 +562,24 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
 
 // ---------------------------------------------------------------------------------------------
 int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
-int vfs_option_lp2_wgs = 1024;     // pass 1: workgroups a launch should reach by splitting the key frames (one 1-wave-per-SIMD workgroup per CU)
-int vfs_option_lp2_cap = 256;      // list entries per (key-frame split, query)
+int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
+int vfs_option_lp2_cap = LP2_MAX_CAP;      // list entries per (key-frame split, query)
 int vfs_option_lp2_xcd = 0;        // pass 1: XCD-aware work order (A/B knob; MI355X: 7.6 instead of 12.4 GB fetched per ResNet-50 frame, but 2.50 vs 2.28 ms)
 
+// Key frames per workgroup: about four workgroups per CU and launch (pass 1 runs ONE workgroup per CU at a time: the query tile fills
+// the register file).  Measured on the MI355X, 21 key frames: 1 / 2 / 3 frames per workgroup = 2.21 / 2.24 / 2.27 ms (ResNet-50) and
+// 0.78 / 0.75 / 0.77 (ResNet-18) - flat; two workgroups of 11 frames per tile: 0.92.
 int vfs_lp2_splits(int H, int W, int nkeys) {
   const int tiles = ((H + 7) / 8) * ((W + 7) / 8);
-  int nsplit = (vfs_option_lp2_wgs + tiles - 1) / tiles;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  }
+  int nsplit = (4 * cus + tiles - 1) / tiles;
   nsplit = max(1, min(nsplit, min(nkeys, LP2_MAX_SPLIT)));
-  const int fpb = (nkeys + nsplit - 1) / nsplit;
+  int fpb = (nkeys + nsplit - 1) / nsplit;
+  if (vfs_option_lp2_fpb > 0) fpb = min(nkeys, max(vfs_option_lp2_fpb, (nkeys + LP2_MAX_SPLIT - 1) / LP2_MAX_SPLIT));
   return (nkeys + fpb - 1) / fpb;
 }
 

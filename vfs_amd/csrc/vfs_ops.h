@@ -265,8 +265,8 @@ struct LabelPropF32Args {
   const int* run_flag = nullptr;   // device word: when given and zero, the dense kernels exit at once (fallback of the two-pass path)
 };
 // two-pass exact label propagation (labelprop2.hip): bf16 hi/lo prefilter on the matrix cores + exact rescoring of the survivors
-#define LP2_MAX_SPLIT 8      // key-frame splits of pass 1 (= candidate lists per query)
-#define LP2_MAX_CAP 256      // list entries per (split, query): the workspace is sized for this
+#define LP2_MAX_SPLIT 24     // key-frame splits of pass 1 (= candidate lists per query)
+#define LP2_MAX_CAP 192      // list entries per (split, query): the workspace is sized for this (seeded thresholds: a handful are used)
 #define LP2_RING 3           // LDS stages per wave of pass 1 (RING - 1 in flight)
 #define LP2_BLOCK_QUEUE 16   // scores of one key block queued per query for its running top 10
 struct Lp2Args {
