@@ -119,7 +119,7 @@ def test_list_overflow_falls_back_to_dense(backend):
         lib.set_option(b'lp2_cap', 16)
         run_2pass(backend, feats, seg, 12, 16, 5, [0, 1, 2], 3, expect_fallback=True)
     finally:
-        lib.set_option(b'lp2_cap', 192)
+        lib.set_option(b'lp2_cap', 0)
     run_2pass(backend, feats, seg, 12, 16, 5, [0, 1, 2], 3, expect_fallback=False)
 
 

@@ -78,3 +78,20 @@ flag = int(ws.view(torch.int32)[(int(n.item()) - 16) // 4])
 per_q = counts.sum(0).float()
 print('overflow flag', flag, '| listed per query: mean %.0f max %d | per (split, query): max %d | splits used %d'
       % (per_q.mean(), int(per_q.max()), int(counts.max()), int((counts.sum(1) > 0).sum())))
+
+# every propagation step of a clip (first + up to 20 preceding key frames, as forward_test builds them): time and fallback flag
+print('key frames : two-pass ms, dense-fallback flag')
+for fq in range(1, T):
+    sl = [0] + list(range(max(0, fq - 20), fq))
+    kk = (ctypes.c_int * len(sl))(*sl)
+    def step():
+        lib.labelprop_f32_2pass(bank, hl, sbank, out2, ws, ws.numel() * 4, fq, kk, len(sl), h, w, C, CO, radius, 0, 10, 0.07, 1, s)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    fl = int(ws.view(torch.int32)[(int(n.item()) - 16) // 4])
+    cnts = ws.view(torch.int32)[(int(dense.item()) + lists_bytes) // 4:(int(dense.item()) + lists_bytes) // 4 + 24 * HW].reshape(24, HW)
+    print(f'{len(sl):3d} : {dt:6.3f} ms  flag {fl}  listed per query max {int(cnts.sum(0).max())}')

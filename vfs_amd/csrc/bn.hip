@@ -69,10 +69,13 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const TIN* __restri
 
 // running = (1 - momentum) * running + momentum * statistic (unbiased variance).  A NaN statistic - the poison a failed SyncBN
 // window exchange writes into its sums (vfs_p2p.h) - must not reach the running statistics: they outlive the step (checkpoints).
+// (written with explicit fmaf: the compiler contracted `a * b + c * d` differently in different kernels - the fused and the
+// two-launch finalisation must produce the same bits, tests/test_emu_bn.py::test_bn_chunked_single_launch_reduction)
 __device__ __forceinline__ void bn_running_update(float& rm, float& rv, float momentum, double mean, double unbiased) {
   if (mean != mean || unbiased != unbiased) return;
-  rm = (1.f - momentum) * rm + momentum * (float)mean;
-  rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+  const float keep = 1.f - momentum;
+  rm = __builtin_fmaf(momentum, (float)mean, keep * rm);
+  rv = __builtin_fmaf(momentum, (float)unbiased, keep * rv);
 }
 
 // sums[G][2][C] (sum x, sum x^2; already all-reduced across ranks for SyncBN) + count ->

@@ -64,7 +64,7 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "lp2")) { vfs_option_lp2 = value; return VFS_OK; }
   if (!strcmp(name, "lp2_fpb")) { vfs_option_lp2_fpb = value; return VFS_OK; }
   if (!strcmp(name, "lp2_xcd")) { vfs_option_lp2_xcd = value; return VFS_OK; }
-  if (!strcmp(name, "lp2_cap")) { vfs_option_lp2_cap = value < 16 ? 16 : (value > LP2_MAX_CAP ? LP2_MAX_CAP : value); return VFS_OK; }
+  if (!strcmp(name, "lp2_cap")) { vfs_option_lp2_cap = value <= 0 ? 0 : (value < 16 ? 16 : value); return VFS_OK; }
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_xcd")) { vfs_option_wgrad_xcd = value; return VFS_OK; }

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
 
 // ---------------------------------------------------------------------------------------------
 // pass 2: one WAVE per query (no workgroup barrier: the four waves of a workgroup are independent)
-#define LP2_ALL_CAP 1024      // listed entries of one query the refinement stages in LDS
+#define LP2_SURV_CAP 512      // survivors of one query the refinement stages in LDS
 __device__ __forceinline__ void lp2_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -432,37 +432,24 @@ __device__ __forceinline__ void lp2_wave_sync() {
 }
 __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
   __shared__ __attribute__((aligned(16))) float sQ[4][1024];      // the query row (C <= 1024)
-  __shared__ unsigned long long sSurv[4][LP2_ALL_CAP];      // the query's listed entries, then (compacted in place) its survivors
+  __shared__ unsigned long long sSurv[4][LP2_SURV_CAP];      // the query's survivors
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W, C = a.C;
   const int q = blockIdx.x * 4 + wave;
   if (q >= HW) return;      // wave-uniform
-  // ---- 1. all listed entries of the query -> LDS.  Lane l owns the list of key-frame split l: the counts arrive in ONE parallel
-  // load and every lane copies its own few entries (a loop over the splits with a dependent count load each cost a memory round
-  // trip per split and sweep: ~0.1 ms of this kernel)
+  // ---- 1. t = the 10th largest listed s~ (ties count as separate candidates).  Lane l owns the list of key-frame split l: the
+  // counts arrive in ONE parallel load (a loop over the splits with a dependent count load each cost a memory round trip per
+  // split), every lane walks its own list - a handful of entries once the thresholds are warm, up to the list capacity in the
+  // first steps of a clip (fewer than ten key frames: the seeds cannot reach the top ten)
   const int cnt = lane < a.nsplit ? a.counts[(size_t)lane * HW + q] : 0;
-  int base = cnt;      // inclusive prefix sum over the lanes
+  int maxcnt = cnt;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(base, d);
-    if (lane >= d) base += o;
-  }
-  const int total = __shfl(base, 63);
-  base -= cnt;
-  if (total > LP2_ALL_CAP) {      // more listed candidates than the refinement stages: the dense kernel redoes the frame
-    if (lane == 0) atomicOr(a.flags, 1);
-    return;
-  }
-  {
-    const unsigned long long* L = a.lists + ((size_t)lane * HW + q) * a.cap;
-    for (int e = 0; e < cnt; ++e) sSurv[wave][base + e] = L[e];
-  }
-  lp2_wave_sync();
-  // ---- 2. t = the 10th largest listed s~ (ties count as separate candidates); survivors = {s~ >= t - margin}, compacted in place
+  for (int d = 32; d >= 1; d >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, d));
+  const unsigned long long* L = a.lists + ((size_t)(lane < a.nsplit ? lane : 0) * HW + q) * a.cap;
   float tv[LPX_TOPK];
 #pragma unroll
   for (int i = 0; i < LPX_TOPK; ++i) tv[i] = -INFINITY;
-  for (int e = lane; e < total; e += 64) lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)sSurv[wave][e]));
+  for (int e = 0; e < cnt; ++e) lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)L[e]));
   float t10 = -INFINITY;
   for (int k = 0; k < LPX_TOPK; ++k) {
     float m = tv[0];
@@ -476,17 +463,21 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
     tv[LPX_TOPK - 1] = pop ? -INFINITY : tv[LPX_TOPK - 1];
   }
   const float thr = t10 - a.margin;      // (fewer than ten candidates: -inf, everything survives)
+  // ---- 2. survivors = {s~ >= t - margin} -> LDS (wave-wide compaction, one list position per step)
   int nsurv = 0;
-  for (int e0 = 0; e0 < total; e0 += 64) {      // chunk by chunk: a chunk's survivors land at or before the chunk's own positions
-    const int e = e0 + lane;
-    const unsigned long long ent = e < total ? sSurv[wave][e] : 0ull;
-    const bool keep = e < total && __builtin_bit_cast(float, (unsigned)ent) >= thr;
+  for (int e = 0; e < maxcnt; ++e) {
+    const unsigned long long ent = e < cnt ? L[e] : 0ull;
+    const bool keep = e < cnt && __builtin_bit_cast(float, (unsigned)ent) >= thr;
     const unsigned long long m = __ballot(keep);
-    lp2_wave_sync();      // everybody has read its entry of this chunk
-    if (keep) sSurv[wave][nsurv + __popcll(m & ((1ull << lane) - 1ull))] = ent;
+    const int pos = nsurv + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && pos < LP2_SURV_CAP) sSurv[wave][pos] = ent;
     nsurv += __popcll(m);
-    lp2_wave_sync();
   }
+  if (nsurv > LP2_SURV_CAP) {      // more near-ties than the refinement holds: the dense kernel redoes the frame
+    if (lane == 0) atomicOr(a.flags, 1);
+    return;
+  }
+  lp2_wave_sync();
   // ---- 3. exact scores: lane j <- survivor j of a batch of 64.  Every lane streams ITS OWN key row - 32 independent 16-byte loads
   // (128 channels) in flight per lane - and runs the defining chain over it; the query row sits in LDS (broadcast reads).  A
   // wave-cooperative, LDS-transposed staging of the rows (coalesced, 32 channels per step) was a chain of 32 dependent memory
@@ -563,7 +554,7 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
 // ---------------------------------------------------------------------------------------------
 int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
 int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
-int vfs_option_lp2_cap = LP2_MAX_CAP;      // list entries per (key-frame split, query)
+int vfs_option_lp2_cap = 0;        // list entries per (key-frame split, query); 0 = the workspace shared out among the splits in use
 int vfs_option_lp2_xcd = 0;        // pass 1: XCD-aware work order (A/B knob; MI355X: 7.6 instead of 12.4 GB fetched per ResNet-50 frame, but 2.50 vs 2.28 ms)
 
 // Key frames per workgroup: about four workgroups per CU and launch (pass 1 runs ONE workgroup per CU at a time: the query tile fills
@@ -595,8 +586,10 @@ int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
   // |s~ - s| <= EPS for unit rows: 3 * 2^-16 (the dropped lo.lo product and the two representation remainders, Cauchy-Schwarz) +
   // 4 * C * 2^-24 (C roundings of the exact chain, <= 3 C of the matrix unit's partial sums); margin = 2 EPS
   a.margin = 2.0f * (3.0f / 65536.0f + 4.0f * (float)a.C / 16777216.0f);
-  a.cap = vfs_option_lp2_cap;
   a.nsplit = vfs_lp2_splits(a.H, a.W, a.nkeys);
+  // the list workspace (LP2_MAX_SPLIT x LP2_MAX_CAP entries per query) is shared out among the splits in use: the first steps of a
+  // clip have few key frames (few splits) and cold thresholds (long lists)
+  a.cap = min(vfs_option_lp2_cap > 0 ? vfs_option_lp2_cap : LP2_LIST_MAX, min(LP2_LIST_MAX, LP2_MAX_SPLIT * LP2_MAX_CAP / a.nsplit));
   const int tiles = ((a.H + 7) / 8) * ((a.W + 7) / 8);
   if (hipMemsetAsync(a.flags, 0, sizeof(int), s) != hipSuccess) return vfs_set_error(VFS_ERR_LAUNCH, "labelprop_f32_2pass: hipMemsetAsync");
   hipLaunchKernelGGL(lp2_seed_kernel, dim3((a.H * a.W + 3) / 4), dim3(256), 0, s, a);

@@ -267,6 +267,7 @@ struct LabelPropF32Args {
 // two-pass exact label propagation (labelprop2.hip): bf16 hi/lo prefilter on the matrix cores + exact rescoring of the survivors
 #define LP2_MAX_SPLIT 24     // key-frame splits of pass 1 (= candidate lists per query)
 #define LP2_MAX_CAP 192      // list entries per (split, query): the workspace is sized for this (seeded thresholds: a handful are used)
+#define LP2_LIST_MAX 2048    // longest single list
 #define LP2_RING 3           // LDS stages per wave of pass 1 (RING - 1 in flight)
 #define LP2_BLOCK_QUEUE 16   // scores of one key block queued per query for its running top 10
 struct Lp2Args {
