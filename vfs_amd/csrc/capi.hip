@@ -30,7 +30,7 @@ int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_bn_wide, vfs_option_bn_wide_min_mb;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
-extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target, vfs_option_lpx_wgs, vfs_option_lpx_minb, vfs_option_lp2, vfs_option_lp2_fpb, vfs_option_lp2_cap, vfs_option_lp2_xcd;
+extern int vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target, vfs_option_lpx_wgs, vfs_option_lpx_minb, vfs_option_lp2, vfs_option_lp2_fpb, vfs_option_lp2_cap, vfs_option_lp2_xcd, vfs_option_lp2_dbg;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
   ConvGeom g;
@@ -64,6 +64,7 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "lp2")) { vfs_option_lp2 = value; return VFS_OK; }
   if (!strcmp(name, "lp2_fpb")) { vfs_option_lp2_fpb = value; return VFS_OK; }
   if (!strcmp(name, "lp2_xcd")) { vfs_option_lp2_xcd = value; return VFS_OK; }
+  if (!strcmp(name, "lp2_dbg")) { vfs_option_lp2_dbg = value; return VFS_OK; }
   if (!strcmp(name, "lp2_cap")) { vfs_option_lp2_cap = value <= 0 ? 0 : (value < 16 ? 16 : value); return VFS_OK; }
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
@@ -626,7 +627,7 @@ int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const fl
   p.qframe = qframe; p.nkeys = nkeys;
   for (int i = 0; i < LP_MAX_KEYS; ++i) p.kslot[i] = i < nkeys ? kslot[i] : 0;
   p.H = H; p.W = W; p.C = C; p.CO = CO; p.radius = radius; p.topk = topk; p.non_mask_len = non_mask_len; p.temperature = temperature;
-  p.margin = 0.f; p.cap = 0; p.nsplit = 0; p.xcd_order = 0;
+  p.margin = 0.f; p.cap = 0; p.nsplit = 0; p.xcd_order = 0; p.dbg = 0;
   int rc = vfs_labelprop_f32_2pass_launch(p, S(stream));
   if (rc) return rc;
   // the dense kernel as the overflow fallback: its workgroups read the flag and leave when no list overflowed

@@ -174,9 +174,49 @@ __device__ __forceinline__ Lp2Off lp2_offsets(const Lp2Window& w, int kb, int la
 __device__ __forceinline__ vfs_rsrc_words lp2_frame_rsrc(const bf16_t* hl, int slot, int HW, unsigned rowb) {
   return vfs_make_rsrc_words(reinterpret_cast<const unsigned char*>(hl) + (size_t)slot * HW * rowb, (unsigned)HW * rowb);
 }
+// the eight pieces of a stage as ONE burst: M0 (the LDS base of a piece) is saved and restored once and stepped by 1 KB between the
+// pieces - vfs_dma16_async saves / sets / restores it around every piece (5 scalar instructions and two M0 reads per KB), and in
+// this kernel the issue path of the DMA pieces, not the memory behind them, is what the matrix pipe waits for (what-if with
+// cache-hot key rows: 1.23 vs 1.34 ms)
 __device__ __forceinline__ void lp2_issue(const vfs_rsrc_words& rs, const Lp2Off& o, unsigned char* dst, unsigned soff) {
+#ifndef VFS_EMU
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)dst);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %6, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %7, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %8, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %9, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %10, %2, %3 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %11, %2, %3 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "s"(rs), "s"(soff), "v"(o.v[0]), "v"(o.v[1]), "v"(o.v[2]), "v"(o.v[3]), "v"(o.v[4]), "v"(o.v[5]), "v"(o.v[6]), "v"(o.v[7])
+      : "memory", "scc");
+#else
 #pragma unroll
   for (int p = 0; p < 8; ++p) vfs_dma16_async(rs, dst + p * 1024, o.v[p], soff);
+#endif
 }
 template <int RH>
 __device__ __forceinline__ void lp2_park(float* dst, const f32x16& v, int r0) {      // dst -> [RH / 4][64 lanes][4]: 16-byte stores
@@ -300,8 +340,10 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       }
       // refill the slot the previous stage used (its fragment reads fed that stage's MFMAs): stage S + RING - 1
       if (req == NST && has_next) {      // the current block is fully requested: the next request is the NEXT block's first stage
-        off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb), lane, W, rowb, lane_off);
-        rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
+        if (!(a.dbg & 2)) {      // (what-if timing, WRONG results: every block re-reads the first block's rows - cache-hot key traffic)
+          off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb), lane, W, rowb, lane_off);
+          rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
+        }
         req = 0;
       }
       if (req < NST) {
@@ -372,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
         ok = ok && (dy * dy + dx * dx < cw.r * cw.r);
       }
       const float s = tot[rg];
-      if (ok && s >= thr_e) {
+      if (ok && s >= thr_e && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
         const int idx = atomicAdd(&sCnt[myq], 1);
         if (idx < a.cap)
           mylist[idx] = ((unsigned long long)(unsigned)(fid + cy * W + cx) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, s);
@@ -553,6 +595,7 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
 
 // ---------------------------------------------------------------------------------------------
 int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
+int vfs_option_lp2_dbg = 0;        // what-if timing (WRONG results): 2 = cache-hot key traffic, 4 = no lists
 int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
 int vfs_option_lp2_cap = 0;        // list entries per (key-frame split, query); 0 = the workspace shared out among the splits in use
 int vfs_option_lp2_xcd = 0;        // pass 1: XCD-aware work order (A/B knob; MI355X: 7.6 instead of 12.4 GB fetched per ResNet-50 frame, but 2.50 vs 2.28 ms)
@@ -596,6 +639,7 @@ int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
   int rcs = vfs_check_launch("lp2_seed");
   if (rcs) return rcs;
   a.xcd_order = vfs_option_lp2_xcd;
+  a.dbg = vfs_option_lp2_dbg;
   if (a.C == 256) hipLaunchKernelGGL(lp2_score_kernel<4>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
   else if (a.C == 512) hipLaunchKernelGGL(lp2_score_kernel<8>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(lp2_score_kernel<16>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);

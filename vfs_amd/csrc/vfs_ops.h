@@ -283,7 +283,7 @@ struct Lp2Args {
   int kslot[LP_MAX_KEYS];
   int H, W, C, CO, radius, topk, non_mask_len;
   float temperature, margin;
-  int cap, nsplit, xcd_order;
+  int cap, nsplit, xcd_order, dbg;
 };
 int vfs_split_rows_bf16x2_launch(const float* x, bf16_t* hl, long long P, int C, hipStream_t s);
 int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s);
