@@ -335,6 +335,7 @@ inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 // lanes are fibers here, not lockstep: the (code-free on hardware) wave barrier is a real rendezvous
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 
 template <typename T>
 inline T __shfl(T v, int src, int width = 64) {

@@ -174,6 +174,47 @@ __device__ __forceinline__ Lp2Off lp2_offsets(const Lp2Window& w, int kb, int la
 __device__ __forceinline__ vfs_rsrc_words lp2_frame_rsrc(const bf16_t* hl, int slot, int HW, unsigned rowb) {
   return vfs_make_rsrc_words(reinterpret_cast<const unsigned char*>(hl) + (size_t)slot * HW * rowb, (unsigned)HW * rowb);
 }
+// LDS-DMA pieces of a stage issued one at a time between MFMAs: M0 (the LDS base of a piece) is saved at lp2_burst_begin and
+// restored at lp2_burst_end; nothing the compiler emits in between uses M0 (gfx9+ LDS instructions do not)
+#ifndef LP2_INTERLEAVE
+#define LP2_INTERLEAVE 0      // 1: the DMA pieces of a stage between its first MFMAs, 0: as one burst in front of them (MI355X: 1.29 vs 1.25 ms)
+#endif
+struct Lp2Burst {
+  unsigned keep, lds;
+  unsigned char* dst;      // (host emulation: the destination as a pointer)
+};
+__device__ __forceinline__ Lp2Burst lp2_burst_begin(unsigned char* dst) {
+  Lp2Burst b;
+  b.dst = dst;
+#ifndef VFS_EMU
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  b.lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)dst);
+  asm volatile("s_mov_b32 %0, m0" : "=s"(b.keep));
+#else
+  b.keep = 0;
+  b.lds = 0;
+#endif
+  return b;
+}
+__device__ __forceinline__ void lp2_piece(const Lp2Burst& b, const vfs_rsrc_words& rs, unsigned voff, unsigned soff, int p) {
+#ifndef VFS_EMU
+  const unsigned addr = b.lds + (unsigned)p * 1024u;
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %3 offen lds"
+      :
+      : "s"(addr), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+#else
+  vfs_dma16_async(rs, b.dst + p * 1024, voff, soff);
+#endif
+}
+__device__ __forceinline__ void lp2_burst_end(const Lp2Burst& b) {
+#ifndef VFS_EMU
+  asm volatile("s_mov_b32 m0, %0" ::"s"(b.keep));
+#endif
+}
 // the eight pieces of a stage as ONE burst: M0 (the LDS base of a piece) is saved and restored once and stepped by 1 KB between the
 // pieces - vfs_dma16_async saves / sets / restores it around every piece (5 scalar instructions and two M0 reads per KB), and in
 // this kernel the issue path of the DMA pieces, not the memory behind them, is what the matrix pipe waits for (what-if with
@@ -275,6 +316,11 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       ql1[g] = *reinterpret_cast<const bf16x8*>(bb + g * 32 + 16);
     }
   }
+  // The query fragments have ARRIVED before the loop starts, and the compiler must know it: its wait-count pass otherwise keeps a
+  // `s_waitcnt vmcnt(n)` in front of the first use of every fragment INSIDE the loop body (n counting down to 0 over the unrolled
+  // stages) - and those waits also cover the untracked LDS-DMA pieces in flight: the key pipeline was drained once per key block
+  // (found in the ISA; the kernel took 2.1 instead of ~1.3 ms for the 21-key ResNet-50 frame).
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), nothing else
   // the query's running top 10 of s~ (sTop, maintained by lane t of wave 0); its 10th entry, the seed and what the other
   // key-frame splits of this tile have reached (a.gthr, device-scope atomic max) give the listing threshold sThr
   int tq_pix = -1, gseen = lp2_enc(-INFINITY);
@@ -338,7 +384,9 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
         else if (RING > 3 && left == 1) vfs_dma_wait<8>();
         else vfs_dma_wait<0>();
       }
-      // refill the slot the previous stage used (its fragment reads fed that stage's MFMAs): stage S + RING - 1
+      // refill the slot the previous stage used (its fragment reads fed that stage's MFMAs): stage S + RING - 1.  The eight DMA
+      // pieces are issued BETWEEN the first MFMAs of this stage, one per MFMA (a piece takes about as long to issue as an MFMA to
+      // execute; as one burst in front of the MFMAs the matrix pipe idled for the whole burst - one wave per SIMD, in-order issue)
       if (req == NST && has_next) {      // the current block is fully requested: the next request is the NEXT block's first stage
         if (!(a.dbg & 2)) {      // (what-if timing, WRONG results: every block re-reads the first block's rows - cache-hot key traffic)
           off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb), lane, W, rowb, lane_off);
@@ -346,20 +394,58 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
         }
         req = 0;
       }
-      if (req < NST) {
-        lp2_issue(rs, off, ring + (slot == 0 ? RING - 1 : slot - 1) * SBYTES, (unsigned)req * 128u);
-        ++req;
-      }
+      const bool dma = req < NST;
+      const unsigned soff = (unsigned)req * 128u;
+      unsigned char* pdst = ring + (slot == 0 ? RING - 1 : slot - 1) * SBYTES;
+      if (dma) ++req;
       const unsigned char* st = ring + slot * SBYTES;
       const int R0 = li, R1 = 32 + li, sw0 = (R0 >> 1) & 7, sw1 = (R1 >> 1) & 7;
-#pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const int g = 2 * s + gg;
-        const bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((gg * 4 + kgrp) ^ sw0) << 4));
-        const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((gg * 4 + 2 + kgrp) ^ sw0) << 4));
-        const bf16x8 ka1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((gg * 4 + kgrp) ^ sw1) << 4));
-        const bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((gg * 4 + 2 + kgrp) ^ sw1) << 4));
-        // the three products of every tile, four independent accumulators between two MFMAs on the same one
+      bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + ((kgrp ^ sw0) << 4));
+      bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((2 + kgrp) ^ sw0) << 4));
+      bf16x8 ka1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + ((kgrp ^ sw1) << 4));
+      bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((2 + kgrp) ^ sw1) << 4));
+#if LP2_INTERLEAVE
+      const Lp2Burst burst = lp2_burst_begin(pdst);
+#else
+      if (dma) lp2_issue(rs, off, pdst, soff);
+#endif
+      {
+        const int g = 2 * s;
+#if LP2_INTERLEAVE
+#define LP2_PIECE(P) if (dma) lp2_piece(burst, rs, off.v[P], soff, P);
+#else
+#define LP2_PIECE(P)
+#endif
+#define LP2_STEP(ACC, KF, QF, P)                                            \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KF, QF, ACC, 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        LP2_PIECE(P)
+        LP2_STEP(a00, ka0, qh0[g], 0)
+        LP2_STEP(a01, ka0, qh1[g], 1)
+        LP2_STEP(a10, ka1, qh0[g], 2)
+        LP2_STEP(a11, ka1, qh1[g], 3)
+        LP2_STEP(a00, ka0, ql0[g], 4)
+        LP2_STEP(a01, ka0, ql1[g], 5)
+        LP2_STEP(a10, ka1, ql0[g], 6)
+        LP2_STEP(a11, ka1, ql1[g], 7)
+#undef LP2_STEP
+#undef LP2_PIECE
+        __builtin_amdgcn_sched_barrier(0);
+#if LP2_INTERLEAVE
+        lp2_burst_end(burst);
+#endif
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh1[g], a11, 0, 0, 0);
+      }
+      {
+        const int g = 2 * s + 1;
+        ka0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((4 + kgrp) ^ sw0) << 4));
+        kl0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((6 + kgrp) ^ sw0) << 4));
+        ka1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((4 + kgrp) ^ sw1) << 4));
+        kl1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((6 + kgrp) ^ sw1) << 4));
         a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qh0[g], a00, 0, 0, 0);
         a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qh1[g], a01, 0, 0, 0);
         a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qh0[g], a10, 0, 0, 0);
@@ -438,8 +524,10 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       const int best = max(mine, gseen);
       // share with the workgroups of the other key-frame splits; what they had reached comes back for the NEXT block (the
       // returned value is first used one iteration later: the atomic's round trip hides behind a block of MFMAs)
-      if (mine > gseen) gseen = max(best, atomicMax(&a.gthr[tq_pix], mine));
-      else gseen = max(gseen, __hip_atomic_load(&a.gthr[tq_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (!(a.dbg & 8)) {      // (dbg 8: what-if without the exchange between the splits)
+        if (mine > gseen) gseen = max(best, atomicMax(&a.gthr[tq_pix], mine));
+        else gseen = max(gseen, __hip_atomic_load(&a.gthr[tq_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
       sThr[t] = best;      // (ordered before the next epilogue's read by the barrier behind the next block's reduction stores)
     }
 
