@@ -268,9 +268,8 @@ __device__ __forceinline__ void lp2_park(float* dst, const f32x16& v, int r0) { 
 // NG = 16-channel groups per wave = C / 64 (4: C = 256, 8: 512, 16: 1024)
 template <int NG>
 __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
-  // ring depth: with one wave per SIMD the loop runs at (bytes in flight) / (memory latency); three stages in flight for the long
-  // channel loops (C >= 512), two for C = 256 (a key block is two stages; requests run at most one block ahead)
-  constexpr int RING = NG >= 8 ? 4 : 3, NST = NG / 2, SBYTES = 64 * 128;
+  // (a fourth stage - three in flight, the reduction in two rounds to make room - measured the same 2.28 ms: kept at three)
+  constexpr int RING = LP2_RING, NST = NG / 2, SBYTES = 64 * 128;
   constexpr int RH = RING == 4 ? 8 : 16;      // accumulator registers parked per reduction round (4 stages of ring: LDS for half a tile)
   static_assert(RING >= 3 && RING - 1 <= NST, "the requests run at most one key block ahead");      // a stage = 32 channels (hi + lo) of 64 key rows = 8 KB per wave
   __shared__ __attribute__((aligned(16))) unsigned char sRing[4][RING][SBYTES];
@@ -487,25 +486,31 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
           tot[r0 + r + 2] = tot[r0 + r + 2] + v[2]; tot[r0 + r + 3] = tot[r0 + r + 3] + v[3];
         }
     }
-    // ---- candidates: circle mask, list everything that may still be in the query's top 10, keep the threshold rising
+    // ---- candidates: circle mask, list everything that may still be in the query's top 10.  Once the threshold is warm almost no
+    // candidate passes: the sixteen tests run branch-free and the listing code is entered only by waves that have something to list
     const float thr_e = lp2_dec(sThr[myq]) - a.margin;
     const int fid = cf * HW;
+    unsigned passmask = 0;
+    int ids[16];
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
       const int pk = sKC[kh * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgrp];
       const int cy = pk >> 16, cx = pk & 0xffff;
-      bool ok = pk >= 0 && q_in;
-      if (cw.r > 0) {
-        const int dy = cy - qy, dx = cx - qx;
-        ok = ok && (dy * dy + dx * dx < cw.r * cw.r);
-      }
-      const float s = tot[rg];
-      if (ok && s >= thr_e && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
-        const int idx = atomicAdd(&sCnt[myq], 1);
-        if (idx < a.cap)
-          mylist[idx] = ((unsigned long long)(unsigned)(fid + cy * W + cx) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, s);
-        const int e = atomicAdd(&sEn[myq], 1);
-        if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = s;      // (a full queue only delays the threshold: it stays a lower bound)
+      const int dy = cy - qy, dx = cx - qx;
+      const bool ok = pk >= 0 && q_in && (cw.r <= 0 || dy * dy + dx * dx < cw.r * cw.r);
+      ids[rg] = fid + cy * W + cx;
+      passmask |= (ok && tot[rg] >= thr_e) ? 1u << rg : 0u;
+    }
+    if (__any(passmask != 0) && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        if (passmask & (1u << rg)) {
+          const float sc = tot[rg];
+          const int idx = atomicAdd(&sCnt[myq], 1);
+          if (idx < a.cap) mylist[idx] = ((unsigned long long)(unsigned)ids[rg] << 32) | (unsigned long long)__builtin_bit_cast(unsigned, sc);
+          const int e = atomicAdd(&sEn[myq], 1);
+          if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = sc;      // (a full queue only delays the threshold: it stays a lower bound)
+        }
       }
     }
     __syncthreads();      // sRed / sKC are rewritten by the next block; the block's listed scores are complete
