@@ -100,7 +100,9 @@ __device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0
   w.nkb = (w.nwin + 63) >> 6;
   return w;
 }
-__device__ __forceinline__ int lp2_block_of(int i, int nkb) {      // i-th block in centre-out order
+__device__ __forceinline__ int lp2_block_of(int i, int nkb, int stagger = 0) {      // i-th block in centre-out order
+  i += stagger;                    // (XCD-aware order: neighbouring tiles run `stagger` blocks apart, so that one FETCHES a key row
+  if (i >= nkb) i -= nkb;          //  and the next HITS it instead of both waiting for the same line in flight)
   const int mid = (nkb - 1) >> 1, off = (i + 1) >> 1;
   return (i & 1) ? mid + off : mid - off;
 }
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   const int trow = lb / (a.nsplit * tiles_x), rem = lb - trow * (a.nsplit * tiles_x);
   const int split = rem / tiles_x, tcol = rem - split * tiles_x;
   const int qy0 = trow * 8, qx0 = tcol * 8;
+  const int stag = a.xcd_order >= 2 ? min(a.xcd_order - 1, 3) * (tcol & 1) : 0;      // (nkb >= 4 for every window this path sees)
   const int fpb = (a.nkeys + a.nsplit - 1) / a.nsplit;
   const int f_begin = split * fpb, f_end = min(a.nkeys, f_begin + fpb);
   const unsigned rowb = (unsigned)C * 4u;      // bytes of one split row (hi + lo)
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   Lp2Window cw = lp2_window(a, cf, qy0, qx0), nw = cw;
   // ONE set of row offsets (`off`, `rs`): it names the block whose stages are being REQUESTED - the current block until its last
   // stage has been requested (two stages before its end), the next block from then on
-  Lp2Off off = lp2_offsets(cw, lp2_block_of(0, cw.nkb), lane, W, rowb, lane_off);
+  Lp2Off off = lp2_offsets(cw, lp2_block_of(0, cw.nkb, stag), lane, W, rowb, lane_off);
   vfs_rsrc_words rs = lp2_frame_rsrc(a.hl, cw.slot, HW, rowb);
   bool has_next = true;
   if (ni >= nw.nkb) {
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       // execute; as one burst in front of the MFMAs the matrix pipe idled for the whole burst - one wave per SIMD, in-order issue)
       if (req == NST && has_next) {      // the current block is fully requested: the next request is the NEXT block's first stage
         if (!(a.dbg & 2)) {      // (what-if timing, WRONG results: every block re-reads the first block's rows - cache-hot key traffic)
-          off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb), lane, W, rowb, lane_off);
+          off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off);
           rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
         }
         req = 0;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     }
 
     // ---- the four channel quarters of the 64 x 64 score block meet: tile (kt, qt) belongs to wave kt + 2 qt
-    const int kb = lp2_block_of(ci, cw.nkb);
+    const int kb = lp2_block_of(ci, cw.nkb, stag);
     if (t < 64) {
       const int kk = kb * 64 + t;
       sKC[t] = kk < cw.nwin ? (((cw.wy0 + kk / cw.ww) << 16) | (cw.wx0 + kk % cw.ww)) : -1;
