@@ -436,6 +436,22 @@ inline v4s ds_read_tr16_b64(uintptr_t p) {
 }
 }  // namespace emu
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16_b64((uintptr_t)(p))
+namespace emu {
+inline unsigned raw_buffer_load_b32(rsrc_t r, unsigned voff, unsigned soff, int aux) {
+  (void)aux;
+  unsigned v = 0;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 4 <= r.num_records) memcpy(&v, r.base + o, 4);
+  return v;
+}
+inline void raw_buffer_store_b32(unsigned v, rsrc_t r, unsigned voff, unsigned soff, int aux) {
+  (void)aux;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 4 <= r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 4);      // out of range: dropped, as the hardware
+}
+}  // namespace emu
+#define __builtin_amdgcn_raw_buffer_load_b32 emu::raw_buffer_load_b32
+#define __builtin_amdgcn_raw_buffer_store_b32 emu::raw_buffer_store_b32
 #define __amdgpu_buffer_rsrc_t emu::rsrc_t
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128

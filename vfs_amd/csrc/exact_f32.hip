@@ -31,22 +31,31 @@ __device__ __forceinline__ f32x4 zerof4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; 
 // workgroup = 128 output pixels x 64 output channels, K in chunks of CONV_F32_BK (kh, kw, cin ascending);
 // wave (w&1, w>>1) owns 64 pixels x 32 channels = two 32x32x2 MFMA tiles (A = pixels, B = channels)
 // LDS image [k][row]: lane (i = l&31, kk = l>>5) of MFMA step s reads element [2s + kk][row0 + i]
-#ifndef CONV_F32_BK
-#define CONV_F32_BK 32     // channels per chunk: 32 MFMAs per wave between two barriers (16: DAVIS R50 5.21-5.22 vs 5.15-5.18 ms per frame, R18 1.45 vs 1.41)
-#endif
-__global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
-  constexpr int BM = 128, BN = 64, BK = CONV_F32_BK, G = BK / 4, RPP = 256 / G;   // float4 groups per row and chunk, rows per loader pass
+// BK = channels per chunk: BK MFMAs per wave between two barriers (16: DAVIS R50 5.21-5.22 vs 5.15-5.18 ms per frame, R18 1.45 vs 1.41)
+// PF = chunks of global loads in flight in registers (1: the next chunk is requested while this one is multiplied; 2: the one after it too)
+template <int BK, int PF>
+__global__ __launch_bounds__(256, 5 - BK / 32 - (PF - 1)) void conv_f32_kernel(ConvF32Args a) {
+  constexpr int BM = 128, BN = 64, G = BK / 4, RPP = 256 / G;   // float4 groups per row and chunk, rows per loader pass
   // LDS planes [k][row], PAD dwords of padding per plane: MFMA step s reads plane 2s + (lane >> 5), 32 consecutive dwords per
   // half-wave - conflict-free; a half-wave of the loaders' ds_write_b32 covers 32 / G rows x G float4 groups at plane 4 * group + e:
   // bank (4 * group * (rows + PAD) + row) mod 32 = 8 * group + row (BK 16, PAD 2) or 4 * group + row (BK 32, PAD 1) - 32 different
-  constexpr int PAD = CONV_F32_BK == 16 ? 2 : 1;
+  constexpr int PAD = BK == 16 ? 2 : 1;
   constexpr int PA = BM + PAD, PB = BN + PAD;
   __shared__ float sA[BK * PA];
   __shared__ float sB[BK * PB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long long M = (long long)a.N * a.Ho * a.Wo;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order (1-D grid): workgroup L runs on XCD L % 8; on ONE XCD consecutive workgroups take the channel tiles of
+  // ONE pixel tile, so the gathered pixels are fetched from HBM once and served to the other channel tiles by that XCD's L2
+  // (pixel tile fastest, as the 2-D grid had it, spread the channel tiles of a pixel tile over the whole launch: 630 MB fetched
+  // per launch for 124 MB of operands, round 3 counters)
+  const int NT = (a.Cout + BN - 1) / BN;
+  const long long MT = (M + BM - 1) / BM;
+  const long long slot = blockIdx.x >> 3;
+  const long long mt = (slot / NT) * 8 + (blockIdx.x & 7);
+  if (mt >= MT) return;
+  const long long m0 = mt * BM;
+  const int n0 = (int)(slot % NT) * BN;
   const int C4 = a.Cin >> 2;
   const int K4 = a.KH * a.KW * C4;           // float4 groups along K
   // loaders: G CONSECUTIVE LANES read the 4 * BK contiguous bytes one row has in a chunk (thread = row t / G, float4 group t % G):
@@ -56,19 +65,23 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   // A: pixels t / G + RPP * i
   constexpr int NA = BM / RPP, NB = BN / RPP;
   const int ap = t / G;
-  bool a_ok[NA];
-  int an[NA], iy0[NA], ix0[NA];
+  // Address arithmetic of the gather, kept OUT of the chunk loop: per row the element offset of its window origin
+  // ((n H + iy0) W + ix0) Cin (may be negative: signed), per chunk ONE uniform delta for the tap and channel group; the tap / channel
+  // counters advance incrementally (no division per chunk).  SQ counters (round 4): 5.2 vector instructions per MFMA, and the
+  // fp32-input MFMA executes on the vector lanes - every one of them is matrix time lost (59 % of the fp32 MFMA peak).
+  int iy0[NA], ix0[NA];
+  long long abase[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const long long am = m0 + ap + RPP * i;
-    a_ok[i] = am < M;
-    an[i] = 0; iy0[i] = 0; ix0[i] = 0;
-    if (a_ok[i]) {
+    iy0[i] = -(1 << 28); ix0[i] = -(1 << 28); abase[i] = 0;      // rows past M: every tap is out of range
+    if (am < M) {
       const int hw = a.Ho * a.Wo;
-      an[i] = (int)(am / hw);
-      const int rem = (int)(am - (long long)an[i] * hw);
+      const int n = (int)(am / hw);
+      const int rem = (int)(am - (long long)n * hw);
       const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
       iy0[i] = oy * a.stride - a.pad; ix0[i] = ox * a.stride - a.pad;
+      abase[i] = (((long long)n * a.H + iy0[i]) * a.W + ix0[i]) * a.Cin;
     }
   }
   // B: output channels t / G + RPP * i
@@ -81,26 +94,28 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
     wrow[i] = a.w + (size_t)(b_ok[i] ? n0 + bc + RPP * i : 0) * K4 * 4;
   }
 
-  f32x4 ra[NA], rb[NB];
-  auto load = [&](int chunk) {
-    const int k4 = chunk * G + lq;
-    const bool k_ok = k4 < K4;
-    const int tap = k_ok ? k4 / C4 : 0, c = (k4 - tap * C4) * 4;
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  f32x4 ra[PF][NA], rb[PF][NB];
+  // this thread's float4 group of the NEXT chunk to load: k4 = chunk * G + lq -> (kh, kw, c4), advanced by G groups per chunk
+  int l_k4 = lq, l_c4 = lq % C4, l_tap = lq / C4, l_kh = l_tap / a.KW, l_kw = l_tap - l_kh * a.KW;
+  auto load = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {      // called for chunk 0, 1, 2, ... in order
+    const bool k_ok = l_k4 < K4;
+    const int dy = l_kh * a.dil, dx = l_kw * a.dil;
+    const long long delta = ((long long)dy * a.W + dx) * a.Cin + l_c4 * 4;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       f32x4 v = zerof4();
-      if (a_ok[i] && k_ok) {
-        const int iy = iy0[i] + kh * a.dil, ix = ix0[i] + kw * a.dil;
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          v = ldf4(a.x + (((size_t)an[i] * a.H + iy) * a.W + ix) * a.Cin + c);
-      }
+      if (k_ok && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W) v = ldf4(a.x + (abase[i] + delta));
       ra[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = (b_ok[i] && k_ok) ? ldf4(wrow[i] + (size_t)k4 * 4) : zerof4();
+    for (int i = 0; i < NB; ++i) rb[i] = (b_ok[i] && k_ok) ? ldf4(wrow[i] + (size_t)l_k4 * 4) : zerof4();
+    l_k4 += G; l_c4 += G;
+    while (l_c4 >= C4) {      // (at most once unless Cin < 32)
+      l_c4 -= C4;
+      if (++l_kw == a.KW) { l_kw = 0; ++l_kh; }
+    }
   };
-  auto store = [&]() {
+  auto store = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -118,19 +133,26 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   const int wp0 = (wave & 1) * 64, wc0 = (wave >> 1) * 32;
   const int li = lane & 31, lk = lane >> 5;
   const int nchunks = (K4 + G - 1) / G;
-  load(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    store();
-    __syncthreads();
-    if (ch + 1 < nchunks) load(ch + 1);
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      const float b = sB[(2 * s + lk) * PB + wc0 + li];
-      const float a0 = sA[(2 * s + lk) * PA + wp0 + li], a1 = sA[(2 * s + lk) * PA + wp0 + 32 + li];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+  for (int u = 0; u < PF; ++u)
+    if (u < nchunks) load(ra[u], rb[u]);
+  for (int ch = 0; ch < nchunks; ch += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (ch + u < nchunks) {
+        store(ra[u], rb[u]);
+        __syncthreads();
+        if (ch + u + PF < nchunks) load(ra[u], rb[u]);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+          const float b = sB[(2 * s + lk) * PB + wc0 + li];
+          const float a0 = sA[(2 * s + lk) * PA + wp0 + li], a1 = sA[(2 * s + lk) * PA + wp0 + 32 + li];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
   // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
   const int co = n0 + wc0 + li;
@@ -165,14 +187,228 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args a) {
   }
 }
 
-int vfs_conv_f32_launch(const ConvF32Args& a, hipStream_t s) {
+
+// ---------------------------------------------------------------------------------------------
+// The same convolution, organised around what the fp32-input MFMA is on gfx950 (tools/probe_mfma_valu_mix.hip, round 4):
+// v_mfma_f32_32x32x2_f32 runs on the vector lanes - vector instructions of ANY wave of the SIMD do not hide behind it, each one takes
+// about 2.5 clk (v_mul_lo 4.6) out of the 64 clk an MFMA needs, at 4 waves per SIMD - and a wave that is gathering, storing to LDS or
+// standing at a barrier contributes no MFMAs.  conv_f32_kernel above spent 2.8-5.2 vector instructions per MFMA and kept every
+// wave out of the matrix pipe between its two barriers per chunk (59-61 % of the fp32 MFMA peak).  Here:
+//   - ONE barrier per chunk: two LDS images; chunk ch + 1 is written to the other image while chunk ch is multiplied
+//   - a straight-line loop body (no conditional loads: raw buffer loads, rows / taps / channels out of range read as zeros through the
+//     descriptor's range check; no end-of-loop special cases: the chunks past the end load nothing and store zeros), so the LDS stores
+//     and the gather of the next chunks are scheduled BETWEEN the MFMAs of this one
+//   - 32-bit offsets and incremental (kh, kw, c) counters: ~1.3 vector instructions per MFMA
+// Same products, same ascending-k fmaf chain per output as conv_f32_kernel: bit-identical results (tests/test_exact_f32.py).
+// The descriptor is based at the first image the pixel tile touches (offsets are 32-bit): any batch size.
+__device__ __forceinline__ unsigned fdiv(unsigned n, VfsFastDiv f) {
+  const unsigned t = (unsigned)(((unsigned long long)n * f.m) >> 32);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+#define CONV_F32_OOB 0xFFFFFFF0u      // >= any num_records: the load returns zeros and moves nothing
+// BN = output channels per workgroup: 64 (wave tile 64 x 32, 3 workgroups per CU) or 128 (wave tile 64 x 64: four MFMAs per four LDS
+// reads, the gather of a pixel row shared by twice the MFMAs; 2 workgroups per CU) - every instruction that is not an MFMA costs
+// matrix time here, so the wider tile is used wherever Cout fills it.
+template <bool SMALLC, int BN>      // SMALLC: Cin < 32 (the stem, Cin = 4): several taps per chunk, the tap counters advance in a loop
+__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv_f32_db_kernel(ConvF32Args a) {
+  constexpr int BM = 128, BK = 32, G = BK / 4, RPP = 256 / G, NA = BM / RPP, NB = BN / RPP, NW = BN / 64;
+  constexpr int PA = BM + 1, PB = BN + 1;      // [k][row] planes, one dword of padding (see conv_f32_kernel)
+  __shared__ float sA[2][BK * PA];
+  __shared__ float sB[2][BK * PB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // (all divisions by launch constants go through the launcher's multipliers: the four 64-bit divisions per thread this prologue
+  //  started with were a quarter of the time of a K = 256 tile; M < 2^31 is checked by the launcher)
+  const unsigned hw = (unsigned)(a.Ho * a.Wo);
+  const unsigned M = (unsigned)a.N * hw;
+  const unsigned NT = (unsigned)(a.Cout + BN - 1) / BN;
+  const unsigned MT = (M + BM - 1) / BM;
+  const unsigned slot = blockIdx.x >> 3;      // XCD-aware tile order, see conv_f32_kernel
+  const unsigned slot_m = fdiv(slot, a.d_nt);
+  const unsigned mt = slot_m * 8 + (blockIdx.x & 7);
+  if (mt >= MT) return;
+  const unsigned m0 = mt * BM;
+  const int n0 = (int)(slot - slot_m * NT) * BN;
+  const int C4 = a.Cin >> 2;
+  const int K4 = a.KH * a.KW * C4;
+  const int lq = t % G, ap = t / G;
+
+  const long long n_first = fdiv(m0, a.d_hw);
+  const long long img = (long long)a.H * a.W * a.Cin;      // elements of one input image
+  const long long left = ((long long)a.N - n_first) * img * 4;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + n_first * img), 0,
+                                                                       (unsigned)(left < 0xFFFFFF00LL ? left : 0xFFFFFF00LL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)((size_t)a.Cout * K4 * 16), 0x00020000);
+
+  // A: pixels ap + RPP * i - window origin (may lie outside the image: the byte offset wraps, valid taps land in range again)
+  int iy0[NA], ix0[NA];
+  unsigned abase[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const unsigned am = m0 + ap + RPP * i;
+    iy0[i] = -(1 << 28); ix0[i] = -(1 << 28); abase[i] = 0;      // rows past M: every tap is out of range
+    if (am < M) {
+      const long long n = fdiv(am, a.d_hw);
+      const unsigned rem = am - (unsigned)n * hw;
+      const int oy = (int)fdiv(rem, a.d_wo), ox = (int)rem - oy * a.Wo;
+      iy0[i] = oy * a.stride - a.pad; ix0[i] = ox * a.stride - a.pad;
+      abase[i] = (unsigned)(((((n - n_first) * a.H + iy0[i]) * a.W + ix0[i]) * a.Cin) * 4);
+    }
+  }
+  // B: output channels ap + RPP * i
+  bool b_ok[NB];
+  unsigned wb[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int c = n0 + ap + RPP * i;
+    b_ok[i] = c < a.Cout;
+    wb[i] = (unsigned)((size_t)(b_ok[i] ? c : 0) * K4 * 16);
+  }
+
+  // this thread's float4 group of the NEXT chunk to load, k4 = chunk * G + lq -> (kh, kw, c4); dy, dx, delta follow it incrementally
+  int l_k4 = lq, l_c4, l_kw, l_kh;
+  { const int tap = (int)fdiv((unsigned)lq, a.d_c4); l_c4 = lq - tap * C4; l_kh = (int)fdiv((unsigned)tap, a.d_kw); l_kw = tap - l_kh * a.KW; }
+  int dy = l_kh * a.dil, dx = l_kw * a.dil;
+  unsigned delta = (unsigned)((((long long)dy * a.W + dx) * a.Cin + l_c4 * 4) * 4);
+  const unsigned d_tap = (unsigned)((a.dil - 1) * a.Cin * 4);      // channel wrap onto the next tap of the row: + dil * Cin - Cin elements
+  const unsigned d_row = (unsigned)((((long long)a.dil * a.W - (long long)(a.KW - 1) * a.dil) * a.Cin - a.Cin) * 4);   // onto the next row
+  f32x4 ra[NA], rb[NB];
+  auto load = [&]() {      // chunk 0, 1, 2, ... in order; past the end: nothing is moved
+    const bool k_ok = l_k4 < K4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const bool ok = k_ok && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? abase[i] + delta : CONV_F32_OOB, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (b_ok[i] && k_ok) ? wb[i] + (unsigned)l_k4 * 16u : CONV_F32_OOB, 0, 0));
+    l_k4 += G; l_c4 += G; delta += G * 16;
+    if (SMALLC) {
+      while (l_c4 >= C4) {
+        l_c4 -= C4;
+        if (++l_kw == a.KW) { l_kw = 0; ++l_kh; delta += d_row; dx = 0; dy += a.dil; }
+        else { delta += d_tap; dx += a.dil; }
+      }
+    } else {      // at most one wrap per chunk (C4 >= G): selects, no branch
+      const bool wrap = l_c4 >= C4;
+      const bool wrap2 = wrap && l_kw + 1 == a.KW;
+      l_c4 -= wrap ? C4 : 0;
+      l_kw = wrap2 ? 0 : l_kw + (wrap ? 1 : 0);
+      delta += wrap ? (wrap2 ? d_row : d_tap) : 0u;
+      dx = wrap2 ? 0 : dx + (wrap ? a.dil : 0);
+      dy += wrap2 ? a.dil : 0;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) sA[buf][(4 * lq + e) * PA + ap + RPP * i] = ra[i][e];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) sB[buf][(4 * lq + e) * PB + ap + RPP * i] = rb[i][e];
+    }
+  };
+
+  f32x16 acc[2][NW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wp0 = (wave & 1) * 64, wc0 = (wave >> 1) * (BN / 2);
+  const int li = lane & 31, lk = lane >> 5;
+  const int nchunks = (K4 + G - 1) / G;
+  load();
+  store(0);
+  load();
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ch += 2) {      // two chunks per trip: the LDS image of every access is a constant
+#pragma unroll
+    for (int cur = 0; cur < 2; ++cur) {
+      if (cur == 1 && ch + 1 >= nchunks) break;
+      if (!(a.dbg & 2)) store(cur ^ 1);      // chunk ch + cur + 1 (zeros past the end), requested one chunk ago
+      if (!(a.dbg & 1)) load();              // chunk ch + cur + 2
+      __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks the requests below the MFMAs: nothing would hide their latency)
+      if (!(a.dbg & 4))
+#pragma unroll
+      for (int s = 0; s < BK / 2; ++s) {
+        const float a0 = sA[cur][(2 * s + lk) * PA + wp0 + li], a1 = sA[cur][(2 * s + lk) * PA + wp0 + 32 + li];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const float b = sB[cur][(2 * s + lk) * PB + wc0 + 32 * j + li];
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();      // image cur read by all, image cur ^ 1 written by all
+    }
+  }
+  // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31].  Outputs and identity values go through descriptors based at the
+  // tile's first row whose range check drops the rows past M and the channels past Cout: one 32-bit add per element, no compare
+  // (the per-element 64-bit address arithmetic and row tests were 325 vector instructions per wave and tile)
+  const unsigned rows = M - m0 < (unsigned)BM ? M - m0 : (unsigned)BM;
+  const unsigned row_b = (unsigned)a.Cout * 4u;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)m0 * a.Cout), 0, rows * row_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((a.res ? a.res : a.y) + (size_t)m0 * a.Cout), 0, rows * row_b, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int co = n0 + wc0 + 32 * j + li;
+    const unsigned off0 = co < a.Cout ? (unsigned)(wp0 + 4 * lk) * row_b + (unsigned)co * 4u : 0x80000000u;
+    const float sc = (a.scale && co < a.Cout) ? a.scale[co] : 1.f, sh = (a.scale && co < a.Cout) ? a.shift[co] : 0.f;
+    float rv[2][16];
+    if (a.res && !(a.dbg & 32)) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[pt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, off0 + (unsigned)(pt * 32 + (r & 3) + 8 * (r >> 2)) * row_b, 0, 0));
+    }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[pt][j][r];
+        if (a.scale) v = __builtin_fmaf(v, sc, sh);
+        if (a.res && !(a.dbg & 32)) v = v + rv[pt][r];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (!(a.dbg & 16) || v == 12345.678f)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off0 + (unsigned)(pt * 32 + (r & 3) + 8 * (r >> 2)) * row_b, 0, 0);
+      }
+  }
+}
+
+int vfs_option_conv_f32_variant = 0;      // A/B knob: 321 = conv_f32_kernel (two barriers per chunk)
+int vfs_option_conv_f32_dbg = 0;
+int vfs_conv_f32_launch(const ConvF32Args& a_in, hipStream_t s) {
+  ConvF32Args a = a_in;
+  a.dbg = vfs_option_conv_f32_dbg;
   if (a.Cin % 4) return vfs_set_error(VFS_ERR_SHAPE, "conv_f32: Cin % 4 (pad the 3-channel input to NHWC4)");
   if (a.N < 1 || a.Ho < 1 || a.Wo < 1 || a.Cout < 1 || a.stride < 1 || a.dil < 1) return vfs_set_error(VFS_ERR_SHAPE, "conv_f32: geometry");
   if (a.Ho != (a.H + 2 * a.pad - a.dil * (a.KH - 1) - 1) / a.stride + 1 || a.Wo != (a.W + 2 * a.pad - a.dil * (a.KW - 1) - 1) / a.stride + 1)
     return vfs_set_error(VFS_ERR_SHAPE, "conv_f32: output size does not match (H + 2 pad - dil (K - 1) - 1) / stride + 1");
   if (a.scale && !a.shift) return vfs_set_error(VFS_ERR_ARG, "conv_f32: scale without shift");
+  if (a.Cin < 4 || a.KH < 1 || a.KW < 1 || a.H < 1 || a.W < 1) return vfs_set_error(VFS_ERR_SHAPE, "conv_f32: geometry");
   const long long M = (long long)a.N * a.Ho * a.Wo;
-  hipLaunchKernelGGL(conv_f32_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((a.Cout + 63) / 64)), dim3(256), 0, s, a);
+  a.d_hw = vfs_fastdiv((unsigned)(a.Ho * a.Wo)); a.d_wo = vfs_fastdiv((unsigned)a.Wo);
+  a.d_c4 = vfs_fastdiv((unsigned)(a.Cin / 4)); a.d_kw = vfs_fastdiv((unsigned)a.KW);
+  // channel tile 128: where Cout fills it, K is long enough to amortise the twice larger epilogue and the tiles still fill two
+  // workgroups per CU (per-layer table of the DAVIS ResNet-50 pass, MEASUREMENTS.md round 4: res4 conv1 / conv2 -5 %, every other
+  // layer +2..13 %).  A/B knob conv_f32_variant: 64 / 128 force one, 321 = the two-barrier kernel
+  const bool wide = a.Cout % 128 == 0 && (long long)a.KH * a.KW * a.Cin >= 512 && ((M + 127) / 128) * (a.Cout / 128) >= 384;
+  const int bn = vfs_option_conv_f32_variant == 64 || vfs_option_conv_f32_variant == 321 ? 64 : vfs_option_conv_f32_variant == 128 ? 128 : wide ? 128 : 64;
+  const long long mt8 = ((M + 127) / 128 + 7) / 8 * 8, nt = (a.Cout + bn - 1) / bn;      // pixel tiles padded to the 8 XCDs
+  a.d_nt = vfs_fastdiv((unsigned)nt);
+  if (mt8 * nt > 0x7fffffffLL) return vfs_set_error(VFS_ERR_SHAPE, "conv_f32: too many tiles");
+  const dim3 grid((unsigned)(mt8 * nt));
+  // images one pixel tile can touch: 32-bit offsets from the first of them
+  const long long span = (127 / ((long long)a.Ho * a.Wo) + 2) * a.H * a.W * a.Cin * 4;
+  if (vfs_option_conv_f32_variant == 321 || M >= 0x7fffff00LL || (long long)a.Cout * 512 >= 0x7fffffffLL || span >= 0xFFFFFF00LL || (long long)a.Cout * a.KH * a.KW * a.Cin * 4 >= 0xFFFFFF00LL)
+    hipLaunchKernelGGL((conv_f32_kernel<32, 1>), grid, dim3(256), 0, s, a);
+  else if (a.Cin < 32 && bn == 64) hipLaunchKernelGGL((conv_f32_db_kernel<true, 64>), grid, dim3(256), 0, s, a);
+  else if (a.Cin < 32) hipLaunchKernelGGL((conv_f32_db_kernel<true, 128>), grid, dim3(256), 0, s, a);
+  else if (bn == 64) hipLaunchKernelGGL((conv_f32_db_kernel<false, 64>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_f32_db_kernel<false, 128>), grid, dim3(256), 0, s, a);
   return vfs_check_launch("conv_f32");
 }
 

@@ -242,6 +242,18 @@ int vfs_seg_postprocess_launch(const float* seg, float* partial, uint8_t* label,
 int vfs_onehot_launch(const uint8_t* lab, float* out, int P, int CO, hipStream_t s);
 
 // ---- exact_f32.hip: the fp32 evaluation path (bit-defined arithmetic, see the file header) -----------
+// unsigned division by a launch constant (Granlund-Montgomery, any 32-bit numerator): q = (t + ((n - t) >> s1)) >> s2, t = mulhi(n, m)
+struct VfsFastDiv {
+  unsigned m, s1, s2;
+};
+inline VfsFastDiv vfs_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  VfsFastDiv f;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1; f.s2 = l > 1 ? l - 1 : 0;
+  return f;
+}
 struct ConvF32Args {
   const float* x;      // [N][H][W][Cin] fp32 NHWC, Cin % 4 == 0
   const float* w;      // [Cout][KH][KW][Cin]
@@ -250,6 +262,8 @@ struct ConvF32Args {
   const float* res;    // [N][Ho][Wo][Cout] identity branch or null
   float* y;            // [N][Ho][Wo][Cout]
   int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, relu;
+  VfsFastDiv d_hw, d_wo, d_nt, d_c4, d_kw;      // set by the launcher: divisions by Ho * Wo, Wo, channel tiles, Cin / 4, KW
+  int dbg;             // what-if timing (WRONG results), set by the launcher from the conv_f32_dbg option: 1 no gather, 2 no LDS stores, 4 no MFMAs, 8 staggered start, 16 no output stores, 32 no residual loads
 };
 struct LabelPropF32Args {
   const float* fbank;  // [frames][H*W][C] L2-normalised fp32 features
