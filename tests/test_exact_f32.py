@@ -38,6 +38,39 @@ CONV_CASES = [
 ]
 
 
+CONV_CASES_WIDE = [      # for the 128-channel tile (Cout a multiple of 128, or forced: ragged channel tiles)
+    (1, 9, 15, 64, 128, 3, 1, 1, 1, True, True, True),       # one wide tile, ragged pixel tile, residual
+    (2, 6, 11, 96, 256, 1, 1, 0, 1, False, False, True),     # 1x1, two wide tiles, K = 96 (three chunks)
+    (1, 8, 8, 32, 256, 3, 1, 4, 4, True, False, True),       # dilation 4 (res4 of the DAVIS backbone)
+    (2, 9, 11, 4, 192, 7, 2, 3, 1, True, False, True),       # stem geometry on the wide tile, second tile half empty
+    (1, 5, 7, 20, 136, 3, 1, 1, 1, True, True, False),       # ragged K and ragged channels
+]
+
+
+@pytest.mark.parametrize('variant', [64, 128, 321])
+@pytest.mark.parametrize('case', range(len(CONV_CASES_WIDE)))
+def test_conv_f32_kernel_variants_bit_exact(backend, case, variant):
+    """the launcher picks the 64- or 128-channel tile by layer shape (and falls back to the two-barrier kernel for sizes the 32-bit
+    offsets do not cover): every one of them forced on the same layers, against the oracle"""
+    lib = backend.hostlib
+    lib.set_option(b'conv_f32_variant', variant)
+    try:
+        test_conv_f32_bit_exact(backend, *CONV_CASES_WIDE[case])
+        if case == 0:
+            test_conv_f32_bit_exact(backend, *CONV_CASES[0])
+    finally:
+        lib.set_option(b'conv_f32_variant', 0)
+
+
+def test_conv_f32_rejects_degenerate_geometry(backend):
+    lib = backend.hostlib
+    x, w, y = torch.zeros(1, 4, 4, 8), torch.zeros(8, 1, 1, 8), torch.zeros(1, 4, 4, 8)
+    with pytest.raises(Exception):
+        lib.conv_f32_fwd(x, w, None, None, None, y, 1, 4, 4, 8, 0, 4, 8, 1, 1, 1, 0, 1, 0, None)      # Ho = 0
+    with pytest.raises(Exception):
+        lib.conv_f32_fwd(x, w, None, None, None, y, 1, 4, 4, 0, 4, 4, 8, 1, 1, 1, 0, 1, 0, None)      # Cin = 0
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad,dil,relu,res,affine', CONV_CASES)
 def test_conv_f32_bit_exact(backend, N, H, W, Cin, Cout, k, stride, pad, dil, relu, res, affine):
     lib = backend.hostlib
