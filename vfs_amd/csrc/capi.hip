@@ -610,7 +610,7 @@ int vfs_labelprop_f32_2pass_workspace_bytes(int H, int W, long long* bytes) {
 int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const float* sbank, float* out, void* workspace,
                             long long workspace_bytes, int qframe, const int* kslot, int nkeys, int H, int W, int C, int CO, int radius,
                             int non_mask_len, int topk, float temperature, int unit_rows, vfs_stream_t stream) {
-  if (!hlbank || !unit_rows || !vfs_lp2_eligible(C))
+  if (!hlbank || !unit_rows || !vfs_lp2_eligible(C) || (long long)H * W >= (1 << 21))      // (2^21 positions: the float index arithmetic of pass 1)
     return vfs_labelprop_f32(fbank, sbank, out, workspace, workspace_bytes, qframe, kslot, nkeys, H, W, C, CO, radius, non_mask_len, topk,
                              temperature, stream);
   if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: 1 <= nkeys <= 64");

@@ -84,6 +84,7 @@ __device__ __forceinline__ void lp2_insert_val(float (&tv)[LPX_TOPK], float s) {
 // are listed before it has)
 struct Lp2Window {
   int slot, r, wy0, wx0, ww, nwin, nkb;
+  float rww;      // 1 / ww
 };
 __device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0, int qx0) {
   Lp2Window w;
@@ -98,6 +99,7 @@ __device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0
   w.ww = wx1 - w.wx0 + 1;
   w.nwin = (wy1 - w.wy0 + 1) * w.ww;
   w.nkb = (w.nwin + 63) >> 6;
+  w.rww = 1.0f / (float)w.ww;
   return w;
 }
 __device__ __forceinline__ int lp2_block_of(int i, int nkb, int stagger = 0) {      // i-th block in centre-out order
@@ -303,9 +305,13 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   const unsigned rowb = (unsigned)C * 4u;      // bytes of one split row (hi + lo)
 
   // ---- the query tile, resident: B fragments (16 channels x 32 queries) of this wave's channel quarter, hi and lo
+  // Every wave names the tiles RELATIVE to the one it owns in the epilogue (keys of half kh x queries of half qhh): accumulator a00
+  // is always the own tile (first key rows = half kh, first queries = half qhh), so the reduction starts from a register set known
+  // at compile time (selecting one of four accumulators by the wave index was 48 v_cndmask per key block, all exposed)
+  const int kh = wave & 1, qhh = wave >> 1;
   bf16x8 qh0[NG], qh1[NG], ql0[NG], ql1[NG];
   {
-    const int qa = li, qb = 32 + li;
+    const int qa = 32 * qhh + li, qb = 32 * (qhh ^ 1) + li;
     const int ya = min(qy0 + (qa >> 3), H - 1), xa = min(qx0 + (qa & 7), W - 1);      // rows past the map: a valid row, masked below
     const int yb = min(qy0 + (qb >> 3), H - 1), xb = min(qx0 + (qb & 7), W - 1);
     const bf16_t* ba = a.hl + ((size_t)a.qframe * HW + (size_t)(ya * W + xa)) * 2 * C + (size_t)wave * NG * 32 + kgrp * 8;
@@ -334,8 +340,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     for (int i = 0; i < LPX_TOPK; ++i) sTop[i][t] = -INFINITY;
   }
 
-  // the wave's part in the epilogue: scores of 32 keys (half kh) x 32 queries (half qh); the lane's query
-  const int kh = wave & 1, qhh = wave >> 1;
+  // the wave's part in the epilogue: scores of 32 keys (half kh) x 32 queries (half qhh); the lane's query
   const int myq = qhh * 32 + li;
   const int qy = qy0 + (myq >> 3), qx = qx0 + (myq & 7);
   const bool q_in = qy < H && qx < W;
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       unsigned char* pdst = ring + (slot == 0 ? RING - 1 : slot - 1) * SBYTES;
       if (dma) ++req;
       const unsigned char* st = ring + slot * SBYTES;
-      const int R0 = li, R1 = 32 + li, sw0 = (R0 >> 1) & 7, sw1 = (R1 >> 1) & 7;
+      const int R0 = 32 * kh + li, R1 = 32 * (kh ^ 1) + li, sw0 = (R0 >> 1) & 7, sw1 = (R1 >> 1) & 7;
       bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + ((kgrp ^ sw0) << 4));
       bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((2 + kgrp) ^ sw0) << 4));
       bf16x8 ka1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + ((kgrp ^ sw1) << 4));
@@ -468,17 +473,21 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     // ---- the four channel quarters of the 64 x 64 score block meet: tile (kt, qt) belongs to wave kt + 2 qt
     const int kb = lp2_block_of(ci, cw.nkb, stag);
     if (t < 64) {
+      // key kk of the window -> (row, column): kk / ww through a float reciprocal, exact here (kk < 2^13, ww <= W: (kk + 0.5) / ww is
+      // at least 0.5 / ww away from an integer, the reciprocal's error moves it by < 1e-3) - the integer division the compiler
+      // emits is ~45 vector instructions, and the other three waves wait for this one at the barrier below
       const int kk = kb * 64 + t;
-      sKC[t] = kk < cw.nwin ? (((cw.wy0 + kk / cw.ww) << 16) | (cw.wx0 + kk % cw.ww)) : -1;
+      const int ky = (int)(((float)kk + 0.5f) * cw.rww);
+      sKC[t] = kk < cw.nwin ? (((cw.wy0 + ky) << 16) | (cw.wx0 + kk - ky * cw.ww)) : -1;
     }
-    f32x16 tot = wave == 0 ? a00 : (wave == 1 ? a10 : (wave == 2 ? a01 : a11));
+    f32x16 tot = a00;
+    const int o10 = (kh ^ 1) + 2 * qhh, o01 = kh + 2 * (qhh ^ 1), o11 = (kh ^ 1) + 2 * (qhh ^ 1);      // owners of the other three tiles
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += RH) {
       if (r0 > 0) __syncthreads();      // the previous round has been read
-      if (wave != 0) lp2_park<RH>(&sRed[0][wave - 1][0][lane][0], a00, r0);
-      if (wave != 1) lp2_park<RH>(&sRed[1][wave < 1 ? wave : wave - 1][0][lane][0], a10, r0);
-      if (wave != 2) lp2_park<RH>(&sRed[2][wave < 2 ? wave : wave - 1][0][lane][0], a01, r0);
-      if (wave != 3) lp2_park<RH>(&sRed[3][wave][0][lane][0], a11, r0);
+      lp2_park<RH>(&sRed[o10][wave < o10 ? wave : wave - 1][0][lane][0], a10, r0);      // [owner][rank of this wave among the other three]
+      lp2_park<RH>(&sRed[o01][wave < o01 ? wave : wave - 1][0][lane][0], a01, r0);
+      lp2_park<RH>(&sRed[o11][wave < o11 ? wave : wave - 1][0][lane][0], a11, r0);
       __syncthreads();
 #pragma unroll
       for (int src = 0; src < 3; ++src)
@@ -489,30 +498,29 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
           tot[r0 + r + 2] = tot[r0 + r + 2] + v[2]; tot[r0 + r + 3] = tot[r0 + r + 3] + v[3];
         }
     }
-    // ---- candidates: circle mask, list everything that may still be in the query's top 10.  Once the threshold is warm almost no
-    // candidate passes: the sixteen tests run branch-free and the listing code is entered only by waves that have something to list
+    // ---- candidates: list everything inside the circle that may still be in the query's top 10.  Once the threshold is warm almost
+    // no score passes it: the sixteen threshold tests come FIRST (two instructions each) and the geometry - key coordinates, circle
+    // mask, candidate id - is worked out only for the scores that passed, only in waves that have one (with one wave per SIMD and
+    // no MFMA in flight here, every vector instruction of this epilogue is exposed: the mask-first form spent ~190 per key block)
     const float thr_e = lp2_dec(sThr[myq]) - a.margin;
-    const int fid = cf * HW;
-    unsigned passmask = 0;
-    int ids[16];
+    unsigned long long hot = 0;      // lanes with a score above the threshold: sixteen compares, OR-ed on the scalar side
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int pk = sKC[kh * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgrp];
-      const int cy = pk >> 16, cx = pk & 0xffff;
-      const int dy = cy - qy, dx = cx - qx;
-      const bool ok = pk >= 0 && q_in && (cw.r <= 0 || dy * dy + dx * dx < cw.r * cw.r);
-      ids[rg] = fid + cy * W + cx;
-      passmask |= (ok && tot[rg] >= thr_e) ? 1u << rg : 0u;
-    }
-    if (__any(passmask != 0) && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
+    for (int rg = 0; rg < 16; ++rg) hot |= __ballot(tot[rg] >= thr_e);
+    if (hot != 0 && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
+      const int fid = cf * HW;
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) {
-        if (passmask & (1u << rg)) {
-          const float sc = tot[rg];
-          const int idx = atomicAdd(&sCnt[myq], 1);
-          if (idx < a.cap) mylist[idx] = ((unsigned long long)(unsigned)ids[rg] << 32) | (unsigned long long)__builtin_bit_cast(unsigned, sc);
-          const int e = atomicAdd(&sEn[myq], 1);
-          if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = sc;      // (a full queue only delays the threshold: it stays a lower bound)
+        if (q_in && tot[rg] >= thr_e) {
+          const int pk = sKC[kh * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kgrp];
+          const int cy = pk >> 16, cx = pk & 0xffff;
+          const int dy = cy - qy, dx = cx - qx;
+          if (pk >= 0 && (cw.r <= 0 || dy * dy + dx * dx < cw.r * cw.r)) {
+            const float sc = tot[rg];
+            const int idx = atomicAdd(&sCnt[myq], 1);
+            if (idx < a.cap) mylist[idx] = ((unsigned long long)(unsigned)(fid + cy * W + cx) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, sc);
+            const int e = atomicAdd(&sEn[myq], 1);
+            if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = sc;      // (a full queue only delays the threshold: it stays a lower bound)
+          }
         }
       }
     }
