@@ -107,7 +107,7 @@ KERNEL_FAMILY = (('conv_igemm_kernel', 'conv_igemm'), ('conv3x3_halo_kernel', 'c
                  ('bn_bwd_reduce_kernel', 'bn_bwd_reduce'), ('stem_pool_bn_bwd_reduce', 'bn_bwd_reduce'), ('bn_reduce_', 'bn_stats'),
                  ('bn_stats_raw', 'bn_stats'), ('bn_finalize', 'bn_stats'), ('bn_relu_maxpool_kernel', 'bn_relu_maxpool'),
                  ('pack_weights_kernel', 'pack_weights'), ('sgd_kernel', 'sgd'), ('labelprop_f32', 'labelprop_f32'),
-                 ('lp2_', 'labelprop_2pass'), ('conv_f32_kernel', 'conv_f32'), ('seg_minmax_exact', 'seg_postprocess'),
+                 ('lp2_', 'labelprop_2pass'), ('conv_f32_kernel', 'conv_f32'), ('conv_f32_db_kernel', 'conv_f32'), ('seg_minmax_exact', 'seg_postprocess'),
                  ('seg_argmax_exact', 'seg_postprocess'))
 
 

@@ -26,7 +26,7 @@ CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels
     # the fp32 DAVIS workload (bench.py --workload davis; `make_traffic_json.py davis_<model> <tag>`)
     'labelprop_f32': ('labelprop_f32_kernel', 'labelprop_f32_merge_kernel'),
     'labelprop_2pass': ('lp2_score_kernel', 'lp2_refine_kernel', 'lp2_seed_kernel'),
-    'conv_f32': ('conv_f32_kernel',),
+    'conv_f32': ('conv_f32_kernel', 'conv_f32_db_kernel'),
     'seg_postprocess': ('seg_minmax_exact_kernel', 'seg_argmax_exact_kernel'),
 }
 # families whose timed launch is SEVERAL kernels: bytes of all of them per launch of the first one
