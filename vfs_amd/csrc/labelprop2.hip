@@ -702,7 +702,7 @@ int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
 int vfs_option_lp2_dbg = 0;        // what-if timing (WRONG results): 2 = cache-hot key traffic, 4 = no lists
 int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
 int vfs_option_lp2_cap = 0;        // list entries per (key-frame split, query); 0 = the workspace shared out among the splits in use
-int vfs_option_lp2_xcd = 0;        // pass 1: XCD-aware work order (A/B knob; MI355X: 7.6 instead of 12.4 GB fetched per ResNet-50 frame, but 2.50 vs 2.28 ms)
+int vfs_option_lp2_xcd = 1;        // pass 1: XCD-aware work order (0 = dispatch order; A/B knob).  First measured slower (2.50 vs 2.28 ms per launch while the epilogue dominated), with the lean epilogue 2.986 vs 3.004 ms per frame - and it fetches 40 % less
 
 // Key frames per workgroup: about four workgroups per CU and launch (pass 1 runs ONE workgroup per CU at a time: the query tile fills
 // the register file).  Measured on the MI355X, 21 key frames: 1 / 2 / 3 frames per workgroup = 2.21 / 2.24 / 2.27 ms (ResNet-50) and
