@@ -86,10 +86,10 @@ def test_two_pass_equals_oracle(backend, case):
     run_2pass(backend, feats, seg, expect_fallback=False, **c)
 
 
-@pytest.mark.parametrize('order', [0, 2])
+@pytest.mark.parametrize('order', [0, 1, 2])
 @pytest.mark.parametrize('case', [CASES[0], CASES[3], CASES[6]])
 def test_two_pass_work_orders(backend, case, order):
-    """pass 1 in dispatch order (0) and in the staggered XCD-aware order (2); the default (1, XCD-aware) runs everywhere else.  The
+    """pass 1 in dispatch order (0), XCD-aware (1) and staggered XCD-aware (2) order (default -1: chosen by the bank width).  The
     remap of workgroup -> (tile row, key-frame split, tile column) must be a bijection for any grid."""
     lib = backend.hostlib
     lib.set_option(b'lp2_xcd', order)
@@ -98,7 +98,7 @@ def test_two_pass_work_orders(backend, case, order):
         feats, seg = _features(c.pop('T'), c['H'], c['W'], c.pop('C'), c.pop('CO'), seed=11)
         run_2pass(backend, feats, seg, expect_fallback=False, **c)
     finally:
-        lib.set_option(b'lp2_xcd', 1)
+        lib.set_option(b'lp2_xcd', -1)
 
 
 def test_two_pass_crowded_scores(backend):

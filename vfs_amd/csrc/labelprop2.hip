@@ -702,7 +702,9 @@ int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
 int vfs_option_lp2_dbg = 0;        // what-if timing (WRONG results): 2 = cache-hot key traffic, 4 = no lists
 int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
 int vfs_option_lp2_cap = 0;        // list entries per (key-frame split, query); 0 = the workspace shared out among the splits in use
-int vfs_option_lp2_xcd = 1;        // pass 1: XCD-aware work order (0 = dispatch order; A/B knob).  First measured slower (2.50 vs 2.28 ms per launch while the epilogue dominated), with the lean epilogue 2.986 vs 3.004 ms per frame - and it fetches 40 % less
+int vfs_option_lp2_xcd = -1;       // pass 1 work order: 1 / 2 = XCD-aware (/ staggered), 0 = dispatch order, -1 = by bank width: XCD-aware for
+                                   // C = 1024 (ResNet-50: level in time, 2.986 vs 3.004 ms per frame, 4.7 instead of 8.3 GB fetched per launch), dispatch order for
+                                   // narrower banks (ResNet-18, C = 256: 1.015 vs 1.054 ms per frame - short key blocks, the tiles of an XCD wait for the same lines)
 
 // Key frames per workgroup: about four workgroups per CU and launch (pass 1 runs ONE workgroup per CU at a time: the query tile fills
 // the register file).  Measured on the MI355X, 21 key frames: 1 / 2 / 3 frames per workgroup = 2.21 / 2.24 / 2.27 ms (ResNet-50) and
@@ -742,7 +744,7 @@ int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
   hipLaunchKernelGGL(lp2_seed_kernel, dim3((a.H * a.W + 3) / 4), dim3(256), 0, s, a);
   int rcs = vfs_check_launch("lp2_seed");
   if (rcs) return rcs;
-  a.xcd_order = vfs_option_lp2_xcd;
+  a.xcd_order = vfs_option_lp2_xcd >= 0 ? vfs_option_lp2_xcd : (a.C >= 1024 ? 1 : 0);
   a.dbg = vfs_option_lp2_dbg;
   if (a.C == 256) hipLaunchKernelGGL(lp2_score_kernel<4>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
   else if (a.C == 512) hipLaunchKernelGGL(lp2_score_kernel<8>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
