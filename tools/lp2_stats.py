@@ -27,7 +27,7 @@ synthetic_weights_(model, seed=5)
 model.to(dev).eval()
 eng = shared_engine()
 lib = eng.lib
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and int(sys.argv[2]) > 0:
     lib.set_option(b'lp2_cap', int(sys.argv[2]))
 T, H, W = 22, 480, 854
 g = torch.Generator(device=dev).manual_seed(1234)
@@ -79,6 +79,15 @@ per_q = counts.sum(0).float()
 print('overflow flag', flag, '| listed per query: mean %.0f max %d | per (split, query): max %d | splits used %d'
       % (per_q.mean(), int(per_q.max()), int(counts.max()), int((counts.sum(1) > 0).sum())))
 
+if len(sys.argv) > 3:      # only the step with that many key frames, 20 times (for `rocprofv3 --kernel-trace --stats -- python tools/lp2_stats.py r50 0 <nkeys>`)
+    nk = int(sys.argv[3])
+    fq = nk - 1
+    sl = [0] + list(range(max(0, fq - 20), fq))
+    kk = (ctypes.c_int * len(sl))(*sl)
+    for _ in range(20):
+        lib.labelprop_f32_2pass(bank, hl, sbank, out2, ws, ws.numel() * 4, fq, kk, len(sl), h, w, C, CO, radius, 0, 10, 0.07, 1, s)
+    torch.cuda.synchronize()
+    sys.exit(0)
 # every propagation step of a clip (first + up to 20 preceding key frames, as forward_test builds them): time and fallback flag
 print('key frames : two-pass ms, dense-fallback flag')
 for fq in range(1, T):
@@ -94,4 +103,5 @@ for fq in range(1, T):
     dt = (time.perf_counter() - t0) * 1e3
     fl = int(ws.view(torch.int32)[(int(n.item()) - 16) // 4])
     cnts = ws.view(torch.int32)[(int(dense.item()) + lists_bytes) // 4:(int(dense.item()) + lists_bytes) // 4 + 24 * HW].reshape(24, HW)
-    print(f'{len(sl):3d} : {dt:6.3f} ms  flag {fl}  listed per query max {int(cnts.sum(0).max())}')
+    pq = cnts.sum(0).float()
+    print(f'{len(sl):3d} : {dt:6.3f} ms  flag {fl}  listed per query mean {float(pq.mean()):7.1f} max {int(pq.max())}  splits used {int((cnts.sum(1) > 0).sum())}')

@@ -508,6 +508,11 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     for (int rg = 0; rg < 16; ++rg) hot |= __ballot(tot[rg] >= thr_e);
     if (hot != 0 && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
       const int fid = cf * HW;
+      // every passing candidate is listed; the query's running top 10 is fed with this lane's BEST TWO of them (four lanes hold a
+      // query's 64 scores of the block: at most eight values per query and block, the queue never overflows).  Feeding the first
+      // sixteen in arrival order let the threshold of a cold clip creep up by a few percentiles per block: ~500 listed candidates
+      // per query in the first nine steps of a clip, and a refinement as long as pass 1 itself.
+      float b1 = -INFINITY, b2 = -INFINITY;
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) {
         if (q_in && tot[rg] >= thr_e) {
@@ -518,10 +523,18 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
             const float sc = tot[rg];
             const int idx = atomicAdd(&sCnt[myq], 1);
             if (idx < a.cap) mylist[idx] = ((unsigned long long)(unsigned)(fid + cy * W + cx) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, sc);
-            const int e = atomicAdd(&sEn[myq], 1);
-            if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = sc;      // (a full queue only delays the threshold: it stays a lower bound)
+            if (sc > b1) { b2 = b1; b1 = sc; }
+            else if (sc > b2) b2 = sc;
           }
         }
+      }
+      if (b1 > -INFINITY) {
+        const int e = atomicAdd(&sEn[myq], 1);
+        if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = b1;      // (a dropped value would only delay the threshold: it stays a lower bound)
+      }
+      if (b2 > -INFINITY) {
+        const int e = atomicAdd(&sEn[myq], 1);
+        if (e < LP2_BLOCK_QUEUE) sEq[myq][e] = b2;
       }
     }
     __syncthreads();      // sRed / sKC are rewritten by the next block; the block's listed scores are complete
@@ -583,19 +596,35 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
   const int HW = a.H * a.W, C = a.C;
   const int q = blockIdx.x * 4 + wave;
   if (q >= HW) return;      // wave-uniform
-  // ---- 1. t = the 10th largest listed s~ (ties count as separate candidates).  Lane l owns the list of key-frame split l: the
-  // counts arrive in ONE parallel load (a loop over the splits with a dependent count load each cost a memory round trip per
-  // split), every lane walks its own list - a handful of entries once the thresholds are warm, up to the list capacity in the
-  // first steps of a clip (fewer than ten key frames: the seeds cannot reach the top ten)
-  const int cnt = lane < a.nsplit ? a.counts[(size_t)lane * HW + q] : 0;
-  int maxcnt = cnt;
+  // ---- 1. t = the 10th largest listed s~ (ties count as separate candidates).  The lists of the key-frame splits are walked as ONE
+  // flat sequence, element i by lane i % 64: coalesced 8-byte loads, ceil(N / 64) rounds.  (One lane per split walking its own list
+  // with a dependent load per entry was fine for the ~20 entries of a warm clip and ~250 us for the ~500 entries a query has in
+  // the first nine steps of a clip, when pass 1 starts every split from the seeds' weak threshold.)
+  __shared__ int sPre[4][LP2_MAX_SPLIT + 1];      // exclusive prefix of the splits' list lengths
+  const int cnt = lane < a.nsplit ? min(a.counts[(size_t)lane * HW + q], a.cap) : 0;
+  int incl = cnt;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, d));
-  const unsigned long long* L = a.lists + ((size_t)(lane < a.nsplit ? lane : 0) * HW + q) * a.cap;
+  for (int d = 1; d < 32; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }      // (nsplit <= 24 < 32)
+  if (lane < a.nsplit) sPre[wave][lane] = incl - cnt;
+  const int N = __shfl(incl, a.nsplit - 1);
+  lp2_wave_sync();
+  const bool staged = N <= LP2_SURV_CAP;      // every entry fits in LDS: the survivors are filtered in place, no second walk
+  auto entry = [&](int i) -> unsigned long long {      // element i < N of the flat sequence
+    int sp = 0;
+    for (int k = 1; k < a.nsplit; ++k) sp += i >= sPre[wave][k] ? 1 : 0;
+    return a.lists[((size_t)sp * HW + q) * a.cap + (i - sPre[wave][sp])];
+  };
   float tv[LPX_TOPK];
 #pragma unroll
   for (int i = 0; i < LPX_TOPK; ++i) tv[i] = -INFINITY;
-  for (int e = 0; e < cnt; ++e) lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)L[e]));
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < N) {
+      const unsigned long long ent = entry(i);
+      lp2_insert_val(tv, __builtin_bit_cast(float, (unsigned)ent));
+      if (staged) sSurv[wave][i] = ent;
+    }
+  }
   float t10 = -INFINITY;
   for (int k = 0; k < LPX_TOPK; ++k) {
     float m = tv[0];
@@ -609,13 +638,17 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
     tv[LPX_TOPK - 1] = pop ? -INFINITY : tv[LPX_TOPK - 1];
   }
   const float thr = t10 - a.margin;      // (fewer than ten candidates: -inf, everything survives)
-  // ---- 2. survivors = {s~ >= t - margin} -> LDS (wave-wide compaction, one list position per step)
+  // ---- 2. survivors = {s~ >= t - margin} -> the front of sSurv (wave-wide compaction, 64 elements per step; in place when the
+  // entries were staged: a step writes positions <= the ones it has read)
+  lp2_wave_sync();
   int nsurv = 0;
-  for (int e = 0; e < maxcnt; ++e) {
-    const unsigned long long ent = e < cnt ? L[e] : 0ull;
-    const bool keep = e < cnt && __builtin_bit_cast(float, (unsigned)ent) >= thr;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned long long ent = i < N ? (staged ? sSurv[wave][i] : entry(i)) : 0ull;
+    const bool keep = i < N && __builtin_bit_cast(float, (unsigned)ent) >= thr;
     const unsigned long long m = __ballot(keep);
     const int pos = nsurv + __popcll(m & ((1ull << lane) - 1ull));
+    lp2_wave_sync();      // (in place: every lane has read its element before any lane overwrites one)
     if (keep && pos < LP2_SURV_CAP) sSurv[wave][pos] = ent;
     nsurv += __popcll(m);
   }
@@ -624,10 +657,12 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
     return;
   }
   lp2_wave_sync();
-  // ---- 3. exact scores: lane j <- survivor j of a batch of 64.  Every lane streams ITS OWN key row - 32 independent 16-byte loads
-  // (128 channels) in flight per lane - and runs the defining chain over it; the query row sits in LDS (broadcast reads).  A
-  // wave-cooperative, LDS-transposed staging of the rows (coalesced, 32 channels per step) was a chain of 32 dependent memory
-  // round trips per batch: 65 us per wave for 21 survivors; the rows are few, latency - not coalescing - is what costs here.
+  // ---- 3. exact scores.  EIGHT lanes share a survivor: lane j of a group reads channels 32 p + 4 j .. + 3 of piece p, so a wave load
+  // touches 8 rows x one whole 128-byte line.  (One row per lane - 64 different lines per load instruction, each line looked up by
+  // eight instructions - kept the CU's vector-memory address path busy for ~14 k clk per query: the kernel took 0.2-0.28 ms, as long
+  // as a sixth of pass 1, for a few dozen rows per query.)  The defining chain acc = fma(k_c, q_c, acc), c ascending, then walks the
+  // lanes of the group: lane j continues from lane j - 1 (DPP row_shr:1), lane 0 of the next piece from lane 7 (row_shl:7).  Every
+  // lane executes every step; only the lane whose turn it is holds the true accumulator, the other values are never used.
   float ev[LPX_TOPK];
   int ei[LPX_TOPK];
 #pragma unroll
@@ -635,26 +670,31 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
   const float* qrow = a.fbank + ((size_t)a.qframe * HW + q) * C;
   for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(&sQ[wave][c]) = lpx_ldf4(qrow + c);
   lp2_wave_sync();
-  for (int b0 = 0; b0 < nsurv; b0 += 64) {
-    const bool on = b0 + lane < nsurv;
-    const int id = on ? (int)(sSurv[wave][b0 + lane] >> 32) : 0;      // (idle lanes: candidate 0's row, result dropped)
+  const int grp = lane >> 3, sub = lane & 7;
+  for (int b0 = 0; b0 < nsurv; b0 += 8) {
+    const bool on = b0 + grp < nsurv;
+    const int id = on ? (int)(sSurv[wave][b0 + grp] >> 32) : (int)(sSurv[wave][0] >> 32);      // (idle groups: survivor 0's row, result dropped)
     const int fr = id / HW, px = id - fr * HW;
-    const float* krow = a.fbank + ((size_t)a.kslot[fr] * HW + px) * C;
+    const float* krow = a.fbank + ((size_t)a.kslot[fr] * HW + px) * C + 4 * sub;
     float acc = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 128) {
-      f32x4 kv[32];
+    for (int c0 = 0; c0 < C; c0 += 256) {      // 8 pieces of 32 channels in flight per lane (C = 256, 512, 1024: C % 256 == 0)
+      f32x4 kv[8];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) kv[i] = lpx_ldf4(krow + c0 + 4 * i);
+      for (int p = 0; p < 8; ++p) kv[p] = lpx_ldf4(krow + c0 + 32 * p);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(&sQ[wave][c0 + 4 * i]);
-        acc = __builtin_fmaf(kv[i][0], qv[0], acc);
-        acc = __builtin_fmaf(kv[i][1], qv[1], acc);
-        acc = __builtin_fmaf(kv[i][2], qv[2], acc);
-        acc = __builtin_fmaf(kv[i][3], qv[3], acc);
+      for (int p = 0; p < 8; ++p) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(&sQ[wave][c0 + 32 * p + 4 * sub]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float t = __builtin_fmaf(kv[p][0], qv[0], acc);
+          t = __builtin_fmaf(kv[p][1], qv[1], t);
+          t = __builtin_fmaf(kv[p][2], qv[2], t);
+          t = __builtin_fmaf(kv[p][3], qv[3], t);
+          acc = s < 7 ? dpp_mov<0x111>(t) : dpp_mov<0x107>(t);      // row_shr:1 / row_shl:7 (the wrap to lane 0 of the group)
+        }
       }
     }
-    if (on) lpx_insert(ev, ei, acc / a.temperature, id);
+    if (on && sub == 0) lpx_insert(ev, ei, acc / a.temperature, id);
   }
   // ---- 4. the query's top 10 under the total order (score desc, candidate id asc): ten rounds of a wave-wide arg-best over
   // the lanes' heads (every lane ends up holding the whole sorted list)
