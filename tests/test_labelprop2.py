@@ -101,6 +101,20 @@ def test_two_pass_work_orders(backend, case, order):
         lib.set_option(b'lp2_xcd', -1)
 
 
+@pytest.mark.parametrize('case', [CASES[0], CASES[3], CASES[4], CASES[6]])
+def test_two_pass_rectangular_windows(backend, case):
+    """pass 1 on the untrimmed rectangle of every masked key frame (the default trims each window row to the columns the tile can
+    reach; rectangles remain for windows larger than the kernel's key table)"""
+    lib = backend.hostlib
+    lib.set_option(b'lp2_trim', 0)
+    try:
+        c = dict(case)
+        feats, seg = _features(c.pop('T'), c['H'], c['W'], c.pop('C'), c.pop('CO'), seed=13)
+        run_2pass(backend, feats, seg, expect_fallback=False, **c)
+    finally:
+        lib.set_option(b'lp2_trim', 1)
+
+
 def test_two_pass_crowded_scores(backend):
     """scores crowded like the bench's synthetic clip (post-ReLU features with a common component: the bf16-rounded scores of
     hundreds of candidates lie within 2^-7 of the 10th best - a single-bf16 prefilter would keep them all)"""

@@ -85,11 +85,25 @@ __device__ __forceinline__ void lp2_insert_val(float (&tv)[LPX_TOPK], float s) {
 struct Lp2Window {
   int slot, r, wy0, wx0, ww, nwin, nkb;
   float rww;      // 1 / ww
+  bool tab;       // keys enumerated by the workgroup's table of a TRIMMED window (below) instead of the rectangle
 };
-__device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0, int qx0) {
+// Trimmed window of a masked key frame: row y of the rectangle keeps only the columns SOME query of the 8 x 8 tile can reach,
+// [qx0 - dx(y), qx0 + 7 + dx(y)] with dx(y) = the largest dx with dx^2 + dmin(y)^2 < r^2, dmin(y) = the distance from y to the
+// tile's rows.  At radius 18 the corners it drops are 12.5 % of the 42 x 42 rectangle - key rows that were streamed, multiplied and
+// masked for every query.  The geometry is the same for every masked key frame of a tile: ONE table per workgroup, key index ->
+// (y << 16 | x) in LDS (which also replaces the integer divisions of the rectangle's index arithmetic).
+__device__ __forceinline__ int lp2_row_reach(int dmin, int r) {      // dx(y) above; dmin <= r - 1
+  const int lim = r * r - 1 - dmin * dmin;      // dx^2 <= lim
+  int dx = (int)__builtin_sqrtf((float)lim);
+  while ((dx + 1) * (dx + 1) <= lim) ++dx;
+  while (dx * dx > lim) --dx;
+  return dx;
+}
+__device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0, int qx0, int tab_nwin = 0) {
   Lp2Window w;
   w.slot = a.kslot[f];
   w.r = f < a.non_mask_len ? 0 : a.radius;
+  w.tab = false;
   int wy1 = a.H - 1, wx1 = a.W - 1;
   w.wy0 = 0; w.wx0 = 0;
   if (w.r > 0) {
@@ -98,6 +112,7 @@ __device__ __forceinline__ Lp2Window lp2_window(const Lp2Args& a, int f, int qy0
   }
   w.ww = wx1 - w.wx0 + 1;
   w.nwin = (wy1 - w.wy0 + 1) * w.ww;
+  if (w.r > 0 && tab_nwin > 0) { w.tab = true; w.nwin = tab_nwin; }
   w.nkb = (w.nwin + 63) >> 6;
   w.rww = 1.0f / (float)w.ww;
   return w;
@@ -153,6 +168,17 @@ __global__ __launch_bounds__(256) void lp2_seed_kernel(Lp2Args a) {
 }
 
 struct Lp2Off { unsigned v[8]; };      // byte offsets of the eight DMA pieces of a key block (by value: stays in registers)
+__device__ __forceinline__ Lp2Off lp2_offsets_tab(const Lp2Window& w, const int* keytab, int kb, int lane, int W, unsigned rowb, unsigned lane_off) {
+  Lp2Off o;      // eight independent LDS reads; rows past the window: its last key (their scores are masked)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = 8 * p + (lane >> 3);
+    const int pk = keytab[min(kb * 64 + r, w.nwin - 1)];
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    o.v[p] = (unsigned)((pk >> 16) * W + (pk & 0xffff)) * rowb + lane_off + (unsigned)c * 16u;
+  }
+  return o;
+}
 __device__ __forceinline__ Lp2Off lp2_offsets(const Lp2Window& w, int kb, int lane, int W, unsigned rowb, unsigned lane_off) {
   // the lane's rows are 8 window positions apart: ONE division, then steps of 8 columns (with one wave per SIMD every VALU
   // instruction of the skeleton is on the critical path - sixteen integer divisions per key block were ~4 k cycles of it)
@@ -281,6 +307,8 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   __shared__ int sKC[64], sThr[64], sCnt[64], sEn[64];
   __shared__ float sEq[64][LP2_BLOCK_QUEUE];      // scores listed for a query in the current key block (feed its running top 10)
   __shared__ float sTop[LPX_TOPK][64];            // the queries' running top 10 of s~ (in LDS: the 512 registers of a lane are taken)
+  __shared__ int sKeyTab[LP2_KEYTAB];             // trimmed window: key index -> (y << 16 | x)
+  __shared__ int sRowStart[64], sTabN;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 31, kgrp = lane >> 5;
@@ -340,6 +368,36 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     for (int i = 0; i < LPX_TOPK; ++i) sTop[i][t] = -INFINITY;
   }
 
+  // ---- the trimmed window of this tile's masked key frames (lp2_row_reach above): row extents by the lanes of wave 0, prefix sums
+  // over the rows, then every row writes its keys' positions into the table
+  int tab_nwin = 0;
+  if (a.trim && a.radius > 0) {
+    const int r = a.radius;
+    const int ty0 = max(0, qy0 - (r - 1)), ty1 = min(H - 1, qy0 + 7 + (r - 1));
+    const int rows = ty1 - ty0 + 1;
+    if (rows <= 64) {      // (uniform over the workgroup)
+      if (t < 64) {
+        int wdt = 0, x0 = 0;
+        if (t < rows) {
+          const int y = ty0 + t;
+          const int dx = lp2_row_reach(max(0, max(qy0 - y, y - (qy0 + 7))), r);
+          x0 = max(0, qx0 - dx);
+          wdt = min(W - 1, qx0 + 7 + dx) - x0 + 1;
+        }
+        int incl = wdt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        const int total = __shfl(incl, 63);
+        if (t == 0) sTabN = total;
+        sRowStart[t] = incl - wdt;
+        if (total <= LP2_KEYTAB)
+          for (int x = 0; x < wdt; ++x) sKeyTab[incl - wdt + x] = ((ty0 + t) << 16) | (x0 + x);
+      }
+      __syncthreads();
+      tab_nwin = sTabN <= LP2_KEYTAB ? sTabN : 0;
+    }
+  }
+
   // the wave's part in the epilogue: scores of 32 keys (half kh) x 32 queries (half qhh); the lane's query
   const int myq = qhh * 32 + li;
   const int qy = qy0 + (myq >> 3), qx = qx0 + (myq & 7);
@@ -349,22 +407,23 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
 
   // ---- block sequence: key frames newest first, blocks centre-out.  (cf, ci) = the block being computed, (nf, ni) = the next one
   int total_blocks = 0;
-  for (int f = f_begin; f < f_end; ++f) total_blocks += lp2_window(a, f, qy0, qx0).nkb;
+  for (int f = f_begin; f < f_end; ++f) total_blocks += lp2_window(a, f, qy0, qx0, tab_nwin).nkb;
   if (total_blocks == 0) return;      // (uniform; cannot happen for a non-empty split)
   // DMA addressing of a block: lane l of piece p fetches chunk c = (l & 7) ^ ((r >> 1) & 7) of key row r = 8 p + (l >> 3), so that
   // the piece lands linearly (piece base + 16 l) in the XOR-swizzled layout the conflict-free fragment reads below expect
   const unsigned lane_off = (unsigned)wave * NG * 64u;
   int cf = f_end - 1, ci = 0, nf = cf, ni = 1;
-  Lp2Window cw = lp2_window(a, cf, qy0, qx0), nw = cw;
+  Lp2Window cw = lp2_window(a, cf, qy0, qx0, tab_nwin), nw = cw;
   // ONE set of row offsets (`off`, `rs`): it names the block whose stages are being REQUESTED - the current block until its last
   // stage has been requested (two stages before its end), the next block from then on
-  Lp2Off off = lp2_offsets(cw, lp2_block_of(0, cw.nkb, stag), lane, W, rowb, lane_off);
+  Lp2Off off = cw.tab ? lp2_offsets_tab(cw, sKeyTab, lp2_block_of(0, cw.nkb, stag), lane, W, rowb, lane_off)
+                      : lp2_offsets(cw, lp2_block_of(0, cw.nkb, stag), lane, W, rowb, lane_off);
   vfs_rsrc_words rs = lp2_frame_rsrc(a.hl, cw.slot, HW, rowb);
   bool has_next = true;
   if (ni >= nw.nkb) {
     nf -= 1; ni = 0;
     if (nf < f_begin) has_next = false;
-    else nw = lp2_window(a, nf, qy0, qx0);
+    else nw = lp2_window(a, nf, qy0, qx0, tab_nwin);
   }
   unsigned char* ring = &sRing[wave][0][0];
   // Pipeline per wave (its own channel quarter, no cross-wave traffic, no barrier): flat stage counter S, stage S lives in ring slot
@@ -396,7 +455,8 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       // execute; as one burst in front of the MFMAs the matrix pipe idled for the whole burst - one wave per SIMD, in-order issue)
       if (req == NST && has_next) {      // the current block is fully requested: the next request is the NEXT block's first stage
         if (!(a.dbg & 2)) {      // (what-if timing, WRONG results: every block re-reads the first block's rows - cache-hot key traffic)
-          off = lp2_offsets(nw, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off);
+          off = nw.tab ? lp2_offsets_tab(nw, sKeyTab, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off)
+                       : lp2_offsets(nw, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off);
           rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
         }
         req = 0;
@@ -478,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       // emits is ~45 vector instructions, and the other three waves wait for this one at the barrier below
       const int kk = kb * 64 + t;
       const int ky = (int)(((float)kk + 0.5f) * cw.rww);
-      sKC[t] = kk < cw.nwin ? (((cw.wy0 + ky) << 16) | (cw.wx0 + kk - ky * cw.ww)) : -1;
+      sKC[t] = kk >= cw.nwin ? -1 : cw.tab ? sKeyTab[kk] : (((cw.wy0 + ky) << 16) | (cw.wx0 + kk - ky * cw.ww));
     }
     f32x16 tot = a00;
     const int o10 = (kh ^ 1) + 2 * qhh, o01 = kh + 2 * (qhh ^ 1), o11 = (kh ^ 1) + 2 * (qhh ^ 1);      // owners of the other three tiles
@@ -567,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       if (ni >= nw.nkb) {
         nf -= 1; ni = 0;
         if (nf < f_begin) has_next = false;
-        else nw = lp2_window(a, nf, qy0, qx0);
+        else nw = lp2_window(a, nf, qy0, qx0, tab_nwin);
       }
     }
   }
@@ -741,6 +801,7 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
 int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
 int vfs_option_lp2_dbg = 0;        // what-if timing (WRONG results): 2 = cache-hot key traffic, 4 = no lists
 int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
+int vfs_option_lp2_trim = 1;       // pass 1: windows of masked key frames trimmed to the columns the tile can reach (0: rectangles, A/B knob)
 int vfs_option_lp2_cap = 0;        // list entries per (key-frame split, query); 0 = the workspace shared out among the splits in use
 int vfs_option_lp2_xcd = -1;       // pass 1 work order: 1 / 2 = XCD-aware (/ staggered), 0 = dispatch order, -1 = by bank width: XCD-aware for
                                    // C = 1024 (ResNet-50: level in time, 2.986 vs 3.004 ms per frame, 4.7 instead of 8.3 GB fetched per launch), dispatch order for
@@ -785,6 +846,7 @@ int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
   int rcs = vfs_check_launch("lp2_seed");
   if (rcs) return rcs;
   a.xcd_order = vfs_option_lp2_xcd >= 0 ? vfs_option_lp2_xcd : (a.C >= 1024 ? 1 : 0);
+  a.trim = vfs_option_lp2_trim;
   a.dbg = vfs_option_lp2_dbg;
   if (a.C == 256) hipLaunchKernelGGL(lp2_score_kernel<4>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);
   else if (a.C == 512) hipLaunchKernelGGL(lp2_score_kernel<8>, dim3(tiles * a.nsplit), dim3(256), 0, s, a);

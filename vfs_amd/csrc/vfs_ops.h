@@ -282,8 +282,9 @@ struct LabelPropF32Args {
 #define LP2_MAX_SPLIT 24     // key-frame splits of pass 1 (= candidate lists per query)
 #define LP2_MAX_CAP 192      // list entries per (split, query): the workspace is sized for this (seeded thresholds: a handful are used)
 #define LP2_LIST_MAX 2048    // longest single list
+#define LP2_KEYTAB 2048      // key positions of a trimmed window the score kernel tabulates in LDS (8 KB); larger windows stay rectangles
 #define LP2_RING 3           // LDS stages per wave of pass 1 (RING - 1 in flight)
-#define LP2_BLOCK_QUEUE 16   // scores of one key block queued per query for its running top 10
+#define LP2_BLOCK_QUEUE 8   // scores of one key block queued per query for its running top 10
 struct Lp2Args {
   const float* fbank;        // [frames][H*W][C] unit rows, fp32 (pass 2: the defining arithmetic)
   const bf16_t* hl;          // [frames][H*W][C/16][hi 16 | lo 16] bf16 split copy of fbank (vfs_split_rows_bf16x2)
@@ -297,7 +298,7 @@ struct Lp2Args {
   int kslot[LP_MAX_KEYS];
   int H, W, C, CO, radius, topk, non_mask_len;
   float temperature, margin;
-  int cap, nsplit, xcd_order, dbg;
+  int cap, nsplit, xcd_order, dbg, trim;
 };
 int vfs_split_rows_bf16x2_launch(const float* x, bf16_t* hl, long long P, int C, hipStream_t s);
 int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s);
