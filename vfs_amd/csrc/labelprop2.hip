@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   __shared__ float sEq[64][LP2_BLOCK_QUEUE];      // scores listed for a query in the current key block (feed its running top 10)
   __shared__ float sTop[LPX_TOPK][64];            // the queries' running top 10 of s~ (in LDS: the 512 registers of a lane are taken)
   __shared__ int sKeyTab[LP2_KEYTAB];             // trimmed window: key index -> (y << 16 | x)
-  __shared__ int sRowStart[64], sTabN;
+  __shared__ int sTabN;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 31, kgrp = lane >> 5;
@@ -389,7 +389,6 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
         const int total = __shfl(incl, 63);
         if (t == 0) sTabN = total;
-        sRowStart[t] = incl - wdt;
         if (total <= LP2_KEYTAB)
           for (int x = 0; x < wdt; ++x) sKeyTab[incl - wdt + x] = ((ty0 + t) << 16) | (x0 + x);
       }
