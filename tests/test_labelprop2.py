@@ -115,6 +115,46 @@ def test_two_pass_rectangular_windows(backend, case):
         lib.set_option(b'lp2_trim', 1)
 
 
+def _visit_rank(nkb):
+    """rank of key block b in pass 1's centre-out order (csrc/labelprop2.hip lp2_block_of)"""
+    mid = (nkb - 1) >> 1
+    order = [mid + (i + 1) // 2 if i & 1 else mid - i // 2 for i in range(nkb)]
+    return {b: i for i, b in enumerate(order)}
+
+
+def test_refinement_of_lists_longer_than_its_staging_area(backend):
+    """Scores that RISE along pass 1's scan order (key frames newest first, key blocks centre-out): the running threshold always lags,
+    nearly every candidate is listed - more per query than the 512 entries the refinement stages in LDS - while only the last few
+    survive the final threshold.  The refinement then walks the global lists twice (the un-staged path) and must still produce the
+    oracle's bits, without the dense fallback."""
+    lib = backend.hostlib
+    H, W, C, CO = 24, 32, 256, 3
+    HW, nkb = H * W, (H * W + 63) // 64
+    rank = _visit_rank(nkb)
+    g = torch.Generator().manual_seed(5)
+    u = torch.nn.functional.normalize(torch.randn(C, generator=g), dim=0)
+    feats = torch.empty(3, HW, C)
+    # frame 2 = the queries (all close to u), frames 1 and 0 = keys; frame 1 is scanned first, so frame 0 scores higher
+    for f, base in ((1, 0.30), (0, 0.62)):
+        for p in range(HW):
+            cos = base + 0.30 * (rank[p // 64] * 64 + (p % 64)) / (nkb * 64)      # rises with the visit rank, distinct per key
+            v = torch.randn(C, generator=g)
+            v = torch.nn.functional.normalize(v - (v @ u) * u, dim=0)
+            feats[f, p] = cos * u + (1 - cos * cos) ** 0.5 * v
+    feats[2] = u[None, :] + 0.01 * torch.randn(HW, C, generator=g)
+    seg = torch.rand(3, HW, CO, generator=g)
+    fb, hl, out, flag = run_2pass(backend, feats, seg, H, W, 0, [0, 1], 2, expect_fallback=False)
+    # list lengths per query: counts[split][query] behind the list area of the workspace
+    ws, dense_bytes = _ws(lib, H, W)
+    out2 = torch.empty(HW, CO)
+    ks = (ctypes.c_int * 2)(0, 1)
+    lib.labelprop_f32_2pass(fb, hl, seg, out2, ws, ws.numel() * 4, 2, ks, 2, H, W, C, CO, 0, 0, 10, 0.07, 1, None)
+    off = (dense_bytes + 24 * HW * 192 * 8) // 4
+    counts = ws.view(torch.int32)[off:off + 24 * HW].reshape(24, HW)[:2].sum(0)
+    assert int(counts.max()) > 512, int(counts.max())      # the un-staged path ran
+    assert same_bits(out2.numpy(), out.numpy())
+
+
 def test_two_pass_crowded_scores(backend):
     """scores crowded like the bench's synthetic clip (post-ReLU features with a common component: the bf16-rounded scores of
     hundreds of candidates lie within 2^-7 of the 10th best - a single-bf16 prefilter would keep them all)"""
