@@ -155,6 +155,19 @@ def test_refinement_of_lists_longer_than_its_staging_area(backend):
     assert same_bits(out2.numpy(), out.numpy())
 
 
+def test_more_exact_ties_than_the_refinement_holds(backend):
+    """every key row identical: all 1536 candidates of a query tie exactly, all survive the final threshold - more than the 512 the
+    refinement rescans - so the frame is redone by the dense kernel (flag raised by pass 2 on the device); the ten kept are the ten
+    smallest candidate ids, as the reference's stable top-k keeps them"""
+    H, W, C, CO = 24, 32, 256, 3
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(3, H * W, C, generator=g)
+    feats[0] = feats[0, :1]
+    feats[1] = feats[0, :1]
+    seg = torch.rand(3, H * W, CO, generator=g)
+    run_2pass(backend, feats, seg, H, W, 0, [0, 1], 2, expect_fallback=True)
+
+
 def test_two_pass_crowded_scores(backend):
     """scores crowded like the bench's synthetic clip (post-ReLU features with a common component: the bf16-rounded scores of
     hundreds of candidates lie within 2^-7 of the 10th best - a single-bf16 prefilter would keep them all)"""
