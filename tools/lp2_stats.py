@@ -79,6 +79,11 @@ per_q = counts.sum(0).float()
 print('overflow flag', flag, '| listed per query: mean %.0f max %d | per (split, query): max %d | splits used %d'
       % (per_q.mean(), int(per_q.max()), int(counts.max()), int((counts.sum(1) > 0).sum())))
 
+if os.environ.get('LP2_PROF'):      # a build with phase timers in pass 1 (see MEASUREMENTS.md round 4): clk per wave of one mid workgroup
+    row = ws.view(torch.int32)[(int(dense.item()) + lists_bytes) // 4 + 23 * HW:(int(dense.item()) + lists_bytes) // 4 + 23 * HW + 64].cpu().view(torch.int64).reshape(4, 8)
+    names = ['kernel', 'stage loops', ' of which DMA waits', 'park + barrier 1', 'reduce + threshold', 'barrier 2', 'wave-0 top-10 / tail', 'blocks']
+    for w in range(4):
+        print('wave', w, ', '.join(f'{n} {int(v)}' for n, v in zip(names, row[w].tolist())))
 if len(sys.argv) > 3:      # only the step with that many key frames, 20 times (for `rocprofv3 --kernel-trace --stats -- python tools/lp2_stats.py r50 0 <nkeys>`)
     nk = int(sys.argv[3])
     fq = nk - 1

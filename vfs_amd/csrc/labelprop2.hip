@@ -204,47 +204,6 @@ __device__ __forceinline__ Lp2Off lp2_offsets(const Lp2Window& w, int kb, int la
 __device__ __forceinline__ vfs_rsrc_words lp2_frame_rsrc(const bf16_t* hl, int slot, int HW, unsigned rowb) {
   return vfs_make_rsrc_words(reinterpret_cast<const unsigned char*>(hl) + (size_t)slot * HW * rowb, (unsigned)HW * rowb);
 }
-// LDS-DMA pieces of a stage issued one at a time between MFMAs: M0 (the LDS base of a piece) is saved at lp2_burst_begin and
-// restored at lp2_burst_end; nothing the compiler emits in between uses M0 (gfx9+ LDS instructions do not)
-#ifndef LP2_INTERLEAVE
-#define LP2_INTERLEAVE 0      // 1: the DMA pieces of a stage between its first MFMAs, 0: as one burst in front of them (MI355X: 1.29 vs 1.25 ms)
-#endif
-struct Lp2Burst {
-  unsigned keep, lds;
-  unsigned char* dst;      // (host emulation: the destination as a pointer)
-};
-__device__ __forceinline__ Lp2Burst lp2_burst_begin(unsigned char* dst) {
-  Lp2Burst b;
-  b.dst = dst;
-#ifndef VFS_EMU
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  b.lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)dst);
-  asm volatile("s_mov_b32 %0, m0" : "=s"(b.keep));
-#else
-  b.keep = 0;
-  b.lds = 0;
-#endif
-  return b;
-}
-__device__ __forceinline__ void lp2_piece(const Lp2Burst& b, const vfs_rsrc_words& rs, unsigned voff, unsigned soff, int p) {
-#ifndef VFS_EMU
-  const unsigned addr = b.lds + (unsigned)p * 1024u;
-  asm volatile(
-      "s_mov_b32 m0, %0\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %2, %3 offen lds"
-      :
-      : "s"(addr), "v"(voff), "s"(rs), "s"(soff)
-      : "memory");
-#else
-  vfs_dma16_async(rs, b.dst + p * 1024, voff, soff);
-#endif
-}
-__device__ __forceinline__ void lp2_burst_end(const Lp2Burst& b) {
-#ifndef VFS_EMU
-  asm volatile("s_mov_b32 m0, %0" ::"s"(b.keep));
-#endif
-}
 // the eight pieces of a stage as ONE burst: M0 (the LDS base of a piece) is saved and restored once and stepped by 1 KB between the
 // pieces - vfs_dma16_async saves / sets / restores it around every piece (5 scalar instructions and two M0 reads per KB), and in
 // this kernel the issue path of the DMA pieces, not the memory behind them, is what the matrix pipe waits for (what-if with
@@ -426,13 +385,13 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   }
   unsigned char* ring = &sRing[wave][0][0];
   // Pipeline per wave (its own channel quarter, no cross-wave traffic, no barrier): flat stage counter S, stage S lives in ring slot
-  // S % RING, RING - 1 stages are in flight.  `req` counts the stages of the block `off` names that have been requested.
-  int req = 0;
+  // S % RING, RING - 1 stages are in flight: while stage s of a block is multiplied, stage s + RING - 1 is requested - of this block,
+  // or (the last RING - 1 stages) of the next one.  Everything about a stage but its ring slot is known at compile time: with ONE
+  // wave per SIMD the wave's own instruction issue is what the stage loop is bound by (phase timers, MEASUREMENTS.md round 4: 1230
+  // clk per stage for 768 clk of MFMAs, 1 % of it waiting for data), so the bookkeeping is kept out of the instruction stream.
 #pragma unroll
-  for (int d = 0; d < RING - 1; ++d) {      // (NST >= 2 and the prologue stays inside the first block: RING - 1 <= NST is asserted at launch)
+  for (int d = 0; d < RING - 1; ++d)      // (the prologue stays inside the first block: RING - 1 <= NST is asserted above)
     lp2_issue(rs, off, ring + d * SBYTES, (unsigned)d * 128u);
-    ++req;
-  }
   int slot = 0;                      // ring slot of the stage about to be consumed
   __syncthreads();                   // sThr / sCnt initialised
 
@@ -443,64 +402,40 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
       // stage (blk, s) has landed once at most the stages requested after it are still in flight: RING - 2 of them, fewer at the end
-      {
-        const int left = (NST - 1 - s) + (has_next ? RING : 0);      // stages after this one that exist (capped below)
-        if (left >= RING - 2) vfs_dma_wait<8 * (RING - 2)>();
-        else if (RING > 3 && left == 1) vfs_dma_wait<8>();
-        else vfs_dma_wait<0>();
-      }
-      // refill the slot the previous stage used (its fragment reads fed that stage's MFMAs): stage S + RING - 1.  The eight DMA
-      // pieces are issued BETWEEN the first MFMAs of this stage, one per MFMA (a piece takes about as long to issue as an MFMA to
-      // execute; as one burst in front of the MFMAs the matrix pipe idled for the whole burst - one wave per SIMD, in-order issue)
-      if (req == NST && has_next) {      // the current block is fully requested: the next request is the NEXT block's first stage
-        if (!(a.dbg & 2)) {      // (what-if timing, WRONG results: every block re-reads the first block's rows - cache-hot key traffic)
+      // of the last block
+      if (s + RING - 2 <= NST - 1 || has_next) vfs_dma_wait<8 * (RING - 2)>();
+      else if (RING > 3 && s == NST - 2) vfs_dma_wait<8>();
+      else vfs_dma_wait<0>();
+      // refill the slot the previous stage used (its fragment reads fed that stage's MFMAs) with stage s + RING - 1
+      bool dma = true;
+      unsigned soff = (unsigned)(s + RING - 1) * 128u;
+      if (s + RING - 1 >= NST) {      // (compile time) a stage of the NEXT block
+        if (s + RING - 1 == NST && has_next && !(a.dbg & 2)) {      // its first: name it (dbg 2, what-if with WRONG results: every block re-reads the first block's rows)
           off = nw.tab ? lp2_offsets_tab(nw, sKeyTab, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off)
                        : lp2_offsets(nw, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off);
           rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
         }
-        req = 0;
+        dma = has_next;
+        soff = (unsigned)(s + RING - 1 - NST) * 128u;
       }
-      const bool dma = req < NST;
-      const unsigned soff = (unsigned)req * 128u;
       unsigned char* pdst = ring + (slot == 0 ? RING - 1 : slot - 1) * SBYTES;
-      if (dma) ++req;
       const unsigned char* st = ring + slot * SBYTES;
       const int R0 = 32 * kh + li, R1 = 32 * (kh ^ 1) + li, sw0 = (R0 >> 1) & 7, sw1 = (R1 >> 1) & 7;
       bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + ((kgrp ^ sw0) << 4));
       bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((2 + kgrp) ^ sw0) << 4));
       bf16x8 ka1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + ((kgrp ^ sw1) << 4));
       bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((2 + kgrp) ^ sw1) << 4));
-#if LP2_INTERLEAVE
-      const Lp2Burst burst = lp2_burst_begin(pdst);
-#else
-      if (dma) lp2_issue(rs, off, pdst, soff);
-#endif
+      if (dma) lp2_issue(rs, off, pdst, soff);      // (one burst in front of the MFMAs; a piece between each of the first MFMAs measured the same or worse, twice)
       {
         const int g = 2 * s;
-#if LP2_INTERLEAVE
-#define LP2_PIECE(P) if (dma) lp2_piece(burst, rs, off.v[P], soff, P);
-#else
-#define LP2_PIECE(P)
-#endif
-#define LP2_STEP(ACC, KF, QF, P)                                            \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KF, QF, ACC, 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        LP2_PIECE(P)
-        LP2_STEP(a00, ka0, qh0[g], 0)
-        LP2_STEP(a01, ka0, qh1[g], 1)
-        LP2_STEP(a10, ka1, qh0[g], 2)
-        LP2_STEP(a11, ka1, qh1[g], 3)
-        LP2_STEP(a00, ka0, ql0[g], 4)
-        LP2_STEP(a01, ka0, ql1[g], 5)
-        LP2_STEP(a10, ka1, ql0[g], 6)
-        LP2_STEP(a11, ka1, ql1[g], 7)
-#undef LP2_STEP
-#undef LP2_PIECE
-        __builtin_amdgcn_sched_barrier(0);
-#if LP2_INTERLEAVE
-        lp2_burst_end(burst);
-#endif
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qh1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ql0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, ql1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ql0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, ql1[g], a11, 0, 0, 0);
         a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh0[g], a00, 0, 0, 0);
         a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh1[g], a01, 0, 0, 0);
         a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh0[g], a10, 0, 0, 0);
