@@ -325,8 +325,9 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
                                    'dense T*HW x HW product the reference executes is not counted); labelprop_2pass (csrc/labelprop2.hip, same '
                                    'bits as the dense fp32 kernel): THREE bf16 products per in-mask pair (hi.hi + hi.lo + lo.hi of the split '
                                    'bank) against the dense bf16 MFMA peak (2.5 PFLOP/s) - the kernel EXECUTES ~2x these products (the window union of an '
-                                   '8 x 8 query tile against the in-mask keys of one query) and is bound by the rate at which key rows enter '
-                                   'LDS (LDS-DMA, ~30 GB/s per CU: the matrix pipe is ~30 % busy), see MEASUREMENTS.md; other families: peak = dense '
+                                   '8 x 8 query tile against the in-mask keys of one query) with ONE wave per SIMD (the query tile fills the register '
+                                   'file), whose in-order instruction stream is the limit (matrix pipe ~30 % busy; phase timers in MEASUREMENTS.md); '
+                                   'other families: peak = dense '
                                    + ('fp32-input MFMA (157.3 TFLOP/s)' if args.precision == 'fp32' else 'bf16 MFMA (2.5 PFLOP/s)'))
         res['roofline']['families'] = [family(k) for k in sorted(agg, key=lambda k: -agg[k][1]) if k != kind and agg[k][1] / tot >= 0.03]
         res['roofline']['in_mask_pairs_per_key_frame'] = mask_pairs(60, 107, radius)
