@@ -80,6 +80,7 @@ struct Fiber {
 
 struct WaveX {  // per-wave exchange area
   uint32_t u32[64];
+  uint32_t x32[2][64];      // shfl_u32: two generations
   uint64_t u64[64];
   short a[64][8];
   short b[64][8];
@@ -202,12 +203,14 @@ inline void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 
 // ---- wave collectives -----------------------------------------------------
 inline uint32_t shfl_u32(uint32_t v, int src) {
+  // ONE barrier per exchange: the slot array alternates with the barrier generation (the same for every lane until the last one
+  // arrives), so the next exchange writes the other array; the one after it can only start once every lane has entered the next
+  // exchange, i.e. has finished reading this one.  (Shuffles and DPP moves dominate the emulated run time of the wave-level kernels.)
   WaveX& W = B->waves[wave_id()];
-  W.u32[lane_id()] = v;
+  const int par = W.gen & 1;
+  W.x32[par][lane_id()] = v;
   wave_barrier();
-  uint32_t r = W.u32[src & 63];
-  wave_barrier();
-  return r;
+  return W.x32[par][src & 63];
 }
 inline uint64_t ballot(int pred) {
   WaveX& W = B->waves[wave_id()];
