@@ -14,6 +14,7 @@ from vfs_amd._lib import get_lib  # noqa: E402
 SHAPES = [  # N, H, W, Cin, Cout
     (64, 64, 64, 64, 64), (64, 64, 64, 64, 256), (64, 64, 64, 256, 64), (64, 32, 32, 128, 512), (64, 32, 32, 512, 128),
     (64, 16, 16, 256, 1024), (64, 16, 16, 1024, 256), (64, 8, 8, 512, 2048), (64, 8, 8, 2048, 512),
+    (64, 64, 64, 256, 128), (64, 32, 32, 512, 256), (64, 16, 16, 1024, 512),      # conv1 of the first block of layers 2-4 (stride sits in conv2)
 ]
 
 

@@ -1,0 +1,184 @@
+// Pointwise (1x1, stride 1) convolution forward / dgrad as a PERSISTENT, producer/consumer-split GEMM for gfx950:
+//
+//   out[pixel][chan] = sum_k Wt[chan][k] * X[pixel][k]    (+ the epilogues of vfs_igemm_epi.h)
+//
+// Replaces the 1x1 torch conv2d calls of the reference's Bottleneck (mmaction/models/backbones/resnet.py:163-230: conv1, conv3,
+// downsample through mmcv ConvModule) and their autograd dgrads - 28 % of the ResNet-50 train step's kernel time.
+//
+// Why a second kernel next to conv_igemm.hip (round 5; numbers in MEASUREMENTS.md): the one-tile-per-workgroup kernels pay, per
+// 128 x 128 tile, a launch-to-first-load prologue, a pipeline fill, and a store tail during which the workgroup holds its LDS and
+// registers but moves nothing - 2-3x the HBM / L2 roof on every 1x1 layer.  Here
+//   * ONE workgroup per CU lives for the whole launch and walks a contiguous range of (pixel block, channel tile) tiles
+//     (XCD-aware: the ranges of one XCD are neighbours, the channel tiles of a pixel block meet in one L2);
+//   * waves 4-7 are LOADERS: they only issue LDS-DMA pieces (buffer_load ... lds, 1 KB each) of the flat (tile, K-step) sequence
+//     into a ring of RING stages [W tile BC x 64 | X tile 128 x 64], as far ahead as the ring allows - across tile boundaries, so
+//     the operands of tile i + 1 land while tile i's epilogue runs; their vmcnt holds DMA pieces only, so "step s has landed" is
+//     an exact count;
+//   * waves 0-3 are CONSUMERS: MFMA K-steps out of the ring, then the shared epilogue (own LDS stage, so it does not touch the
+//     ring); their output stores are never waited for - they drain under the next tile's K-steps.
+// Every wave of the workgroup executes the SAME number of s_barrier: one per K-step (B: stage landed / previous stage free), one
+// after a tile's last K-step (T: the last stage is free) and the epilogue's own (the loaders mirror them).
+#include "vfs_igemm_epi.h"
+
+int vfs_option_igemm_pw = 1;          // 0: off; 1: where the plan below says so; 2: every eligible 1x1
+int vfs_option_igemm_pw_min_tiles = 192;   // fewer 128-pixel tiles than this leave CUs idle: the split-channel kernels take over
+
+template <int BC, bool FBN>
+constexpr int pw_ring_stages() {
+  constexpr int stage = (BC + 128) * 64 * 2, fixed = igemm_stage_elems<BC, FBN>() * 2 + 2 * BC * 2 * 4 + 512;
+  constexpr int n = (160 * 1024 - fixed) / stage;
+  return n > 5 ? 5 : n;
+}
+
+template <int BC, int MODE, bool FBN>
+__global__ __launch_bounds__(512) void conv_pw_kernel(ConvArgs a) {
+  constexpr int BP = 128, WC = BC / 2, TM = WC / 16, TN = 4;
+  constexpr int STAGE = (BC + BP) * 64;                 // bf16 elements of one ring stage: [W tile | X tile]
+  constexpr int RING = pw_ring_stages<BC, FBN>();
+  static_assert(RING >= 3, "ring too short");
+  constexpr int XQ = 4, WQ = BC / 32, LPW = XQ + WQ;    // DMA pieces per loader wave and K-step
+  constexpr bool HAS_STATS = (MODE == GATHER_FWD);
+  __shared__ __attribute__((aligned(16))) bf16_t ring[RING * STAGE];
+  __shared__ __attribute__((aligned(16))) bf16_t stage[igemm_stage_elems<BC, FBN>()];
+  __shared__ float sRed[2][BC][2];
+
+  const ConvGeom g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int Mc = g.M;
+  const int npb = (Mc + BP - 1) / BP, ncb = (a.Cout + BC - 1) / BC, nk = g.Ktot >> 6;
+  // this workgroup's tiles: a contiguous range of the (pixel block, channel tile) sequence, channel tile fastest; hardware
+  // workgroup b runs on XCD b % 8 (observed, a speed matter only): the ranges of one XCD are neighbours
+  int lw = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lw & 7;
+    if (a.xcd_swizzle) lw = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lw >> 3);
+  }
+  const long long T = (long long)npb * ncb;
+  const int tile_begin = (int)(T * lw / gridDim.x), tile_end = (int)(T * (lw + 1) / gridDim.x);
+  const int S = (tile_end - tile_begin) * nk;           // K-steps of this workgroup
+  const int nsync = ((FBN && a.bn.partial != nullptr) ? 1 : 0) + ((HAS_STATS && a.stats != nullptr) ? 1 : 0);   // barriers inside igemm_epilogue
+
+  if (wave_u >= 4) {
+    // ------------------------------------------------ loaders
+    const int lwv = wave_u - 4;
+    const unsigned cbytes = (unsigned)g.C * 2u, kbytes = (unsigned)g.Ktot * 2u;
+    unsigned xrow[XQ], xoff[XQ], xc16[XQ], wrow[WQ], woff[WQ], wc16[WQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {      // lane l of a piece lands at piece_base + 16 l: it FETCHES the (row, chunk) whose swizzled slot that is
+      const int slot = (lwv * XQ + q) * 64 + lane, row = slot >> 3, chunk = (slot & 7) ^ ((row >> 1) & 7);
+      xrow[q] = row; xc16[q] = chunk * 16; xoff[q] = row * cbytes + chunk * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int slot = (lwv * WQ + q) * 64 + lane, row = slot >> 3, chunk = (slot & 7) ^ ((row >> 1) & 7);
+      wrow[q] = row; wc16[q] = chunk * 16; woff[q] = row * kbytes + chunk * 16;
+    }
+    const vfs_rsrc_words xrw = vfs_make_rsrc_words(a.src, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2));
+    const vfs_rsrc_words wrw = vfs_make_rsrc_words(a.wgt, (unsigned)((size_t)a.Cout * g.Ktot * 2));
+    int ipb = tile_begin / ncb, icb = tile_begin - ipb * ncb, ikt = 0, ist = 0, issued = 0;   // the NEXT step to issue
+    auto issue = [&]() {
+      const int m0 = ipb * BP, c0 = icb * BC;
+      bf16_t* sW = ring + ist * STAGE;
+      bf16_t* sX = sW + BC * 64;
+      const unsigned sx = (unsigned)m0 * cbytes + (unsigned)ikt * 128u, sw = (unsigned)c0 * kbytes + (unsigned)ikt * 128u;
+#pragma unroll
+      for (int q = 0; q < XQ; ++q)      // rows past the ragged end re-fetch row 0 of the tile (their outputs are masked by the epilogue)
+        vfs_dma16_async(xrw, sX + (lwv * XQ + q) * 512, m0 + (int)xrow[q] < Mc ? xoff[q] : xc16[q], sx);
+#pragma unroll
+      for (int q = 0; q < WQ; ++q)
+        vfs_dma16_async(wrw, sW + (lwv * WQ + q) * 512, c0 + (int)wrow[q] < a.Cout ? woff[q] : wc16[q], sw);
+      ++issued;
+      ist = ist + 1 == RING ? 0 : ist + 1;
+      if (++ikt == nk) {
+        ikt = 0;
+        if (++icb == ncb) { icb = 0; ++ipb; }
+      }
+    };
+#pragma unroll 1
+    for (int d = 0; d < RING; ++d)
+      if (issued < S) issue();
+    int kt = 0;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+      // this wave's pieces of step s have landed: only the pieces of the `ahead` later steps already issued may be in flight
+      const int ahead = issued - 1 - s;
+      if (ahead >= 4) vfs_dma_wait<4 * LPW>();
+      else if (ahead == 3) vfs_dma_wait<3 * LPW>();
+      else if (ahead == 2) vfs_dma_wait<2 * LPW>();
+      else if (ahead == 1) vfs_dma_wait<LPW>();
+      else vfs_dma_wait<0>();
+      __syncthreads();                        // B(s): everybody's pieces of step s have landed; the consumers are done with step s - 1
+      if (kt > 0 && issued < S) issue();      // ... whose stage takes step s - 1 + RING (after a tile's last step: issued behind T below)
+      if (++kt == nk) {
+        kt = 0;
+        __syncthreads();                      // T: the consumers are done with step s
+        if (issued < S) issue();
+        for (int e = 0; e < nsync; ++e) __syncthreads();   // the epilogue's barriers
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------- consumers
+  const int wc = wave_u >> 1, wp = wave_u & 1;
+  int pb = tile_begin / ncb, cb = tile_begin - pb * ncb, st = 0;
+#pragma unroll 1
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();                        // B(s)
+      const bf16_t* sW = ring + st * STAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      mma_kstep<TM, TN, false>(sW, sW + BC * 64, wc * WC, wp * 64, lane, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st + 1 == RING ? 0 : st + 1;
+    }
+    __syncthreads();                          // T
+    igemm_epilogue<BC, MODE, FBN, true>(a, pb * BP, cb * BC, pb, Mc, 0, 0, g.Ho, g.Wo, acc, stage, sRed);
+    if (++cb == ncb) { cb = 0; ++pb; }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static int pw_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <int BC, int MODE, bool FBN>
+static int launch_pw(const ConvArgs& a, hipStream_t stream) {
+  const long long T = (long long)((a.g.M + 127) / 128) * ((a.Cout + BC - 1) / BC);
+  const int G = (int)(T < pw_cus() ? T : pw_cus());
+  hipLaunchKernelGGL((conv_pw_kernel<BC, MODE, FBN>), dim3(G), dim3(512), 0, stream, a);
+  return vfs_check_launch("conv_pw");
+}
+
+// a pure-GEMM problem (checked by the caller: 1x1, stride 1, no padding, K % 64 == 0, no split-K, tensors < 4 GiB): does the
+// persistent kernel take it?
+bool vfs_conv_pw_eligible(const ConvArgs& a, int mode) {
+  if (!vfs_option_igemm_pw || (mode != GATHER_FWD && mode != GATHER_DGRAD)) return false;
+  if (a.g.KH * a.g.KW != 1 || a.g.stride != 1 || a.g.pad != 0 || a.g.H != a.g.Ho || a.g.W != a.g.Wo || a.ksplit > 1) return false;
+  if (a.bn.partial && mode != GATHER_DGRAD) return false;
+  if (vfs_option_igemm_pw >= 2) return true;
+  const int bc = a.Cout % 128 == 0 ? 128 : 64;
+  const long long T = (long long)((a.g.M + 127) / 128) * ((a.Cout + bc - 1) / bc);
+  return T >= vfs_option_igemm_pw_min_tiles;
+}
+
+int vfs_conv_pw_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
+  const bool wide = a.Cout % 128 == 0;
+  if (mode == GATHER_FWD) return wide ? launch_pw<128, GATHER_FWD, false>(a, stream) : launch_pw<64, GATHER_FWD, false>(a, stream);
+  if (a.bn.partial) return wide ? launch_pw<128, GATHER_DGRAD, true>(a, stream) : launch_pw<64, GATHER_DGRAD, true>(a, stream);
+  return wide ? launch_pw<128, GATHER_DGRAD, false>(a, stream) : launch_pw<64, GATHER_DGRAD, false>(a, stream);
+}
