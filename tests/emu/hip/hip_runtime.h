@@ -513,6 +513,12 @@ inline void vfs_dma16_async(vfs_rsrc_words rsrc, void* lds_wave_base, unsigned v
   const emu::v4u v = emu::raw_buffer_load_b128(rsrc, voffset, soffset, 0);
   memcpy((char*)lds_wave_base + 16 * emu::lane_id(), &v, 16);
 }
+// LDS "addresses" of the host build: byte offsets are plain pointers carried in a uintptr_t
+typedef uintptr_t vfs_lds_t;
+inline vfs_lds_t vfs_lds_addr(const void* lds) { return (uintptr_t)lds; }
+inline void vfs_dma16_async_at(vfs_rsrc_words rsrc, vfs_lds_t lds_addr, unsigned voffset, unsigned soffset) {
+  vfs_dma16_async(rsrc, (void*)lds_addr, voffset, soffset);
+}
 inline void vfs_dma_wait_all() {}
 // The HIP atomic intrinsics, scopes and fences csrc/vfs_common.h uses for inter-workgroup / inter-process hand-offs: blocks run on
 // different host threads, two "ranks" of csrc/p2p.hip on two host threads of the test process.

@@ -510,3 +510,51 @@ def test_ring_upfront_reads_bit_identical(backend):
             lib.set_option(b'igemm_ring_upfront', 0)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert relerr(nchw(outs[1][0]), F.conv2d(nchw(x.cpu()), w)) < 6e-3
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [
+    (4, 8, 8, 256, 128),      # whole 8x8 images in pairs, four channel chunks: the ring wraps across chunk boundaries, two patch buffers
+    (2, 16, 16, 128, 256),    # 8x16 tiles, two chunks, two channel blocks
+    (2, 14, 14, 192, 128),    # ragged tiles, three chunks
+    (3, 7, 7, 64, 128),       # one chunk only (nine steps), odd image count (the second image of the last tile does not exist)
+])
+def test_halo_deep_schedule_matches_two_stage(backend, N, H, W, Cin, Cout):
+    """the deep schedule of the halo kernel (32x32x16 MFMAs, four weight stages requested four taps ahead, the patch by LDS-DMA
+    into two buffers, next tap's fragments read under this tap's MFMAs; option halo_deep_max) against the two-stage
+    schedule: the same products, K summed 16 instead of 32 at a time - equal to fp32 rounding (the emulator's MFMAs are
+    k-ordered fmaf chains: bit-identical there), statistics rows consistent with the stored outputs, both against torch"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N * 3 + Cin + Cout)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5)
+    wf, wd = pack(backend, w)
+    dy = rb(torch.randn(N, Cout, H, W, generator=g))
+    add = rb(torch.randn(N, Cin, H, W, generator=g))
+    nblk = conv_stats_rows(N, 1, H, W, Cin, Cout, 3, 1, 1, H, W)
+    outs = []
+    for deep in (256, 0):
+        lib.set_option(b'halo_deep_max', deep)
+        try:
+            y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+            stats = torch.full((nblk, 2, Cout), float('nan'), device=dev)
+            lib.conv_fwd(d(nhwc(x)), wf, y, None, stats, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, None)
+            outs.append((y.cpu(), stats.cpu()))
+            if Cin % 128 == 0:      # the dgrad produces Cin channels: a 128-channel tile again
+                dx = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+                lib.conv_dgrad(d(nhwc(dy)), wd, dx, d(nhwc(add)), N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, None)
+                outs[-1] += (dx.cpu(),)
+        finally:
+            lib.set_option(b'halo_deep_max', 256)
+    for a_, b_ in zip(outs[0], outs[1]):
+        if backend.name == 'emu':
+            assert torch.equal(a_, b_)
+        else:      # one bf16 ulp where an fp32 rounding difference crosses a rounding boundary; fp32 statistics rows of those outputs
+            assert relerr(a_.float(), b_.float()) < 8e-3
+    yf = outs[0][0].float().reshape(-1, Cout).double()
+    assert torch.allclose(outs[0][1][:, 0].double().sum(0), yf.sum(0), rtol=1e-4, atol=5e-3)
+    assert torch.allclose(outs[0][1][:, 1].double().sum(0), (yf * yf).sum(0), rtol=1e-4, atol=5e-3)
+    assert relerr(nchw(outs[0][0]), F.conv2d(x, w, None, 1, 1)) < 6e-3
+    if Cin % 128 == 0:
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, 1, 1).backward(dy)
+        assert relerr(nchw(outs[0][2]), xr.grad + add) < 6e-3

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark / PMC target: only the 3x3 stride-1 convs (fwd, dgrad, wgrad) of ResNet-18 at bench size."""
+"""Micro-benchmark / PMC target: only the 3x3 stride-1 convs (fwd, dgrad, wgrad) of ResNet-18 (default) or ResNet-50 (`r50`)
+at bench size.  tools/bench_halo.py [iters] [fdw] [r50] [opt=value ...]"""
 import os
 import sys
 
@@ -23,7 +24,12 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     what = sys.argv[2] if len(sys.argv) > 2 else 'fdw'
-    for (N, H, W, C) in SHAPES:
+    for kv in [a for a in sys.argv[3:] if '=' in a]:
+        k, v = kv.split('=')
+        lib.set_option(k.encode(), int(v))
+    shapes = [(64, 64, 64, 64), (64, 32, 32, 128), (64, 16, 16, 256), (64, 8, 8, 512)] if 'r50' in sys.argv[3:] else SHAPES
+    print(' '.join(sys.argv[1:]))
+    for (N, H, W, C) in shapes:
         M = N * H * W
         x = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
         wf = torch.randn(C, 3, 3, C, device=dev).to(torch.bfloat16)

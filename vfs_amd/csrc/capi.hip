@@ -72,6 +72,7 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_xcd")) { vfs_option_wgrad_xcd = value; return VFS_OK; }
+  if (!strcmp(name, "halo_deep_max")) { vfs_option_halo_deep_max = value; return VFS_OK; }
   if (!strcmp(name, "halo_xcd")) { vfs_option_halo_xcd = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_fbn")) { vfs_option_igemm_ring_fbn = value; return VFS_OK; }
   if (!strcmp(name, "igemm_pw")) { vfs_option_igemm_pw = value; return VFS_OK; }

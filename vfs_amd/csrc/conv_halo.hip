@@ -15,6 +15,7 @@
 //     BC =  64: 1 (channels) x 4 (pixels)  -> 16x16 pixel tile (less halo, weights amortised 2x)
 // Fragment reads are software-pipelined across the k-steps and across the per-tap barrier (the patch
 // does not change at a tap boundary), so a wave's LDS reads overlap its own and its neighbours' MFMAs.
+#include <type_traits>
 #include "vfs_conv.h"
 
 // any offset >= num_records reads as zero; 2^31 leaves room for a scalar offset on top without wrapping
@@ -24,6 +25,11 @@
 // consecutive rows are bank-conflict free on gfx950 and, being linear, every tap / k-step / MFMA
 // tile is an IMMEDIATE offset from one per-lane base register (no address VALU in the main loop).
 #define HALO_RS 80
+// what-if builds (tools/make_variant_lib.sh; results are garbage, only the time is read): 1 no weight DMA in the tap loop,
+// 2 no barrier per tap, 4 no MFMAs (the fragment reads stay), 8 no fragment reads in the deep tap loop, 16 no epilogue, 32 no tap loop (deep)
+#ifndef HALO_WHATIF
+#define HALO_WHATIF 0
+#endif
 
 // lane column lr of 16-pixel group tn of pixel-wave wp -> pixel of the spatial tile.  For the 8-wide
 // tile a group is two 8-pixel rows, 10 patch rows apart; the second row is permuted so that the patch
@@ -260,21 +266,36 @@ __device__ __forceinline__ void halo_epilogue_dispatch(const ConvArgs& a, const 
   else halo_epilogue<15, BC, SMALLW, RAGGED>(a, acc, sRed, stage, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
 
-template <int BC, bool DGRAD, bool SMALLW, bool RAGGED>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
+// NW = weight stages.  2: the tap's weight tile is requested one tap ahead (two workgroups per CU hide the round trip for
+// each other: the large maps).  4 (round 5): the deep stages - 16 x 16 / 8 x 8 maps, at most one workgroup per CU, 36 - 72 taps
+// in ONE dependent chain - waited a full L2 round trip per tap (~1 us for 0.2 us of MFMAs: 37 / 65 us per launch for 19 GFLOP);
+// with a ring of four tiles the DMA runs three taps ahead and a tap costs its MFMAs.
+template <int BC, bool DGRAD, bool SMALLW, bool RAGGED, int NW = 2>
+__global__ __launch_bounds__(256, NW > 2 ? 1 : 2) void conv3x3_halo_kernel(ConvArgs a) {
   constexpr int WAVES_C = BC / 64, WAVES_P = 4 / WAVES_C;      // wave grid: channels x pixels
   constexpr int TW = SMALLW ? 8 : 16, TH = SMALLW ? 8 : 4 * WAVES_P, TI = SMALLW ? WAVES_P : 1;
   constexpr int PW = TW + 2, PH = TH + 2;
   constexpr int PROWS = TI * PH * PW;            // patch rows of 64 channels: 180 / 200 / 324
   constexpr int PLD = (PROWS * 8 + 255) / 256;   // 16-byte patch loads per thread
   constexpr int TM = 4, TN = 4;
-  constexpr int RS = HALO_RS;
-  // one arena: [patch | 2 weight tiles]; after the last tap the epilogue re-uses it as output stage
-  __shared__ __attribute__((aligned(16))) bf16_t smem[PROWS * RS + 2 * BC * RS];
+  // DEEP (NW > 2): the patch travels by LDS-DMA as well (lanes of padding pixels are sent out of range: the DMA writes zeros -
+  // tools/probe_dma_oob.hip), into TWO patch buffers: no register stage, no compiler-tracked load in the loop (a tracked load's
+  // s_waitcnt would drain the ring at every chunk boundary), no second barrier at a chunk boundary
+  constexpr bool DEEP = NW > 2;
+  // LDS row stride (bf16): 160 bytes for the 16-row fragments of the two-stage schedule, 144 bytes (an ODD multiple of 16: the
+  // 32 rows of a 32x32x16 fragment fall into 16 distinct 16-byte bank groups per ds_read_b128 lane group) for the deep one
+  constexpr int RS = DEEP ? 72 : HALO_RS;
+  constexpr int PPQ = ((PROWS * RS * 2 + 4095) / 4096) * 4, PQ = PPQ / 4;   // DMA pieces (1 KB) per patch buffer / per wave
+  constexpr int PSZ = DEEP ? PPQ * 512 : PROWS * RS;                       // bf16 elements of one patch buffer
+  constexpr int NPB = DEEP ? 2 : 1;
+  // one arena: [patch buffer(s) | NW weight tiles]; after the last tap the epilogue re-uses it as output stage
+  constexpr int NQD = ((BC * RS * 2 + 4095) / 4096) * 4;          // DEEP: DMA pieces of a weight stage, padded so that every wave moves the same number
+  constexpr int WST = DEEP ? NQD * 512 : BC * RS;                 // bf16 elements between weight stages
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NPB * PSZ + NW * WST];
   __shared__ __attribute__((aligned(16))) float sRed[WAVES_P][2][BC];
-  static_assert((PROWS * RS + 2 * BC * RS) * 2 >= 4 * HALO_STAGE_WAVE * 2 + 4 * 8 * 2 * 64 * 4, "output stage + statistics do not fit");
+  static_assert((NPB * PSZ + NW * WST) * 2 >= 4 * HALO_STAGE_WAVE * 2 + 4 * 8 * 2 * 64 * 4, "output stage + statistics do not fit");
   bf16_t* const sP = smem;
-  bf16_t* const sW = smem + PROWS * RS;
+  bf16_t* const sW = smem + NPB * PSZ;
 
   const ConvGeom g = a.g;                        // FWD: H,W,C = input; DGRAD: H,W,C = dY (same H,W)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -324,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
     const int pos = (i * 4 + wave_u) * 1024 + lane * 16;
     const int row = pos / (RS * 2), col = pos - row * (RS * 2);
     wvoff[i] = (unsigned)(((size_t)(c0 + (row < BC ? row : 0)) * g.Ktot) * 2 + (col < 128 ? col : 0));
+    if (DEEP && row >= BC) wvoff[i] = OOB_OFFSET;      // the padding pieces of the deep schedule's stage: zero fill
   }
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.src, 0, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2), 0x00020000);
@@ -358,8 +380,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
       const int q = i * 4 + wave_u;
-      if (NQ % 4 == 0 || q < NQ) vfs_dma16_async(wrs, sW + buf * (BC * RS) + q * 512, wvoff[i], wcol);
+      if (DEEP || NQ % 4 == 0 || q < NQ) vfs_dma16_async(wrs, sW + buf * WST + q * 512, wvoff[i], wcol);
     }
+  };
+
+  // DEEP: the patch as PQ DMA pieces per wave: lane l of piece q fills bytes q * 1024 + 16 l = (patch row, column) of the padded
+  // buffer; padding pixels, the 32-byte row padding and the rows past the patch are sent out of range (zeros)
+  const vfs_rsrc_words xrw = vfs_make_rsrc_words(a.src, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2));
+  unsigned pdoff[DEEP ? PQ : 1];
+  if (DEEP) {
+#pragma unroll
+    for (int i = 0; i < PQ; ++i) {
+      const int pos = (i * 4 + wave_u) * 1024 + lane * 16;
+      const int pr = pos / (RS * 2), col = pos - pr * (RS * 2);
+      unsigned off = OOB_OFFSET;
+      if (pr < PROWS && col < 128) {
+        const int ti = pr / (PH * PW), rem = pr - ti * (PH * PW);
+        const int py = rem / PW, px = rem - py * PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px, n = tn0 + ti;
+        if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W && n < g.N)
+          off = (unsigned)((((size_t)(n * g.H + y) * g.W + x) * g.C) * 2 + col);
+      }
+      pdoff[i] = off;
+    }
+  }
+  auto dma_patch = [&](int cc, int buf) {
+#pragma unroll
+    for (int i = 0; i < PQ; ++i) vfs_dma16_async(xrw, sP + buf * PSZ + (i * 4 + wave_u) * 512, pdoff[i], cc * 128);
   };
 
   // ---- per-lane fragment bases: everything else in the main loop is an immediate offset
@@ -390,13 +437,149 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto mma = [&](const bf16x8* af, const bf16x8* bf) {
+#if HALO_WHATIF & 4
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(af[tm]), "v"(bf[tm]));
+#else
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+#endif
   };
 
+  const int S = 9 * nchunk;      // steps of the flat (chunk, tap) sequence; step s = 9 cc + tap
+  if constexpr (DEEP) {
+    // ---------------- deep schedule (round 5) ----------------
+    // What-if builds of the two-stage loop on the 16 x 16 / 8 x 8 layers (one workgroup per CU, one wave per SIMD) showed its
+    // phases ADDING UP instead of overlapping - fragment reads + MFMAs + weight DMA + barriers, an in-order wave that reads,
+    // waits, multiplies, then issues DMA - and tools/probe_mfma_rate.hip showed the 16x16x32 MFMA sustaining 1.47 PFLOP/s
+    // chip-wide in this pattern where the 32x32x16 one sustains 2.43 (MEASUREMENTS.md).  Here
+    //   * v_mfma_f32_32x32x16_bf16, wave tile 64 channels x 64 pixels = 2 x 2 tiles; a tap's 16 MFMAs carry, in their issue
+    //     shadows, the 16 fragment reads of the NEXT tap (second register set) and the DMA pieces of the step FOUR taps ahead
+    //   * stage s % NW holds step s; at the top of tap s that stage is free (its fragments were read during tap s - 1, behind a
+    //     barrier) and takes step s + NW; stage s + 1 is being read, s + 2 must land by the end of the tap, s + 3 is in flight
+    //   * the patch of chunk cc + 1 is requested at the top of chunk cc (other buffer) and has landed by the end of its tap 2
+    //   * the accumulators meet the shared epilogue through one LDS transposition into the 16x16 layout it is written for
+    // K is summed 16 at a time instead of 32: results equal the two-stage kernel's to fp32 rounding, not bit for bit.
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    // The tap body is BRANCH-FREE (round 5 what-ifs: with the wait ladder and the tail / last-chunk conditions compiled into ~15
+    // scalar branches per tap, a tap of MFMAs alone took 0.40 us where the bare MFMA stream takes 0.22): every tap issues exactly
+    // WQ weight pieces per wave and every chunk PQ patch pieces - past the end of the sequence they are sent out of range
+    // (zero fill into a stage / buffer nobody reads any more) - so the wait counts are compile-time constants of the tap index.
+    static_assert(NW == 4 && WQ * 4 == NQD, "the deep schedule's wait counts assume a four-stage ring of equal pieces");
+    const vfs_lds_t lds_w = vfs_lds_addr(sW), lds_p = vfs_lds_addr(sP);
+    dma_patch(0, 0);
+#pragma unroll
+    for (int d = 0; d < NW; ++d) dma_w(d / 9, d % 9, d);          // S >= 9 > NW
+    vfs_dma_wait_all();
+    __syncthreads();
+    // fragment addresses of the 32-row layout: lane l = row l % 32 (channel / pixel), k offset 8 (l / 32) inside a 16-deep step
+    const int l32 = lane & 31, lk = (lane >> 5) * 8;
+    const int abase32 = (wc * 64 + l32) * RS + lk;
+    int pbase32[2];
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {      // MFMA column l % 32 of column tile tq = pixel (tn = 2 tq + (l % 32) / 16, lr = l % 16) of the epilogue's layout
+      int ti, py, px;
+      halo_pixel<SMALLW>(wp, 2 * tq + (l32 >> 4), l32 & 15, ti, py, px);
+      pbase32[tq] = (ti * (PH * PW) + py * PW + px) * RS + lk;
+    }
+    bf16x8 fa[2][4][2], fb[2][4][2];                               // [register set][16-deep k step][tile]
+    const bf16_t* sPc = sP;                                        // patch buffer of the current chunk
+    auto rd_a = [&](int buf, int ks, int tq) { return *reinterpret_cast<const bf16x8*>(sW + buf * WST + abase32 + tq * 32 * RS + ks * 16); };
+    auto rd_b = [&](const bf16_t* patch, int tap, int ks, int tq) { return *reinterpret_cast<const bf16x8*>(&patch[pbase32[tq] + tap_shift(tap) + ks * 16]); };
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq) { fa[0][ks][tq] = rd_a(0, ks, tq); fb[0][ks][tq] = rd_b(sPc, 0, ks, tq); }
+    __syncthreads();              // everybody holds step 0's fragments: tap 0 may overwrite stage 0 with step NW
+    f32x16 acc32[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    int wbuf = 0, pbuf = 0;
+    auto chunk = [&](auto parity, int cc) {
+      constexpr int P = decltype(parity)::value;
+      // the next chunk's patch into the other buffer (past the last chunk: out of range, zero fill)
+      {
+        const unsigned pso = cc + 1 < nchunk ? (unsigned)(cc + 1) * 128u : OOB_OFFSET;
+        const vfs_lds_t dst = lds_p + (vfs_lds_t)((pbuf ^ 1) * PSZ * 2);
+#pragma unroll
+        for (int i = 0; i < PQ; ++i) vfs_dma16_async_at(xrw, dst + (vfs_lds_t)((i * 4 + wave_u) * 1024), pdoff[i], pso);
+      }
+      const bf16_t* sPn = sP + (pbuf ^ 1) * PSZ;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int cur = (P * 9 + tap) & 1, nxt = cur ^ 1;
+        const int s = cc * 9 + tap;
+        const int ntap = (tap + NW) % 9, ncc = cc + (tap + NW) / 9;
+        const unsigned wcol = s + NW < S ? (unsigned)((ntap * g.C + ncc * 64) * 2) : OOB_OFFSET;   // past the end: zero fill
+        const int nstage = wbuf + 1 == NW ? 0 : wbuf + 1;            // stage of step s + 1
+        const vfs_lds_t wdst = lds_w + (vfs_lds_t)(wbuf * WST * 2 + wave_u * 1024);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (!(HALO_WHATIF & 8)) {
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {      // (the last tap of the last chunk reads a stage / buffer of zeros: never used)
+              fa[nxt][ks][tq] = rd_a(nstage, ks, tq);
+              fb[nxt][ks][tq] = tap < 8 ? rd_b(sPc, tap + 1, ks, tq) : rd_b(sPn, 0, ks, tq);
+            }
+          }
+          if (!(HALO_WHATIF & 1)) {               // pieces 2 ks, 2 ks + 1 of this wave's WQ
+#pragma unroll
+            for (int i = 2 * ks; i < 2 * ks + 2 && i < WQ; ++i) vfs_dma16_async_at(wrs, wdst + (vfs_lds_t)(i * 4096), wvoff[i], wcol);
+          }
+#if !(HALO_WHATIF & 4)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ks][i], fb[cur][ks][j], acc32[i][j], 0, 0, 0);
+#else
+          asm volatile("" ::"v"(fa[cur][ks][0]), "v"(fb[cur][ks][0]), "v"(fa[cur][ks][1]), "v"(fb[cur][ks][1]));
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // step s + 2 has landed (this wave's pieces; everybody's behind the barrier): steps s + 3, s + 4 - and, in a chunk's first
+        // two taps, the next chunk's patch pieces, issued behind step s + 3's - stay in flight
+        if (tap <= 1) vfs_dma_wait<2 * WQ + PQ>(); else vfs_dma_wait<2 * WQ>();
+        if (!(HALO_WHATIF & 2)) __syncthreads();
+        wbuf = nstage;
+      }
+      pbuf ^= 1;
+      sPc = sPn;
+    };
+    for (int cc = 0; cc < ((HALO_WHATIF & 32) ? 0 : nchunk); cc += 2) {
+      chunk(std::integral_constant<int, 0>{}, cc);
+      if (cc + 1 < nchunk) chunk(std::integral_constant<int, 1>{}, cc + 1);
+    }
+    vfs_dma_wait_all();                // the zero-fill pieces of the last taps
+    __syncthreads();
+    // ---- accumulators -> the 16x16 layout of the epilogue, through LDS (the ring is idle: the last tap waited for everything)
+    // 32x32 tile (i, j), register 4 q + r of lane l: channel 32 i + 8 q + 4 (l / 32) + r, pixel index 32 j + l % 32
+    constexpr int TR = 68;                                         // floats per pixel row of the transposition slab (64 + 4: odd multiple of 16 bytes)
+    static_assert((NPB * PSZ + NW * WST) * 2 >= 4 * 64 * TR * 4, "transposition slab does not fit");
+    float* slab32 = reinterpret_cast<float*>(smem) + wave * (64 * TR);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(&slab32[(32 * j + l32) * TR + 32 * i + 8 * q + 4 * (lane >> 5)]) =
+              (f32x4){acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
+    __builtin_amdgcn_wave_barrier();   // wave-private slab, in-order LDS pipe
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = *reinterpret_cast<const f32x4*>(&slab32[(tn * 16 + lr) * TR + tm * 16 + lq * 4]);
+    __syncthreads();                   // the epilogue's output stage overlaps the other waves' slabs
+  } else {
+  // ---------------- two-stage schedule: the tap's weight tile is requested one tap ahead ----------------
   load_patch(0);
   dma_w(0, 0, 0);
   store_patch();
@@ -413,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
       const bool last_tap = tap == 8;
       const bool more = !last_tap || more_chunks;
       // next tap's weights: DMA issued FIRST so that the L2 round trip hides under this tap's MFMAs
-      if (more) dma_w(last_tap ? cc + 1 : cc, last_tap ? 0 : tap + 1, wbuf ^ 1);
+      if (more && !(HALO_WHATIF & 1)) dma_w(last_tap ? cc + 1 : cc, last_tap ? 0 : tap + 1, wbuf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       const bf16_t* wsrc = sW + wbuf * (BC * RS) + abase;
       // k-step 0 operands: b0 was read before the barrier; k-step 1 operands are read now and
@@ -430,15 +613,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a) {
         store_patch();
       }
       vfs_dma_wait_all();                          // this wave's pieces of the next weight tile landed
-      __syncthreads();
+      if (!(HALO_WHATIF & 2)) __syncthreads();
       if (last_tap && more_chunks) read_b(b0, 0, 0);
       wbuf ^= 1;
     }
   }
+  }
 
   // the loop's final barrier has passed: no wave reads the patch / weight tiles any more
+  if (HALO_WHATIF & 16) return;
   halo_epilogue_dispatch<BC, SMALLW, RAGGED>(a, acc, &sRed[0][0][0], smem, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
+
+int vfs_option_halo_deep_max = 256;   // the four-stage weight ring (one workgroup per CU) for launches of at most this many workgroups (0: never)
 
 template <int BC, bool DGRAD, bool SMALLW>
 static int launch_halo(const ConvArgs& a0, hipStream_t stream) {
@@ -449,6 +636,12 @@ static int launch_halo(const ConvArgs& a0, hipStream_t stream) {
   const int tiles = ((a.g.N + TI - 1) / TI) * ((a.g.H + TH - 1) / TH) * ((a.g.W + TW - 1) / TW);
   const int ncb = a.Cout / BC;
   const bool ragged = a.g.H % TH != 0 || a.g.W % TW != 0;
+  if (BC == 128 && !a.in_bnp && tiles * ncb <= vfs_option_halo_deep_max) {
+    constexpr int NWD = BC == 128 ? 4 : 2;     // (only the 128-channel tile has equal DMA piece counts in every wave)
+    if (ragged) hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, true, NWD>), dim3(tiles * ncb), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, false, NWD>), dim3(tiles * ncb), dim3(256), 0, stream, a);
+    return vfs_check_launch("conv3x3_halo");
+  }
   if (ragged) hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, true>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv3x3_halo_kernel<BC, DGRAD, SMALLW, false>), dim3(tiles * ncb), dim3(256), 0, stream, a);
   return vfs_check_launch("conv3x3_halo");

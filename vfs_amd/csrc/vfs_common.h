@@ -82,6 +82,22 @@ __device__ __forceinline__ void vfs_dma16_async(vfs_rsrc_words rsrc, void* lds_w
       : "v"(voffset), "s"(lds_addr), "s"(rsrc), "s"(soffset)
       : "memory");
 }
+// the same with the LDS byte address given as a wave-uniform 32-bit value (one s_add per piece instead of a generic-pointer
+// conversion with its null check) and m0 declared clobbered instead of saved and restored: 4 instructions per piece instead of 10
+typedef unsigned vfs_lds_t;
+__device__ __forceinline__ vfs_lds_t vfs_lds_addr(const void* lds) {
+  typedef __attribute__((address_space(3))) const void* lds_cptr;
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)lds);
+}
+__device__ __forceinline__ void vfs_dma16_async_at(vfs_rsrc_words rsrc, vfs_lds_t lds_addr, unsigned voffset, unsigned soffset) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %2, %3 offen lds"
+      :
+      : "v"(voffset), "s"(lds_addr), "s"(rsrc), "s"(soffset)
+      : "memory", "m0");
+}
 __device__ __forceinline__ void vfs_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's vector-memory operations (DMA pieces) are still in flight
 template <int N>

@@ -104,7 +104,7 @@ extern int vfs_option_igemm_pw, vfs_option_igemm_pw_min_tiles;
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode);
 // maps of at most 8x8 pixels that fill most of an 8x8 tile (8x8, 7x7 with the default 70 %): the halo kernels take
 // two whole images per workgroup
-extern int vfs_option_halo_min_fill, vfs_option_halo_xcd;
+extern int vfs_option_halo_min_fill, vfs_option_halo_xcd, vfs_option_halo_deep_max;
 static inline bool vfs_small_map(int H, int W) { return H <= 8 && W <= 8 && H * W * 100 >= 64 * vfs_option_halo_min_fill; }
 int vfs_conv_halo_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode);
