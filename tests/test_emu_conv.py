@@ -91,6 +91,9 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (1, 28, 28, 64, 64, 3, 1, 1),     # halo-tile kernel, RAGGED 16x16 tiles (28 x 28)
     (3, 7, 14, 128, 128, 3, 1, 1),    # halo-tile kernel, ragged bottom row only, odd image count
     (4, 7, 7, 64, 128, 3, 1, 1),      # halo-tile kernel, whole 7x7 images in pairs (8x8 tiles, masked)
+    (2, 16, 16, 64, 128, 3, 2, 1),    # stride-2 3x3 on an evenly tiled map: linear-address weight gradient with per-step row validity (LIN = 2)
+    (3, 32, 32, 128, 64, 3, 2, 1),    # the same, 16-wide output rows, odd image count, two K-steps per tap
+    (4, 8, 8, 128, 128, 1, 2, 0),     # stride-2 1x1 (downsample unit), 4-wide output rows: sixteen rows per 64-pixel step
 ]
 
 

@@ -30,7 +30,7 @@ def both(lib, fn):
         try:
             outs.append(fn())
         finally:
-            lib.set_option(b'igemm_pw', 1)
+            lib.set_option(b'igemm_pw', 0)
     lib.set_option(b'igemm_narrow_below', 513)
     return outs
 

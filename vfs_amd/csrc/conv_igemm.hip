@@ -105,25 +105,23 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   // (3 workgroups per CU: VALU busy 78 %, not HBM: 3.4 TB/s).
   const bool pure = (MODE == GATHER_FWD || MODE == GATHER_DGRAD) && g.KH * g.KW == 1 && g.stride == 1 && g.pad == 0 &&
                     g.H == g.Ho && g.W == g.Wo;
-  unsigned xbase[4], xmask[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + row0 + 32 * i;
+  // descriptor of destination pixel m, 16-byte chunk jc of its gathered rows: byte offset base (mod 2^32) + tap validity bits
+  auto row_desc = [&](int m, int jc, unsigned& xb, unsigned& xm) {
     unsigned mask = 0;
     long long base = 0;
     if (pure) {
-      if (m < Mc) { base = (long long)m * g.C + j * 8; mask = 1u; }
+      if (m < Mc) { base = (long long)m * g.C + jc * 8; mask = 1u; }
     } else if (m < Mc) {
       const int hw = Hc * Wc;
       const int n = m / hw;
       const int rem = m - n * hw;
       const int hc = rem / Wc, wcx = rem - hc * Wc;
       if (MODE == GATHER_STEM) {
-        const int hb = 2 * hc - 3 + (j >> 2), wi = 2 * wcx - 4 + 2 * (j & 3);
+        const int hb = 2 * hc - 3 + (jc >> 2), wi = 2 * wcx - 4 + 2 * (jc & 3);
         base = ((long long)(n * g.H + hb) * g.W + wi) * 4;
         const bool wok = (unsigned)wi < (unsigned)g.W;
         for (int kt = 0; kt < 4; ++kt) {
-          const int r = 2 * kt + (j >> 2), hi = hb + 2 * kt;
+          const int r = 2 * kt + (jc >> 2), hi = hb + 2 * kt;
           if (wok && r < 7 && (unsigned)hi < (unsigned)g.H) mask |= 1u << kt;
         }
       } else {
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
         if (MODE == GATHER_FWD) { hb = hc * g.stride - g.pad; wb = wcx * g.stride - g.pad; }
         else if (MODE == GATHER_DGRAD) { hb = hc + g.pad; wb = wcx + g.pad; }
         else { hb = hc; wb = wcx; }
-        base = ((long long)(n * g.H + hb) * g.W + wb) * g.C + j * 8;
+        base = ((long long)(n * g.H + hb) * g.W + wb) * g.C + jc * 8;
         for (int ri = 0; ri < nr; ++ri)
           for (int si = 0; si < ns; ++si) {
             const int r = r0 + tstep * ri, s = s0 + tstep * si;
@@ -143,8 +141,13 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
           }
       }
     }
-    xbase[i] = (unsigned)(base * 2);
-    xmask[i] = mask;
+    xb = (unsigned)(base * 2);
+    xm = mask;
+  };
+  unsigned xbase[4], xmask[4];
+  if (PIPE < 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_desc(m0 + row0 + 32 * i, j, xbase[i], xmask[i]);
   }
   unsigned wbase[WLD];
   bool wok[WLD];
@@ -171,9 +174,8 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     l_ti = kbeg / cpt; l_cc = kbeg - l_ti * cpt;
     l_ri = l_ti / ns; l_si = l_ti - l_ri * ns;
   }
-  auto load_tiles = [&](int kt) {                // called with kt = 0, 1, 2, ... in order
-    // uniform decode of the K-step: tap index, source delta (bytes), weight column (bytes)
-    int ti, delta, wcol;
+  // uniform decode of the NEXT K-step (called with kt = kbeg, kbeg + 1, ... in order): tap index, source delta, weight column (bytes)
+  auto step_decode = [&](int kt, int& ti, int& delta, int& wcol) {
     if (MODE == GATHER_STEM) {
       ti = kt; delta = 2 * kt * g.W * 4 * 2; wcol = kt * 64 * 2;
     } else {
@@ -191,6 +193,10 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       delta = ((dh * g.W + dw) * g.C + cc) * 2;
       wcol = ((r * g.KW + s) * g.C + cc) * 2;
     }
+  };
+  auto load_tiles = [&](int kt) {                // called with kt = kbeg, kbeg + 1, ... in order
+    int ti, delta, wcol;
+    step_decode(kt, ti, delta, wcol);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned off = ((xmask[i] >> ti) & 1u) ? xbase[i] + (unsigned)delta : OOB_OFFSET;
@@ -220,12 +226,21 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     const vfs_rsrc_words xrw = vfs_make_rsrc_words(a.src, (unsigned)((size_t)g.N * g.H * g.W * g.C * 2));
     const vfs_rsrc_words wrw = vfs_make_rsrc_words(a.wgt, (unsigned)((size_t)a.Cout * g.Ktot * 2));
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned xvo[XQ], wvo[WQ];
+    // lane l of a piece lands at piece_base + 16 l: it FETCHES the (row, chunk) whose swizzled slot that is.  Pure GEMM: rows
+    // past the ragged end re-fetch the tile's first row (their outputs are masked by the epilogue); gathers (round 5: 3x3 /
+    // strided layers, the stride-2 dgrad classes): a row's taps that fall on padding - and every tap of a row past M - are sent
+    // out of range, where the DMA writes zeros (tools/probe_dma_oob.hip)
+    unsigned xvo[XQ], xvm[XQ], wvo[WQ];
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
       const int slot = (wave_u * XQ + q) * 64 + lane, row = slot >> 3, chunk = (slot & 7) ^ ((row >> 1) & 7);
-      const int m = m0 + row < Mc ? m0 + row : m0;
-      xvo[q] = (unsigned)(((size_t)m * g.C) * 2 + chunk * 16);
+      if (pure) {
+        const int m = m0 + row < Mc ? m0 + row : m0;
+        xvo[q] = (unsigned)(((size_t)m * g.C) * 2 + chunk * 16);
+        xvm[q] = 1u;
+      } else {
+        row_desc(m0 + row, chunk, xvo[q], xvm[q]);
+      }
     }
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
@@ -234,10 +249,20 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       wvo[q] = (unsigned)(((size_t)c * g.Ktot) * 2 + chunk * 16);
     }
     auto issue = [&](int kt, int st) {
+      if (pure) {
 #pragma unroll
-      for (int q = 0; q < XQ; ++q) vfs_dma16_async(xrw, sX[st] + (wave_u * XQ + q) * 512, xvo[q], (unsigned)kt * 128u);
+        for (int q = 0; q < XQ; ++q) vfs_dma16_async(xrw, sX[st] + (wave_u * XQ + q) * 512, xvo[q], (unsigned)kt * 128u);
 #pragma unroll
-      for (int q = 0; q < WQ; ++q) vfs_dma16_async(wrw, sW[st] + (wave_u * WQ + q) * 512, wvo[q], (unsigned)kt * 128u);
+        for (int q = 0; q < WQ; ++q) vfs_dma16_async(wrw, sW[st] + (wave_u * WQ + q) * 512, wvo[q], (unsigned)kt * 128u);
+      } else {
+        int ti, delta, wcol;
+        step_decode(kt, ti, delta, wcol);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+          vfs_dma16_async(xrw, sX[st] + (wave_u * XQ + q) * 512, ((xvm[q] >> ti) & 1u) ? xvo[q] + (unsigned)delta : OOB_OFFSET, 0u);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) vfs_dma16_async(wrw, sW[st] + (wave_u * WQ + q) * 512, wvo[q], (unsigned)wcol);
+      }
     };
     constexpr int RING = 3;
 #pragma unroll
@@ -324,6 +349,7 @@ int vfs_option_igemm_narrow_below = 513;   // 64-channel tiles when the 128-chan
 int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a K-step before its MFMAs (prepared, not yet measured)
 int vfs_option_igemm_ring_fbn = 1;      // the DMA ring also for dgrads with fused BatchNorm-backward statistics (A/B knob)
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
+int vfs_option_igemm_ring_gather = 0;      // DMA ring for GATHERED problems (3x3 / strided forward, stride-1 and stride-2 dgrad classes) with at most this many tiles (0: off)
 int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
 
 template <int BC, int MODE, int PIPE = 0, bool FBN = false>
@@ -382,6 +408,19 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   if (ring) {
     if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(a, stream) : launch_igemm<64, GATHER_FWD, 3>(a, stream);
     return wide ? launch_igemm<128, GATHER_DGRAD, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3>(a, stream);
+  }
+  // gathered problems with a long reduction (round 5): 3x3 stride-2 forward / dgrad, strided 1x1, ragged-map 3x3 - one dependent
+  // chain of 18-72 K-steps per workgroup, a full memory round trip per step on the register double buffer
+  {
+    int cls = mode == GATHER_DGRAD && a.g.stride == 2 ? 4 : 1;
+    const long long mcls = cls == 4 ? (long long)a.g.N * ((a.g.Ho + 1) / 2) * ((a.g.Wo + 1) / 2) : a.g.M;
+    const long long gtiles = ((mcls + 127) / 128) * ((a.Cout + bc - 1) / bc) * cls;
+    const bool gring = vfs_option_igemm_ring_gather > 0 && !ring && a.g.KH * a.g.KW > 0 && a.g.Ktot >= 256 && a.ksplit <= 1 &&
+                       gtiles <= vfs_option_igemm_ring_gather && !a.bn.partial &&
+                       !(a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0);
+    if (gring && mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 3>(a, stream) : launch_igemm<64, GATHER_FWD, 3>(a, stream);
+    if (gring && mode == GATHER_DGRAD && a.g.stride == 1) return wide ? launch_igemm<128, GATHER_DGRAD, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3>(a, stream);
+    if (gring && mode == GATHER_DGRAD && a.g.stride == 2) return wide ? launch_igemm<128, GATHER_DGRAD2, 3>(a, stream) : launch_igemm<64, GATHER_DGRAD2, 3>(a, stream);
   }
   switch (mode) {
     case GATHER_FWD:

@@ -20,7 +20,7 @@
 // after a tile's last K-step (T: the last stage is free) and the epilogue's own (the loaders mirror them).
 #include "vfs_igemm_epi.h"
 
-int vfs_option_igemm_pw = 1;          // 0: off; 1: where the plan below says so; 2: every eligible 1x1
+int vfs_option_igemm_pw = 0;          // 0: off (default: measured slower than the one-tile kernels, MEASUREMENTS.md round 5); 1: where the plan below says so; 2: every eligible 1x1
 int vfs_option_igemm_pw_min_tiles = 192;   // fewer 128-pixel tiles than this leave CUs idle: the split-channel kernels take over
 
 template <int BC, bool FBN>

@@ -30,11 +30,14 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const bf16_t* tile, int lo_off, int
 // path re-derives (n, h, w) -> address for every 16-byte load (~230 VALU instructions per 64-pixel step, more than twice
 // the issue time of the step's 32 MFMAs, and with ONE wave per SIMD nothing hides them: SQ counters of the 2048 -> 512
 // layer: VALU busy 30 %, MFMA busy 14 %, the rest waits); here a load is `buffer_load voffset` with voffset += one step.
-template <int BCW, int MODE, bool LIN = false>
+// LIN = 2 (round 5): the same idea for 3x3 / 1x1 convolutions with stride 1 or 2 whose maps tile evenly (H = stride Ho, W = stride
+// Wo, Wo | 64, 4 | Wo: the stride-2 layers of the ResNets - 6 launches of ResNet-50 that ran at 108 us each on the generic path).
+// Output pixel (R, wo) of GLOBAL row R = n Ho + ho reads input pixel (stride R + r - pad, stride wo + s - pad) - linear in R
+// across image boundaries because H = stride Ho - so a lane's byte offset advances by a CONSTANT per 64-pixel step; only the tap's
+// validity changes: the column test is fixed per lane, the row test follows ho (one add per step).
+template <int BCW, int MODE, int LIN = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BKC = 128;        // k-columns per workgroup (two forward K-steps)
-  constexpr int TM = 4;           // 64 k-columns per wave
-  constexpr int TN = BCW / 32;    // (BCW/2) couts per wave
   // pixel-major tiles: per buffer two k-column halves [64 px][64 + pad] and BCW/64 cout tiles
   constexpr int TILE = 64 * WG_RS, DT = BCW / 64;
   __shared__ __attribute__((aligned(16))) bf16_t sA[2][2 * TILE];
@@ -109,16 +112,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   u32x4 av[4], dv[4];
   // LIN: per-lane byte offsets of the four rows this lane fetches; rows past M are past num_records (zero fill); lanes
   // without work (k-columns past Ktot, the idle half of the dY loaders) stay at WG_OOB (their step is 0)
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, LIN ? (unsigned)((size_t)g.M * g.C * 2) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, LIN ? (unsigned)((size_t)g.N * g.H * g.W * g.C * 2) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, LIN ? (unsigned)((size_t)g.M * a.Cout * 2) : 0u, 0x00020000);
   unsigned xvo[4], dvo[4];
-  const unsigned xstep = (LIN && a_ok) ? 64u * (unsigned)g.C * 2u : 0u, dstep = (LIN && d_active) ? 64u * (unsigned)a.Cout * 2u : 0u;
+  unsigned xstep = (LIN && a_ok) ? 64u * (unsigned)g.C * 2u : 0u;
+  const unsigned dstep = (LIN && d_active) ? 64u * (unsigned)a.Cout * 2u : 0u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     xvo[i] = (LIN && a_ok) ? (unsigned)((((size_t)pix_begin + a_pg * 4 + i) * g.C + a_kt * 64 + a_j * 8) * 2) : WG_OOB;
     dvo[i] = (LIN && d_active) ? (unsigned)((((size_t)pix_begin + d_pg * 4 + i) * a.Cout + cb * BCW + d_cj * 8) * 2) : WG_OOB;
   }
+  // LIN = 2: tap (r, s) of this lane's k-columns; the four pixels of a lane lie in one output row (4 | Wo)
+  int l2_ho = 0, l2_dho = 0, l2_hb = 0;
+  unsigned l2_wv = 0;         // bit i: column of pixel i inside the map
+  if (LIN == 2 && a_ok) {
+    const int m = pix_begin + a_pg * 4, R = m / g.Wo, wo0 = m - R * g.Wo;
+    const int dh = 64 / g.Wo;
+    l2_ho = R % g.Ho;
+    l2_dho = dh % g.Ho;
+    l2_hb = a_ks.r - g.pad;
+    xstep = (unsigned)(dh * g.stride * g.W * g.C * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int wi = (wo0 + i) * g.stride + a_ks.s - g.pad;
+      if ((unsigned)wi < (unsigned)g.W) l2_wv |= 1u << i;
+      const long long pix = ((long long)R * g.stride + a_ks.r - g.pad) * g.W + wi;
+      xvo[i] = (unsigned)((pix * g.C + a_ks.c0 + a_j * 8) * 2);
+    }
+  }
   auto load_tiles = [&](int it) {   // must be called with it = 0, 1, 2, ... in order
+    if (LIN == 2) {
+      const unsigned hv = (unsigned)(l2_ho * g.stride + l2_hb) < (unsigned)g.H ? l2_wv : 0u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ((hv >> i) & 1u) ? xvo[i] : WG_OOB, 0, 0); xvo[i] += xstep; }
+      l2_ho += l2_dho;
+      if (l2_ho >= g.Ho) l2_ho -= g.Ho;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dv[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, dvo[i], 0, 0); dvo[i] += dstep; }
+      return;
+    }
     if (LIN) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { av[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[i], 0, 0); xvo[i] += xstep; }
@@ -153,18 +185,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       for (int i = 0; i < 4; ++i) st16(&sD[buf][(d_cj >> 3) * TILE + (d_pg * 4 + i) * WG_RS + (d_cj & 7) * 8], dv[i]);
     }
   };
-  // fragment geometry (conv_wgrad_halo.hip): MFMA k index 8*lq + 4*h + e of k-step ks <-> tile pixel
-  // 32*ks + 16*h + 4*lq + e; a lane points at pixel row pl and its 4-channel run chq
-  const int lr = lane & 15, lq = lane >> 4;
-  const int pl = 4 * lq + (lr >> 2), chq = (lr & 3) * 4;
-  const int a_base = wm * TILE + pl * WG_RS + chq;                                   // wave = k-column half wm
+  // fragment geometry (conv_wgrad_halo.hip; round 5: v_mfma_f32_32x32x16_bf16 - the 16x16x32 shape sustains 1.47 PFLOP/s chip-wide
+  // in this pattern, the 32x32x16 shape 2.43, tools/probe_mfma_rate.hip): a k-step is 16 pixels; MFMA row m = lane % 32 = channel,
+  // lane / 32 = k half (k = 8 (lane / 32) + 0..7 <-> pixel 16 st + k).  The four 16-lane groups of a wave are (channels 0-15 |
+  // 16-31) x (k half 0 | 1); inside a group one transpose read hands lane i the element of channel i at the four pixel rows the
+  // group's lanes point at (lane i points at pixel row i / 4, channel run i % 4).
+  const int l16 = lane & 15, h2 = lane >> 5;
+  const int pl = 8 * h2 + (l16 >> 2), chq = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+  const int a_base = wm * TILE + pl * WG_RS + chq;                                   // wave = k-column half wm (64 columns: two 32-row tiles)
   const int d_base = (BCW == 128 ? wn * TILE : wn * 32) + pl * WG_RS + chq;          // 64 (or 32) couts of the wave
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  constexpr int QM = 2, QN = BCW / 64;    // 32 x 32 tiles of the wave: k-columns x couts
 
-  f32x4 acc[TM][TN];
+  f32x16 acc[QM][QN];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int tm = 0; tm < QM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tn = 0; tn < QN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
 
   load_tiles(0);
   store_tiles(0);
@@ -174,40 +213,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const bool more = it + 1 < iters;
     if (more) load_tiles(it + 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[TM], bfr[TN];
+    for (int st = 0; st < 4; ++st) {
+      bf16x8 af[QM], bfr[QN];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-        af[tm] = wg_tr_frag(sA[cur] + a_base, (32 * ks) * WG_RS + tm * 16, (32 * ks + 16) * WG_RS + tm * 16);
+      for (int tm = 0; tm < QM; ++tm)
+        af[tm] = wg_tr_frag(sA[cur] + a_base, (16 * st) * WG_RS + tm * 32, (16 * st + 4) * WG_RS + tm * 32);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        bfr[tn] = wg_tr_frag(sD[cur] + d_base, (32 * ks) * WG_RS + tn * 16, (32 * ks + 16) * WG_RS + tn * 16);
+      for (int tn = 0; tn < QN; ++tn)
+        bfr[tn] = wg_tr_frag(sD[cur] + d_base, (16 * st) * WG_RS + tn * 32, (16 * st + 4) * WG_RS + tn * 32);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < QM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < QN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
+  // D[k-column][cout] (32 x 32 tiles): register 4 q + r of lane l = k-column 8 q + 4 (l / 32) + r, cout l % 32 -> 16-byte stores
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int cout = cb * BCW + wn * (BCW / 2) + tn * 16 + lr;
+  for (int tn = 0; tn < QN; ++tn) {
+    const int cout = cb * BCW + wn * (BCW / 2) + tn * 32 + (lane & 31);
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int kc = kb * BKC + wm * 64 + tm * 16 + lq * 4;
-      if (kc < g.Ktot)
-        *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) = acc[tm][tn];
-    }
+    for (int tm = 0; tm < QM; ++tm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kc = kb * BKC + wm * 64 + tm * 32 + 8 * q + 4 * h2;
+        if (kc < g.Ktot)
+          *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
+              (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
+      }
   }
 }
 
 int vfs_option_wgrad_xcd = 1;   // XCD-aware block order of the generic weight-gradient kernel (A/B knob)
+int vfs_option_wgrad_lin2 = 1;  // ... and its generalisation to evenly tiled 3x3 / stride-2 problems (A/B knob)
 int vfs_option_wgrad_lin = 1;   // the linear-address path for 1x1 / stride-1 problems (A/B knob)
 
-template <int BCW, int MODE, bool LIN = false>
+template <int BCW, int MODE, int LIN = 0>
 static int launch_wgrad(const WgradArgs& a0, hipStream_t stream) {
   WgradArgs a = a0;
   int nkb = (a.g.Ktot + 127) / 128;
@@ -226,7 +270,13 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
   const size_t rows = (size_t)a.g.M + a.pix_per_split, widest = (size_t)(a.g.C > a.Cout ? a.g.C : a.Cout);
   const bool lin = vfs_option_wgrad_lin && mode == GATHER_FWD && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
                    a.g.H == a.g.Ho && a.g.W == a.g.Wo && rows * widest * 2 < 0xFFF00000ull;
-  if (lin) return wide ? launch_wgrad<128, GATHER_FWD, true>(a, stream) : launch_wgrad<64, GATHER_FWD, true>(a, stream);
+  if (lin) return wide ? launch_wgrad<128, GATHER_FWD, 1>(a, stream) : launch_wgrad<64, GATHER_FWD, 1>(a, stream);
+  // evenly tiled 3x3 / 1x1 with stride 1 or 2 (LIN = 2)
+  const size_t inrows = (size_t)a.g.N * a.g.H * a.g.W + (size_t)a.pix_per_split * a.g.stride * a.g.stride + 4 * (size_t)a.g.W;
+  const bool lin2 = vfs_option_wgrad_lin >= 1 && vfs_option_wgrad_lin2 && mode == GATHER_FWD && a.g.KH == a.g.KW && (a.g.KH == 1 || a.g.KH == 3) && a.g.pad == a.g.KH / 2 &&
+                    (a.g.stride == 1 || a.g.stride == 2) && a.g.dil == 1 && a.g.H == a.g.stride * a.g.Ho && a.g.W == a.g.stride * a.g.Wo &&
+                    a.g.Wo % 4 == 0 && 64 % a.g.Wo == 0 && a.g.C % 64 == 0 && inrows * (size_t)a.g.C * 2 < 0xFFF00000ull && rows * (size_t)a.Cout * 2 < 0xFFF00000ull;
+  if (lin2) return wide ? launch_wgrad<128, GATHER_FWD, 2>(a, stream) : launch_wgrad<64, GATHER_FWD, 2>(a, stream);
   if (mode == GATHER_FWD) return wide ? launch_wgrad<128, GATHER_FWD>(a, stream) : launch_wgrad<64, GATHER_FWD>(a, stream);
   if (mode == GATHER_STEM) return launch_wgrad<64, GATHER_STEM>(a, stream);
   return vfs_set_error(VFS_ERR_ARG, "conv_wgrad: bad mode");

@@ -89,6 +89,9 @@ __device__ __forceinline__ vfs_lds_t vfs_lds_addr(const void* lds) {
   typedef __attribute__((address_space(3))) const void* lds_cptr;
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)lds);
 }
+// (m0 is a reserved register: clang warns that it cannot promise to keep a clobbered one - nothing in these kernels lives in it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void vfs_dma16_async_at(vfs_rsrc_words rsrc, vfs_lds_t lds_addr, unsigned voffset, unsigned soffset) {
   asm volatile(
       "s_mov_b32 m0, %1\n\t"
@@ -98,6 +101,7 @@ __device__ __forceinline__ void vfs_dma16_async_at(vfs_rsrc_words rsrc, vfs_lds_
       : "v"(voffset), "s"(lds_addr), "s"(rsrc), "s"(soffset)
       : "memory", "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ void vfs_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's vector-memory operations (DMA pieces) are still in flight
 template <int N>
