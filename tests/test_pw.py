@@ -145,3 +145,36 @@ def test_pw_bench_shapes_bit_identical(gpu_backend, N, H, W, Cin, Cout):
     assert torch.equal(y1, y0) and torch.equal(s1, s0) and torch.equal(d1, d0)
     ref = torch.nn.functional.conv2d(x[:2].float().permute(0, 3, 1, 2), wf.float().permute(0, 3, 1, 2))
     assert relerr(y1[:2].float().permute(0, 3, 1, 2), ref) < 6e-3
+
+
+@pytest.mark.parametrize('M,Cin,Cout', [(64, 2048, 512), (40, 256, 64), (128, 512, 2048), (8, 128, 16), (97, 384, 48)])
+def test_skinny_linear_layers(backend, M, Cin, Cout):
+    """the skinny GEMM of the head's Linear layers (at most 128 rows: four K quarters per workgroup, fragments straight from
+    global memory) - forward with bias, dgrad with a residual operand - against torch (fp32, same bf16 operands) and against
+    the implicit-GEMM kernel (equal up to one bf16 rounding: the K quarters are summed in another order)"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(M + Cin + Cout)
+    x = rb(torch.randn(M, Cin, generator=g))
+    w = rb(torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    wf, wd = pack(backend, w.reshape(Cout, Cin, 1, 1))
+    outs = []
+    for flag in (1, 0):
+        lib.set_option(b'igemm_skinny', flag)
+        try:
+            y = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+            lib.conv_fwd(d(x.to(torch.bfloat16)), wf, y, d(bias), None, M, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 0, None)
+            res = [y.float().cpu()]
+            if Cout % 128 == 0 and Cin % 16 == 0:     # the dgrad's K is Cout
+                dy = rb(torch.randn(M, Cout, generator=torch.Generator().manual_seed(7)))
+                add = rb(torch.randn(M, Cin, generator=torch.Generator().manual_seed(8)))
+                dx = torch.full((M, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+                lib.conv_dgrad(d(dy.to(torch.bfloat16)), wd, dx, d(add.to(torch.bfloat16)), M, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 0, None)
+                res.append(dx.float().cpu())
+                assert relerr(res[1], dy @ w + add) < 6e-3
+            outs.append(res)
+        finally:
+            lib.set_option(b'igemm_skinny', 1)
+    assert relerr(outs[0][0], x @ w.t() + bias) < 6e-3
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.isfinite(a_).all() and relerr(a_, b_) < 8e-3

@@ -77,6 +77,7 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "halo_xcd")) { vfs_option_halo_xcd = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_fbn")) { vfs_option_igemm_ring_fbn = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_gather")) { vfs_option_igemm_ring_gather = value; return VFS_OK; }
+  if (!strcmp(name, "igemm_skinny")) { vfs_option_igemm_skinny = value; return VFS_OK; }
   if (!strcmp(name, "igemm_pw")) { vfs_option_igemm_pw = value; return VFS_OK; }
   if (!strcmp(name, "igemm_pw_min_tiles")) { vfs_option_igemm_pw_min_tiles = value; return VFS_OK; }
   if (!strcmp(name, "igemm_ring_upfront")) { vfs_option_igemm_ring_upfront = value; return VFS_OK; }

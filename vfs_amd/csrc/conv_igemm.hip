@@ -386,6 +386,7 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   if (a.g.dil != 1 && mode != GATHER_FWD) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: dilation is forward-only");
   if (a.bn.partial && (mode != GATHER_DGRAD || a.g.stride != 1))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: fused BatchNorm-backward statistics need a stride-1 dgrad");
+  if (vfs_conv_skinny_eligible(a, mode)) return vfs_conv_skinny_dispatch(a, stream);   // at most 128 rows (conv_pw.hip)
   if (vfs_conv_pw_eligible(a, mode)) return vfs_conv_pw_dispatch(a, mode, stream);   // persistent kernel (conv_pw.hip)
   // 128-channel tiles, unless that leaves the chip under-filled (deep stages: 16x16 / 8x8 maps, the head): with fewer than
   // igemm_narrow_below tiles the 64-channel tile doubles the workgroups - two latency-bound K chains per CU instead of one

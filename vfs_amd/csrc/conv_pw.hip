@@ -182,3 +182,72 @@ int vfs_conv_pw_dispatch(const ConvArgs& a, int mode, hipStream_t stream) {
   if (a.bn.partial) return wide ? launch_pw<128, GATHER_DGRAD, true>(a, stream) : launch_pw<64, GATHER_DGRAD, true>(a, stream);
   return wide ? launch_pw<128, GATHER_DGRAD, false>(a, stream) : launch_pw<64, GATHER_DGRAD, false>(a, stream);
 }
+
+// ------------------------------------------------------------------ skinny GEMM (the SimSiam head's Linear layers)
+//   out[m][c] = sum_k X[m][k] * Wt[c][k]   (+bias[c]) (+add[m][c])      for M <= 128 rows
+// Replaces nn.Linear forward / dgrad of the reference's SimSiamHead (mmaction/models/heads/sim_siam_head.py:78-111: projection
+// and predictor MLPs on the pooled [B*T, 2048] features).  With 64 rows the implicit-GEMM tiling (128 pixels x 64 channels) has
+// 32 workgroups on 256 CUs, each walking 32 dependent K-steps: 17-21 us for 8 MB of weights (1.4 us at the HBM roof).  Here a
+// workgroup owns 16 output channels x 32 rows, its four waves each take a QUARTER of K with fragments loaded straight from global
+// memory into MFMA operand registers (a lane's 16 bytes = 8 consecutive k of one row: exactly the 16x16x32 fragment) - no LDS
+// stage, no barrier in the loop, many independent loads in flight - and meet once in LDS.  Cout / 16 x ceil(M / 32) workgroups.
+int vfs_option_igemm_skinny = 1;      // A/B knob
+
+__global__ __launch_bounds__(256) void conv_skinny_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float sAcc[4][2][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int M = a.g.M, K = a.g.Ktot, C = a.Cout;
+  const int ncb = C >> 4;
+  const int cb = blockIdx.x % ncb, mb = blockIdx.x / ncb;
+  const int c0 = cb * 16, m0 = mb * 32;
+  const int kq = K >> 2;                                  // K % 128 == 0: whole 32-deep steps per wave
+  const bf16_t* wrow = a.wgt + (size_t)(c0 + lr) * K + wave * kq + lq * 8;
+  const int r0 = m0 + lr < M ? m0 + lr : M - 1, r1 = m0 + 16 + lr < M ? m0 + 16 + lr : M - 1;   // rows past M: clamped, masked at the store
+  const bf16_t* x0 = a.src + (size_t)r0 * K + wave * kq + lq * 8;
+  const bf16_t* x1 = a.src + (size_t)r1 * K + wave * kq + lq * 8;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int steps = kq >> 5;
+#pragma unroll 4
+  for (int s = 0; s < steps; ++s) {
+    const bf16x8 af = *reinterpret_cast<const bf16x8*>(wrow + s * 32);
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(x0 + s * 32);
+    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(x1 + s * 32);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b1, acc1, 0, 0, 0);
+  }
+  *reinterpret_cast<f32x4*>(&sAcc[wave][0][lane][0]) = acc0;
+  *reinterpret_cast<f32x4*>(&sAcc[wave][1][lane][0]) = acc1;
+  __syncthreads();
+  if (wave < 2) {      // wave w finishes row tile w: lane = (channel quad lq, row lr); the K quarters add up in wave order
+    f32x4 v = *reinterpret_cast<const f32x4*>(&sAcc[0][wave][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&sAcc[w][wave][lane][0]);
+    const int m = m0 + wave * 16 + lr, c = c0 + lq * 4;
+    if (m < M) {
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += a.bias[c + r];
+      }
+      if (a.add) {
+        const u32x2 ad = ld8(a.add + (size_t)m * C + c);
+        v[0] += bflo(ad.x); v[1] += bfhi(ad.x); v[2] += bflo(ad.y); v[3] += bfhi(ad.y);
+      }
+      u32x2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      st8(a.out + (size_t)m * C + c, pk);
+    }
+  }
+}
+
+bool vfs_conv_skinny_eligible(const ConvArgs& a, int mode) {
+  if (!vfs_option_igemm_skinny || (mode != GATHER_FWD && mode != GATHER_DGRAD)) return false;
+  if (a.g.KH * a.g.KW != 1 || a.g.stride != 1 || a.g.pad != 0 || a.g.H != a.g.Ho || a.g.W != a.g.Wo || a.ksplit > 1) return false;
+  return a.g.M <= 128 && a.g.Ktot % 128 == 0 && a.Cout % 16 == 0 && !a.stats && !a.bn.partial && !a.add_mask && a.g.C == a.g.Ktot;
+}
+
+int vfs_conv_skinny_dispatch(const ConvArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(conv_skinny_kernel, dim3((a.Cout / 16) * ((a.g.M + 31) / 32)), dim3(256), 0, stream, a);
+  return vfs_check_launch("conv_skinny");
+}

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
   const ConvGeom g = a.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;            // wave = 32 cin x 32 cout, all taps
+  const int lr = lane & 15, lq = lane >> 4;
   const int nchunk = g.C >> 6, ncb = a.Cout >> 6;
   int b = blockIdx.x;
   if (a.xcd_swizzle) {      // XCD-aware block order (see conv_wgrad.hip): the (cin chunk, cout block) tiles of one split share an L2
@@ -129,22 +130,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     for (int i = 0; i < 4; ++i) st16(&sD[(row0 + 32 * i) * RS + j * 8], dv[i]);
   };
 
-  // fragment geometry (round 5: v_mfma_f32_32x32x16_bf16 - tools/probe_mfma_rate.hip: the 16x16x32 shape sustains 1.47 PFLOP/s
-  // chip-wide in this pattern, the 32x32x16 shape 2.43).  A k-step is 16 pixels (one row of the 8x16 tile / two rows of an 8x8
-  // image); MFMA row m = lane % 32 = channel (cin for A, cout for B), lane / 32 = k half: k = 8 (lane / 32) + 0..7.  The four
-  // 16-lane groups of a wave are (channels 0-15 | 16-31) x (k half 0 | 1); inside a group one transpose read hands lane i the
-  // element of channel i at the four pixel rows the group's lanes point at (lane i points at pixel row i / 4, channel run i % 4).
-  //   k = 8 h2 + 4 h + e  <->  pixel 16 st + k of the tile      (h: lo / hi read, e = (lane % 16) / 4)
-  // Everything except the lane's own (k half, pixel row, channel run) is a compile-time constant.
-  const int l16 = lane & 15, h2 = lane >> 5;
-  const int chq = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;  // this lane's 4-channel run inside the wave's 32 channels
-  const int pl = 8 * h2 + (l16 >> 2);                      // pixel of the k-step this lane points at (lo read; hi: + 4)
+  // fragment geometry: MFMA k index (8*lq + 4*h + e) of k-step ks <-> tile pixel
+  //   p = 32*ks + 16*h + 4*lq + e        (e = lr>>2: the pixel row this lane points at)
+  // so a transpose read (fixed h) covers 16 consecutive pixels and everything except the lane's
+  // own (lq, e, channel run) is a compile-time constant
+  const int pl = 4 * lq + (lr >> 2);                       // 0..15
+  const int chq = (lr & 3) * 4;                            // this lane's 4-channel run
   const int d_base = pl * RS + wn * 32 + chq;
-  const int x_base = (SMALLW ? h2 * PW + (l16 >> 2) : pl) * RS + wm * 32 + chq;
-  auto xrow = [](int st) {                                 // patch row of pixel 16 st (tap 0,0), constexpr-foldable
-    return SMALLW ? (st >> 2) * (PH * PW) + 2 * (st & 3) * PW : st * PW;
+  const int x_base = (SMALLW ? (pl >> 3) * PW + (pl & 7) : pl) * RS + wm * 32 + chq;
+  auto xrow = [](int ks, int h) {                          // patch row of pixel 32ks+16h (tap 0,0), constexpr-foldable
+    const int p = 32 * ks + 16 * h;
+    return SMALLW ? (p >> 6) * (PH * PW) + ((p >> 3) & 7) * PW : (p >> 4) * PW;
   };
-  typedef __attribute__((ext_vector_type(16))) float f32x16;
 
   if (BNIN) {   // up to 8 groups x {scale, shift} x this chunk's 64 channels
     const int ngroups = min(8, (g.N + a.in_npg - 1) / a.in_npg);
@@ -154,11 +151,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     }
     __syncthreads();
   }
-  f32x16 acc[9];
+  f32x4 acc[9][2][2];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[tp][e] = 0.f;
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) acc[tp][tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int t_begin = split * tiles_per_split;
   const int t_end = min(ntiles, t_begin + tiles_per_split);
@@ -169,27 +168,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     for (int tile = t_begin; tile < t_end; ++tile) {
       const bool more = tile + 1 < t_end;
       if (more) load_tile(tile + 1);
-      // 72 items (16-pixel step st, tap tp) per tile, ONE MFMA each.  The launch plans give a CU one workgroup - one wave per SIMD -
-      // and an in-order wave that reads a fragment, waits for the LDS round trip, multiplies, 72 times over, spent ~5 us per tile
-      // on ~1 us of MFMAs (round 5).  Software pipeline: the transpose reads of item i + 3 are issued in front of the MFMA of
-      // item i (ring of four A fragments, the dY fragment of the next step fetched mid-step); sched_barrier keeps the order (left
-      // alone the compiler hoists every read of the tile and spills).
-      {
-        auto rd_a = [&](int idx) {
-          const int st = idx / 9, tp = idx % 9, shift = (tp / 3) * PW + (tp % 3);
-          return tr_frag(sP + x_base, (xrow(st) + shift) * RS, (xrow(st) + shift + 4) * RS);
-        };
-        bf16x8 ring[4], bcur = tr_frag(sD + d_base, 0, 4 * RS), bnext = bcur;
+      // the two-image tile needs ~20 more address / staging registers: fully unrolled it only fits one
+      // wave per SIMD (472 registers) and ran at 640 TFLOP/s; rolled k-steps keep it at two waves
+#pragma unroll(SMALLW ? 1 : 4)
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 bfr[2];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ring[i] = rd_a(i);
+        for (int tn = 0; tn < 2; ++tn)
+          bfr[tn] = tr_frag(sD + d_base, (32 * ks) * RS + tn * 16, (32 * ks + 16) * RS + tn * 16);
 #pragma unroll
-        for (int idx = 0; idx < 72; ++idx) {
-          const int st = idx / 9, tp = idx % 9;
-          if (idx + 3 < 72) ring[(idx + 3) & 3] = rd_a(idx + 3);
-          if (tp == 4 && st + 1 < 8) bnext = tr_frag(sD + d_base, (16 * (st + 1)) * RS, (16 * (st + 1) + 4) * RS);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[idx & 3], bcur, acc[tp], 0, 0, 0);
-          if (tp == 8) bcur = bnext;
-          __builtin_amdgcn_sched_barrier(0);
+        for (int tp = 0; tp < 9; ++tp) {
+          const int shift = (tp / 3) * PW + (tp % 3);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const bf16x8 af = tr_frag(sP + x_base, (xrow(ks, 0) + shift) * RS + tm * 16, (xrow(ks, 1) + shift) * RS + tm * 16);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              acc[tp][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[tn], acc[tp][tm][tn], 0, 0, 0);
+          }
         }
       }
       __syncthreads();            // everyone is done reading this tile
@@ -200,17 +196,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     }
   }
 
-  // D[cin][cout] (32 x 32 per tap): register 4 q + r of lane l = cin 8 q + 4 (l / 32) + r, cout l % 32 -> 16-byte stores
+  // D[cin][cout]: lane holds 4 consecutive cin of cout = lane&15 -> one 16-byte store
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-    const int cout = cb * 64 + wn * 32 + (lane & 31);
+  for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int kc = tp * g.C + cc * 64 + wm * 32 + 8 * q + 4 * h2;
-      *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
-          (f32x4){acc[tp][4 * q], acc[tp][4 * q + 1], acc[tp][4 * q + 2], acc[tp][4 * q + 3]};
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cout = cb * 64 + wn * 32 + tn * 16 + lr;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int kc = tp * g.C + cc * 64 + wm * 32 + tm * 16 + lq * 4;
+        *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) = acc[tp][tm][tn];
+      }
     }
-  }
 }
 
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode) {

@@ -100,7 +100,9 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
 // conv_pw.hip: persistent producer / consumer kernel for pure-GEMM (1x1, stride 1) problems
 bool vfs_conv_pw_eligible(const ConvArgs& a, int mode);
 int vfs_conv_pw_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
-extern int vfs_option_igemm_pw, vfs_option_igemm_pw_min_tiles;
+extern int vfs_option_igemm_pw, vfs_option_igemm_pw_min_tiles, vfs_option_igemm_skinny;
+bool vfs_conv_skinny_eligible(const ConvArgs& a, int mode);      // M <= 128 rows: the head's Linear layers
+int vfs_conv_skinny_dispatch(const ConvArgs& a, hipStream_t stream);
 bool vfs_conv_halo_eligible(const ConvArgs& a, int mode);
 // maps of at most 8x8 pixels that fill most of an 8x8 tile (8x8, 7x7 with the default 70 %): the halo kernels take
 // two whole images per workgroup
