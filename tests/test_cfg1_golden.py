@@ -217,15 +217,16 @@ def test_hip_train_step_vs_reference_golden_at_224(gpu_backend, name, depth):
 
 
 @pytest.mark.gpu
-def test_hip_train_step_end_to_end_vs_fp32_oracle_32_frames_per_view(gpu_backend):
-    """End to end where the comparison CAN resolve something: ResNet-18, imgs [32,2,3,1,224,224] (BatchNorm batches of 32 frames, the
-    bench's batch).  Reference = the oracle in fp32 (pinned to the real reference at this crop by test_oracle_matches_reference_at_224),
+@pytest.mark.parametrize('depth', [18, 50])
+def test_hip_train_step_end_to_end_vs_fp32_oracle_32_frames_per_view(gpu_backend, depth):
+    """End to end where the comparison CAN resolve something: ResNet-18 and (round 5) ResNet-50 - the headline configuration's
+    network at its batch - imgs [32,2,3,1,224,224] (BatchNorm batches of 32 frames, the bench's batch).  Reference = the oracle in fp32 (pinned to the real reference at this crop by test_oracle_matches_reference_at_224),
     yardstick = four bf16-storage emulation draws (their error ratios scatter 0.75 .. 1.33 at this size, build container).
     HIP vs fp32: loss <= 3 x the largest draw + 2e-4, layer4 features <= 1.1 x the largest draw (1.89e-2 in every draw: what is
     left is bf16 storage), every gradient norm <= 1.5 x the largest draw + 0.05, median gradient-norm error <= 1.5 x the largest
     draw's median (draws: 0.7 - 0.9 %).  Calibration (build container, four further draws as stand-ins for the HIP step): medians
     0.5 - 0.8 %, single parameters up to 0.039 above 1.5 x the largest draw, features 1.0009 x, loss 0.9 x."""
-    depth, shape = 18, [32, 2, 3, 1, 224, 224]
+    shape = [32, 2, 3, 1, 224, 224]
     imgs = O.fill_tensor(shape, seed=11, scale=2.0)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     ref, _, log32, feats32 = _oracle_step(depth, imgs, False)
@@ -262,7 +263,7 @@ def test_hip_train_step_end_to_end_vs_fp32_oracle_32_frames_per_view(gpu_backend
     table['worst gradient-norm error HIP'] = max((mine['norm'][n], n) for n in names)
     table['largest (HIP error - 1.5 x largest draw) over the parameters (bar 0.05)'] = max(mine['norm'][n] - 1.5 * top[n] for n in names)
     print(table)
-    _keep('r18_b32_224_end_to_end', table)
+    _keep(f'r{depth}_b32_224_end_to_end', table)
     if not med_hip <= 1.5 * max(m for _, m in med_draws):
         failed.append(('median', med_hip, med_draws))
     assert not failed, failed
