@@ -60,10 +60,18 @@ def train(rank, world, out):
     per = imgs.shape[0] // world
     local = imgs[rank * per:(rank + 1) * per].to(dev)
     opt = vfs_amd.build_optimizer(model, cfg.optimizer)
+    poison = os.environ.get('VFS_TEST_POISON_RANK')
+    before = None
     for step in range(int(os.environ.get('VFS_TEST_STEPS', '1'))):
         batch = local if step == 0 else (local * (1.0 + 0.25 * step)).contiguous()
         o = model.train_step(dict(imgs=batch, label=torch.zeros(per, 1, device=dev)), None)
         opt.zero_grad()
+        if poison is not None and step == int(os.environ.get('VFS_TEST_STEPS', '1')) - 1:
+            # the last step: ONE rank's exchange "timed out" (its error word is set, as vfs_p2p.h does) - no rank may update
+            torch.cuda.synchronize()
+            before = {n: p.detach().clone() for n, p in model.named_parameters()}
+            if rank == int(poison):
+                eng._p2p.state[1] = 1
         o['loss'].backward()
         opt.step()
     torch.cuda.synchronize()
@@ -74,6 +82,9 @@ def train(rank, world, out):
     for n, b in model.named_buffers():
         if 'running' in n:
             res['buf/' + n] = b.cpu().numpy().copy()
+    if before is not None:
+        res['poison_unchanged'] = int(all(torch.equal(before[n], p.detach()) for n, p in model.named_parameters()))
+        res['poison_word'] = int(eng._p2p.state[1].item())
     res['p2p_active'] = int(eng._p2p is not None)
     res['p2p_exchanges'] = int(eng._p2p.state[0].item()) if eng._p2p is not None else 0
     np.savez(out, **res)

@@ -232,3 +232,19 @@ def test_two_processes_one_gpu_train_steps_equal_collective_path(gpu_backend, tm
         if k.startswith(('param/', 'grad/', 'buf/')):
             assert np.array_equal(p2p[0][k], p2p[1][k]), k
     assert n > 50
+
+
+@pytest.mark.gpu
+def test_two_processes_one_gpu_poisoned_step_is_skipped_on_every_rank(gpu_backend, tmp_path):
+    """ONE rank's SyncBN exchange times out in the last of two steps (its error word set, as vfs_p2p.h does): the word is
+    MAX-reduced behind the gradient buckets, so BOTH ranks' sgd_step leaves the weights untouched and both end with the word set
+    (round 4 advisor finding: only the failing rank skipped, the healthy rank - the checkpoint writer - applied its peer's
+    gradients)"""
+    r = _run_two(tmp_path, 'poison', 'train', dict(VFS_SYNCBN_P2P='1', VFS_TEST_STEPS='2', VFS_TEST_POISON_RANK='1'))
+    for k in range(2):
+        assert int(r[k]['p2p_active']) == 1
+        assert int(r[k]['poison_unchanged']) == 1, f'rank {k} applied a poisoned step'
+        assert int(r[k]['poison_word']) != 0
+    for key in r[0].files:
+        if key.startswith('param/'):
+            assert np.array_equal(r[0][key], r[1][key]), key

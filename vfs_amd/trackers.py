@@ -509,6 +509,13 @@ class SimSiamBaseTracker(BaseTracker):
         finally:
             eng.defer_wgrad = False
         eng.wgrad_join(dev)
+        x = eng._p2p
+        if eng.collectives_on and x is not None and x.state.device == dev:
+            # SyncBN window exchange: a rank whose wait timed out has NaN statistics, skips its own update (optim.py) - and has
+            # just sent NaN gradients into the buckets above.  The error word is MAX-reduced over the ranks behind the last
+            # bucket, so EVERY rank's sgd_step sees it and leaves weights and momentum untouched: the replicas stay identical
+            # and the checkpoint writer never holds a poisoned step (round 4 advisor finding: the guard was local).
+            eng.record(self._issue_allreduce, x.state[1:2], dist.ReduceOp.MAX)
         eng.record(self._wait_works)
         if self._bf16_pending:                  # bf16 buckets: back to the fp32 gradient arena once the collectives are done
             stage, g = eng.bufs['ddp.grad_bf16'], self._flat['grads']
