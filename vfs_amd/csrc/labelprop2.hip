@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     // no score passes it: the sixteen threshold tests come FIRST (two instructions each) and the geometry - key coordinates, circle
     // mask, candidate id - is worked out only for the scores that passed, only in waves that have one (with one wave per SIMD and
     // no MFMA in flight here, every vector instruction of this epilogue is exposed: the mask-first form spent ~190 per key block)
-    const float thr_e = lp2_dec(sThr[myq]) - a.margin;
+    const float thr_e = (a.dbg & 16) ? -INFINITY : lp2_dec(sThr[myq]) - a.margin;      // (dbg 16, tests: list EVERY in-mask candidate with its s~)
     unsigned long long hot = 0;      // lanes with a score above the threshold: sixteen compares, OR-ed on the scalar side
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) hot |= __ballot(tot[rg] >= thr_e);
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void lp2_refine_kernel(Lp2Args a) {
 
 // ---------------------------------------------------------------------------------------------
 int vfs_option_lp2 = 1;            // 0: always the dense kernel (A/B knob)
-int vfs_option_lp2_dbg = 0;        // what-if timing (WRONG results): 2 = cache-hot key traffic, 4 = no lists
+int vfs_option_lp2_dbg = 0;        // what-if timing (WRONG results): 2 = cache-hot key traffic, 4 = no lists; 16 = list every in-mask candidate (results unchanged: tests read the s~ of the lists)
 int vfs_option_lp2_fpb = 0;        // pass 1: key frames per workgroup; 0 = chosen per launch (vfs_lp2_splits)
 int vfs_option_lp2_trim = 1;       // pass 1: windows of masked key frames trimmed to the columns the tile can reach (0: rectangles, A/B knob)
 int vfs_option_lp2_cap = 0;        // list entries per (key-frame split, query); 0 = the workspace shared out among the splits in use
