@@ -274,6 +274,20 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
         return float(tm.item()), out
     dt, out = timed()
     log(f'{K} propagated frames: {dt / K * 1e3:.3f} ms/frame')
+    # steady state: every frame from the 21st on propagates from the full key window (first + 20 preceding frames); the first 20
+    # have fewer key frames (and cold thresholds).  steady = (whole clip - its first 21 frames) / the frames in between
+    steady = None
+    if K > 24:
+        head = imgs[:, :, :, :21].contiguous()
+        run(head)
+        torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(head)
+        torch.cuda.synchronize()
+        dt_head = time.perf_counter() - t0
+        steady = (dt - dt_head) / (K - 20) * 1e3
+        log(f'first 20 propagated frames: {dt_head / 20 * 1e3:.3f} ms/frame; steady state (21 key frames): {steady:.3f} ms/frame')
     C = 256 if depth == 18 else 1024
     radius = int(tc['neighbor_range']) // 2
     res = {'metric': f'DAVIS label propagation frames/sec (R{depth} res4, 480x854, first + 20 preceding key frames)',
@@ -284,6 +298,7 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
                                   f'attention (top-10, tau 0.07, radius {radius}, first + 20 preceding frames) + upsample/min-max/argmax, '
                                   f'one {K + 1}-frame 480x854 clip per GPU, {args.precision} evaluation path',
                       'frames_per_clip': K + 1, 'parallelism': f'replicas x{world}'},
+           'steady_state_ms_per_frame': steady,
            'labels_present': sorted(int(v) for v in np.unique(out[0][-1]))}
     if rank == 0 and not args.no_roofline:
         eng.prof = []
@@ -312,10 +327,12 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
             fl, tm, cnt, nb = agg[kind]
             # the two-pass label propagation scores on the bf16 matrix path (three products per candidate): its roof is the bf16 peak
             fpeak = PEAK_BF16_TFLOPS if kind == 'labelprop_2pass' else peak
-            hbm_bound = nb / (PEAK_HBM_GBS * 1e9) >= fl / (fpeak * 1e12)
+            # (the two-pass label propagation is a contraction: priced against the matrix roof whichever way the byte model falls)
+            hbm_bound = nb / (PEAK_HBM_GBS * 1e9) >= fl / (fpeak * 1e12) and kind != 'labelprop_2pass'
             ach, pk, unit = (nb / tm / 1e9, PEAK_HBM_GBS, 'GB/s') if hbm_bound else (fl / tm / 1e12, fpeak, 'TFLOP/s')
             tr = tclasses.get(kind, {}).get('hbm_bytes_per_launch')
-            return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': pk, 'unit': unit, 'frac': ach / pk,
+            ex = {'executed_frac': 3.0 * ach / pk, 'executed_TFLOP/s': 3.0 * ach} if (kind == 'labelprop_2pass' and not hbm_bound) else {}
+            return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': pk, 'unit': unit, 'frac': ach / pk, **ex,
                     'traffic': tr, 'traffic_ratio': (tr / (nb / cnt)) if (tr and nb) else None, 'launches': cnt, 'avg_launch_ms': tm / cnt * 1e3, 'time_share_of_kernels': tm / tot,
                     'algorithmic_flop_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
         kind = max(agg, key=lambda k: agg[k][1])
@@ -323,8 +340,9 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
         res['roofline']['traffic_source'] = tsource
         res['roofline']['note'] = ('FLOP = the affinity INSIDE the circular mask only (2 * C * in-mask (query, key) pairs per key frame; the '
                                    'dense T*HW x HW product the reference executes is not counted); labelprop_2pass (csrc/labelprop2.hip, same '
-                                   'bits as the dense fp32 kernel): THREE bf16 products per in-mask pair (hi.hi + hi.lo + lo.hi of the split '
-                                   'bank) against the dense bf16 MFMA peak (2.5 PFLOP/s) - the kernel EXECUTES ~2x these products (the window union of an '
+                                   'bits as the dense fp32 kernel): frac counts ONE product per in-mask pair (SURVEY 8(d)) against the dense bf16 MFMA peak '
+                                   '(2.5 PFLOP/s); executed_frac = the THREE bf16 products per pair the kernel runs for it (hi.hi + hi.lo + lo.hi of the split '
+                                   'bank) - it EXECUTES ~2x these again (the window union of an '
                                    '8 x 8 query tile against the in-mask keys of one query) with ONE wave per SIMD (the query tile fills the register '
                                    'file), whose in-order instruction stream is the limit (matrix pipe ~30 % busy; phase timers in MEASUREMENTS.md); '
                                    'other families: peak = dense '
@@ -359,7 +377,7 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='davis workload: evaluation precision')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-davis', action='store_true', help='train workload: skip the DAVIS leg appended to the JSON line (N = 1 only)')
-    ap.add_argument('--davis-frames', type=int, default=30, help='propagated frames of the appended DAVIS leg')
+    ap.add_argument('--davis-frames', type=int, default=49, help='propagated frames of the appended DAVIS leg (49: the T = 50 clip of BASELINE configs[3] / SURVEY 8(d) Cfg 4)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--min-seconds', type=float, default=0.0,
                     help='make the timed region at least this long: the number of timed steps is raised to ceil(min_seconds / step time) '
@@ -497,10 +515,28 @@ def main():
     # ---- roofline: per-kernel HIP events need eager launches (a graph replay is one launch), so the
     # same number of steps is repeated eagerly right after the timed region with an event pair around
     # every conv launch (events pre-created; only hipEventRecord is added)
-    prof, dt_prof = None, None
-    if not args.no_roofline:
-        # one stream for this leg: with the weight-gradient kernels running concurrently on the side
-        # stream a per-kernel event pair would time two overlapping kernels, not one
+    prof, dt_prof, prof_mode = None, None, None
+    tape_mode = os.environ.get('VFS_TAPE', '1') == '1' and not (world == 1 and os.environ.get('VFS_GRAPHS', '0') == '1')
+    if not args.no_roofline and tape_mode:
+        # per-kernel durations of the schedule that was TIMED: the same command-tape replay (weight gradients on the side stream,
+        # overlapping the dgrad chain) with every C-ABI launch bracketed by HIP events on the stream it is launched on
+        # (vfs_amd/_lib.py Tape.timing); the one eager launch of the step (SGD) through the engine's own event pair
+        from vfs_amd._lib import Tape
+        Tape.timing, eng.prof = [], []
+        step()
+        torch.cuda.synchronize()
+        per_step = len(Tape.timing) + len(eng.prof)
+        Tape.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step * args.steps + 64)]
+        eng.prof_pool = [torch.cuda.Event(enable_timing=True) for _ in range(4 * args.steps + 16)]
+        Tape.timing, eng.prof = [], []
+        dt_prof, _ = timed(args.steps)
+        prof, Tape.timing, eng.prof, Tape.event_pool = Tape.timing + eng.prof, None, None, None
+        prof_mode = (f'{args.steps} steps of the TIMED schedule (command-tape replay, two streams) right after the timed region, HIP events '
+                     f'around every launch on its own stream: {dt_prof / args.steps * 1e3:.2f} ms/step with the events')
+        log(f'{args.steps} replayed steps with per-kernel events: {dt_prof / args.steps * 1e3:.2f} ms/step')
+    elif not args.no_roofline:
+        # (hipGraph / eager launch modes) one stream for this leg: with the weight-gradient kernels running concurrently on the side
+        # stream a per-kernel event pair on torch's current stream would time two overlapping kernels, not one
         side_prev = os.environ.get('VFS_SIDE_STREAM')
         os.environ['VFS_SIDE_STREAM'] = '0'
         eng.prof = []
@@ -512,6 +548,8 @@ def main():
         dt_prof, _ = timed(args.steps)
         log(f'{args.steps} eager steps with per-kernel events: {dt_prof / args.steps * 1e3:.2f} ms/step')
         prof, eng.prof = eng.prof, None
+        prof_mode = (f'{args.steps} eager single-stream steps right after the timed region (FALLBACK: not the timed schedule), '
+                     f'{dt_prof / args.steps * 1e3:.2f} ms/step (HIP events around every launch)')
         if side_prev is None:
             os.environ.pop('VFS_SIDE_STREAM')
         else:
@@ -584,9 +622,9 @@ def main():
             return {'kernel': kind, 'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': ach, 'peak': peak, 'unit': unit,
                     'frac': ach / peak, 'traffic': tr, 'launches_per_step': cnt / args.steps, 'avg_launch_ms': tm / cnt * 1e3,
                     'kernel_ms_per_step': tm / args.steps * 1e3,
-                    # share of the REPORTED step (command-tape replay, weight gradients on their own stream: families on the two
-                    # streams overlap, so the shares of one step may add up to more than 1) and of the eager single-stream leg
-                    'time_share_of_step': tm / dt, 'time_share_of_eager_step': tm / dt_prof,
+                    # share of the REPORTED step and of the event-instrumented one (weight gradients on their own stream: families on
+                    # the two streams overlap, so the shares of one step may add up to more than 1)
+                    'time_share_of_step': tm / dt, 'time_share_of_profiled_step': tm / dt_prof,
                     'algorithmic_bytes_per_launch': nb / cnt,
                     'algorithmic_flop_per_launch': fl / cnt, 'GB/s': nb / tm / 1e9, 'TFLOP/s': fl / tm / 1e12}
         if os.environ.get('VFS_BENCH_SHAPES'):      # diagnostics: every distinct (family, work) launch of the eager leg with its rate
@@ -596,20 +634,21 @@ def main():
                 a[0] += e0.elapsed_time(e1) * 1e-3
                 a[1] += 1
             with open(os.environ['VFS_BENCH_SHAPES'], 'w') as fsh:
-                fsh.write(f'per-launch table of the eager single-stream leg, {args.steps} steps; sorted by time per step\n')
+                fsh.write(f'per-launch table, {prof_mode}; sorted by time per step\n')
                 for (k, flops, nbytes), (tm, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
                     fsh.write(f'{k:20s} {cnt / args.steps:5.1f}/step  avg {tm / cnt * 1e6:8.1f} us  per-step {tm / args.steps * 1e3:7.3f} ms  '
                               f'{nbytes / 1e6:8.1f} MB  {nbytes / (tm / cnt) / 1e12:5.2f} TB/s  {flops / 1e9:8.2f} GFLOP  {flops / (tm / cnt) / 1e12:7.1f} TFLOP/s\n')
         kind = max(agg, key=lambda k: agg[k][1])
         res['roofline'] = family(kind)
         res['roofline']['traffic_source'] = tsource
-        res['roofline']['measured_over'] = (f'{args.steps} eager single-stream steps right after the timed region, '
-                                            f'{dt_prof / args.steps * 1e3:.2f} ms/step (HIP events around every launch)')
+        res['roofline']['measured_over'] = prof_mode
         # every other family that takes >= 3 % of the step (BatchNorm / streaming kernels included), and what is left
         fams = sorted((k for k in agg if k != kind), key=lambda k: -agg[k][1])
         res['roofline']['families'] = [family(k) for k in fams if agg[k][1] / dt_prof >= 0.03]
         res['roofline']['small_families_time_share'] = sum(agg[k][1] for k in fams if agg[k][1] / dt_prof < 0.03) / dt_prof
-        res['roofline']['unlabelled_time_share'] = max(0.0, 1.0 - sum(v[1] for v in agg.values()) / dt_prof)
+        # launches without a family of their own (C-ABI calls outside Engine.timed: they appear as 'other:<entry point>')
+        res['roofline']['unlabelled_time_share'] = sum(v[1] for k, v in agg.items() if k.startswith('other:')) / dt_prof
+        res['roofline']['kernel_time_over_step'] = sum(v[1] for v in agg.values()) / dt_prof      # > 1: the two streams overlap
         # the same families on the schedule that was TIMED (tape replay, two streams): the committed rocprofv3 --stats summary of
         # this command, when the round has one; `live_over_rocprof` = this run's eager event time / that summary's kernel time
         rp = rocprof_families(f'bench_{args.model}')

@@ -117,15 +117,50 @@ class Tape:
     def __init__(self, lib):
         self.lib = lib
         self.ops = []
+        self.meta = {}          # op index -> (family, algorithmic FLOP, algorithmic bytes) of the launches recorded through Engine.timed
+        self.next_meta = None
 
     host_seconds = 0.0      # diagnostics: host time spent replaying tapes (all tapes of the process)
     slowest = None
+    timing = None           # bench.py: a list -> every C-ABI launch of a replay is bracketed by events ON ITS OWN STREAM (the last
+                            # argument of every launch entry point) and (family, flop, bytes, e0, e1) is appended: per-kernel
+                            # durations of the schedule that is actually timed (two streams, overlapping), not of an eager stand-in
+    _streams = {}
+    event_pool = None       # optional list of pre-created timing events (creating one costs more than recording it)
+
+    def _replay_timed(self):
+        import torch
+        check = self.lib.check
+        out = Tape.timing
+        for i, (name, fn, args) in enumerate(self.ops):
+            if name is None:
+                fn(*args)
+                continue
+            sp = args[-1] if args and (args[-1] is None or isinstance(args[-1], int)) else None
+            st = Tape._streams.get(sp)
+            if st is None:
+                st = torch.cuda.ExternalStream(sp) if sp else torch.cuda.default_stream()
+                Tape._streams[sp] = st
+            pool = Tape.event_pool
+            if pool:
+                e0, e1 = pool.pop(), pool.pop()
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = fn(*args)
+            e1.record(st)
+            kind, flops, nbytes = self.meta.get(i, ('other:' + name, 0.0, 0.0))
+            out.append((kind, flops, e0, e1, nbytes))
+            if rc:
+                check(name, rc)
 
     def replay(self):
         import time
         check = self.lib.check
         t0 = time.perf_counter()
-        if Tape.slowest is not None:          # VFS_TAPE_PROFILE=1: per-op host time, to find a call that blocks
+        if Tape.timing is not None:
+            self._replay_timed()
+        elif Tape.slowest is not None:          # VFS_TAPE_PROFILE=1: per-op host time, to find a call that blocks
             for name, fn, args in self.ops:
                 t1 = time.perf_counter()
                 rc = fn(*args)
@@ -163,6 +198,9 @@ class TapeLib:
         def call(*args):
             conv = tuple(a.data_ptr() if hasattr(a, 'data_ptr') else a for a in args)
             ops.append((name, fn, conv))
+            tape = self._tape
+            if tape.next_meta is not None:
+                tape.meta[len(ops) - 1], tape.next_meta = tape.next_meta, None
             rc = fn(*conv)
             lib.check(name, rc)
             return rc

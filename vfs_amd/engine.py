@@ -140,6 +140,12 @@ class Engine:
         if SKIP and kind in SKIP:      # what-if measurement (VFS_DEBUG_SKIP=family,...): the step WITHOUT this family's launches
             return 0
         if self.prof is None or dev.type != 'cuda':
+            if self.tape is not None:      # recording: the launch carries its family and algorithmic work onto the tape (_lib.Tape.meta)
+                self.tape.next_meta = (kind, flops, nbytes)
+                try:
+                    return fn(*args)
+                finally:
+                    self.tape.next_meta = None
             return fn(*args)
         pool = getattr(self, 'prof_pool', None)
         if pool:                       # pre-created events: creation is the expensive part

@@ -214,9 +214,10 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
             nmask = len(slots) - non_mask_len
             work = (2.0 * C * (nmask * pairs + non_mask_len * float(h * w) ** 2),          # in-mask affinity FLOP
                     float(bank.element_size()) * (len(set(slots)) + 1) * h * w * C)         # every key / query row once
-            if hl is not None:      # same label maps, bit for bit (csrc/labelprop2.hip); algorithmic work: THREE bf16 products per
-                # in-mask (query, key, channel) - hi.hi + hi.lo + lo.hi - and every key / query row once in both copies (fp32 + split)
-                eng.timed('labelprop_2pass', (3.0 * work[0], 2.0 * work[1]), dev, eng.lib.labelprop_f32_2pass, bank, hl, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks,
+            if hl is not None:      # same label maps, bit for bit (csrc/labelprop2.hip); algorithmic work as SURVEY section 8(d) counts it:
+                # ONE product per in-mask (query, key, channel) (the kernel EXECUTES three bf16 products for it - hi.hi + hi.lo + lo.hi:
+                # bench.py reports that as executed_frac) and every key / query row once in both copies (fp32 + split)
+                eng.timed('labelprop_2pass', (work[0], 2.0 * work[1]), dev, eng.lib.labelprop_f32_2pass, bank, hl, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks,
                           len(slots), h, w, C, CO, radius, non_mask_len, topk, temp, 1, s)
             else:
                 eng.timed('labelprop_f32' if exact else 'labelprop', work, dev, lp, bank, sbank, sbank[f], lpws, lpws.numel() * 4, f, ks, len(slots), h, w,
