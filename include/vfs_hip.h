@@ -66,6 +66,16 @@ int vfs_pack_weights(const void* desc, int ntensors, long long total_tiles, vfs_
 int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats,
                  int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                  int pad, vfs_stream_t stream);
+/* vfs_conv_fwd that ALSO sums its statistics rows in groups of 2^coarse_log2 consecutive rows (round 5): the last workgroup of a
+ * group to arrive (device-scope ticket) adds the group's rows in row order (deterministic) into
+ *   stats_coarse: float[ceil(rows / 2^coarse_log2)][2][Cout]          rows = what vfs_conv_fwd writes to `stats`
+ * so that the consumer finishing the BatchNorm statistics in its prologue (vfs_bn_act_fin, at most 128 rows per group) can be
+ * used for the large maps as well and the separate reduction launch between conv and BatchNorm (torch: the batch_norm op's own
+ * statistics pass, resnet.py via mmcv ConvModule) disappears.  tickets: uint32 [ceil(rows / 2^L) * ceil(Cout / 64)], zero before
+ * the first launch, left at zero.  `stats` is still written (the fine rows are the exchange medium). */
+int vfs_conv_fwd_coarse(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, float* stats_coarse,
+                        uint32_t* tickets, int coarse_log2, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                        int stride, int pad, vfs_stream_t stream);
 /* 7x7/2 stem conv (resnet.py:422-434) on NHWC4 input, wf = [64][8][8][4].  stats rows: one per
  * spatial tile of 8x16 output pixels, N*ceil(Ho/8)*ceil(Wo/16) rows of [2][64] (image-major) */
 int vfs_stem_fwd(const vfs_bf16* x4, const vfs_bf16* wf, vfs_bf16* y, float* stats, int N, int H,

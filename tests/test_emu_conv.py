@@ -561,3 +561,40 @@ def test_halo_deep_schedule_matches_two_stage(backend, N, H, W, Cin, Cout):
         xr = x.clone().requires_grad_(True)
         F.conv2d(xr, w, None, 1, 1).backward(dy)
         assert relerr(nchw(outs[0][2]), xr.grad + add) < 6e-3
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,L', [
+    (4, 16, 32, 64, 128, 1, 2),       # implicit-GEMM kernel: 16 rows, groups of 4, one 128-channel tile
+    (3, 16, 16, 64, 192, 1, 1),       # 6 rows in groups of 2, three 64-channel tiles
+    (5, 16, 16, 128, 64, 1, 3),       # 10 rows, groups of 8: the last group holds two rows
+    (4, 16, 32, 64, 128, 3, 2),       # halo kernel, 8x16 tiles (one row per workgroup): 16 rows, groups of 4
+    (2, 32, 32, 64, 64, 3, 2),        # halo kernel, 16x16 tiles (TWO rows per workgroup): 16 rows, groups of 4 = 2 workgroups
+    (6, 8, 8, 64, 128, 3, 1),         # halo kernel, whole 8x8 images in pairs
+])
+def test_conv_forward_coarse_statistics_rows(backend, N, H, W, Cin, Cout, k, L):
+    """vfs_conv_fwd_coarse: same outputs and fine rows as vfs_conv_fwd, and coarse row g = the fine rows 2^L g .. added in row
+    order (fp32, deterministic) by the last workgroup of the group to arrive; the tickets are back at zero (run twice)"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N + H + Cin + Cout + k)
+    pad = k // 2
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    wf, _ = pack(backend, w)
+    nblk = conv_stats_rows(N, 1, H, W, Cin, Cout, k, 1, pad, H, W)
+    ng = (nblk + (1 << L) - 1) >> L
+    y0 = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+    s0 = torch.full((nblk, 2, Cout), float('nan'), device=dev)
+    lib.conv_fwd(d(nhwc(x)), wf, y0, None, s0, N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+    tickets = torch.zeros(ng * ((Cout + 63) // 64), dtype=torch.int32, device=dev)
+    for rep in range(2):
+        y1 = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+        s1 = torch.full((nblk, 2, Cout), float('nan'), device=dev)
+        c1 = torch.full((ng, 2, Cout), float('nan'), device=dev)
+        lib.conv_fwd_coarse(d(nhwc(x)), wf, y1, None, s1, c1, tickets, L, N, H, W, Cin, H, W, Cout, k, k, 1, pad, None)
+        assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(s1.cpu(), s0.cpu())
+        assert int(tickets.cpu().abs().sum()) == 0
+        want = torch.zeros(ng, 2, Cout)
+        fine = s0.cpu()
+        for r in range(nblk):      # row order, fp32
+            want[r >> L] = want[r >> L] + fine[r]
+        assert torch.equal(c1.cpu(), want), float((c1.cpu() - want).abs().max())

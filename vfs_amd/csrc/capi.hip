@@ -101,6 +101,18 @@ int vfs_conv_fwd(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float
   a.in_bnp = nullptr; a.in_npg = 0;
   return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
 }
+int vfs_conv_fwd_coarse(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, float* stats_coarse,
+                        uint32_t* tickets, int coarse_log2, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                        int stride, int pad, vfs_stream_t stream) {
+  if (!stats || !stats_coarse || !tickets || coarse_log2 < 1 || coarse_log2 > 8)
+    return vfs_set_error(VFS_ERR_ARG, "conv_fwd_coarse: stats, stats_coarse, tickets and 1 <= coarse_log2 <= 8");
+  ConvArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.src = x; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
+  a.in_bnp = nullptr; a.in_npg = 0;
+  a.stats_coarse = stats_coarse; a.stats_tickets = tickets; a.coarse_log2 = coarse_log2;
+  return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
+}
 int vfs_conv_fwd_dilated(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, const float* bias, float* stats, int N, int H, int W,
                          int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int dilation, vfs_stream_t stream) {
   if (dilation < 1) return vfs_set_error(VFS_ERR_ARG, "conv_fwd_dilated: dilation >= 1");

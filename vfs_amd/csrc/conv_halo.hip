@@ -247,10 +247,19 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, const f32x4 (&a
     }
     __syncthreads();
     // one partial row per 128 pixels = per pair of pixel-waves (rows tile*WAVES_P/2 + h)
+    const bool coarse = a.coarse_log2 > 0 && a.stats_coarse != nullptr;      // uniform (vfs_conv.h: coarse statistics rows)
     for (int e = t; e < WAVES_P * BC; e += 256) {
       const int h = e / (2 * BC), rem = e - h * 2 * BC, st = rem / BC, cl = rem - st * BC;
       float* dst = a.stats + ((size_t)tile * (WAVES_P / 2) + h) * 2 * a.Cout;
-      dst[st * a.Cout + c0 + cl] = sRed[((2 * h) * 2 + st) * BC + cl] + sRed[((2 * h + 1) * 2 + st) * BC + cl];
+      const float v = sRed[((2 * h) * 2 + st) * BC + cl] + sRed[((2 * h + 1) * 2 + st) * BC + cl];
+      if (coarse) vfs_store_agent(dst + st * a.Cout + c0 + cl, v);
+      else dst[st * a.Cout + c0 + cl] = v;
+    }
+    if (coarse) {
+      constexpr int RW = WAVES_P / 2;                       // fine rows per workgroup
+      const int ncb = a.Cout / BC, rows = (int)(gridDim.x / ncb) * RW;
+      const int L = a.coarse_log2, grp = (tile * RW) >> L, row0 = grp << L, nrow = min(1 << L, rows - row0);
+      vfs_stats_coarsen_tail(a, grp, row0, nrow, nrow / RW, grp * ncb + c0 / BC, c0, BC);
     }
   }
 }

@@ -170,6 +170,7 @@ bool vfs_conv_pw_eligible(const ConvArgs& a, int mode) {
   if (!vfs_option_igemm_pw || (mode != GATHER_FWD && mode != GATHER_DGRAD)) return false;
   if (a.g.KH * a.g.KW != 1 || a.g.stride != 1 || a.g.pad != 0 || a.g.H != a.g.Ho || a.g.W != a.g.Wo || a.ksplit > 1) return false;
   if (a.bn.partial && mode != GATHER_DGRAD) return false;
+  if (a.coarse_log2 > 0) return false;      // (the loaders mirror a fixed number of epilogue barriers)
   if (vfs_option_igemm_pw >= 2) return true;
   const int bc = a.Cout % 128 == 0 ? 128 : 64;
   const long long T = (long long)((a.g.M + 127) / 128) * ((a.Cout + bc - 1) / bc);

@@ -66,6 +66,14 @@ struct ConvArgs {
   // gradient g itself and the masked copy g * (y > 0) is never written (Cout % 64 == 0).
   const unsigned char* add_mask = nullptr;
   long long add_rows = 0;
+  // optional COARSE statistics rows (round 5): the launch's workgroups also sum their rows in groups of 2^coarse_log2 - the last
+  // workgroup of a group to arrive (device-scope ticket) adds the group's rows in row order (deterministic) into
+  // stats_coarse [ceil(rows / 2^L)][2][Cout] - so that the consumer (vfs_bn_act_fin: statistics finished in its prologue) sees
+  // at most 128 rows per group and the separate reduction launch between the convolution and its BatchNorm disappears.
+  // stats_tickets: unsigned [groups x channel blocks], zero before the first launch, left at zero.
+  float* stats_coarse = nullptr;
+  unsigned* stats_tickets = nullptr;
+  int coarse_log2 = 0;
   int mfma_stats = 0;    // implicit-GEMM kernel: forward statistics rows by MFMA from the staged bf16 tile (set by the dispatcher)
   int xcd_swizzle = 0;   // implicit-GEMM kernel: XCD-aware logical tile order (set by the dispatcher)
 };
@@ -97,6 +105,36 @@ __device__ __forceinline__ u32x4 bn_relu_vec(u32x4 v, const f32x4& sc0, const f3
 }
 
 int vfs_conv_igemm_dispatch(const ConvArgs& a, int mode, hipStream_t stream);
+
+// Tail of a forward epilogue with coarse statistics rows: this workgroup has WRITTEN its fine rows (agent-scope stores, channels
+// [c0, c0 + nch)); it takes a ticket of its group, and the last of the group's `arrivals` workgroups adds the group's fine rows
+// [row0, row0 + nrow) in row order into coarse row `grp`.  Called by all 256 threads.
+// vfs_stats_coarsen_finish: the same with the ticket already drawn by thread 0 (issued early: its round trip ran under other work).
+__device__ __forceinline__ void vfs_stats_coarsen_finish(const ConvArgs& a, unsigned ticket_of_t0, int grp, int row0, int nrow, int arrivals, int ticket_idx,
+                                                         int c0, int nch);
+__device__ __forceinline__ void vfs_stats_coarsen_tail(const ConvArgs& a, int grp, int row0, int nrow, int arrivals, int ticket_idx, int c0, int nch) {
+  vfs_release_workgroup();      // this wave's row stores have been performed
+  __syncthreads();
+  unsigned tk = 0;
+  if (threadIdx.x == 0) tk = vfs_ticket_agent(&a.stats_tickets[ticket_idx]);
+  vfs_stats_coarsen_finish(a, tk, grp, row0, nrow, arrivals, ticket_idx, c0, nch);
+}
+__device__ __forceinline__ void vfs_stats_coarsen_finish(const ConvArgs& a, unsigned ticket_of_t0, int grp, int row0, int nrow, int arrivals, int ticket_idx,
+                                                         int c0, int nch) {
+  __shared__ unsigned s_cticket;
+  const int t = threadIdx.x;
+  if (t == 0) s_cticket = ticket_of_t0;
+  __syncthreads();
+  if (s_cticket != (unsigned)arrivals - 1u) return;
+  if (t == 0) vfs_store_agent(&a.stats_tickets[ticket_idx], 0u);
+  for (int e = t; e < 2 * nch; e += 256) {
+    const int st = e / nch, c = c0 + e - st * nch;
+    const float* p = a.stats + (size_t)row0 * 2 * a.Cout + (size_t)st * a.Cout + c;
+    float sum = 0.f;
+    for (int j = 0; j < nrow; ++j) sum += vfs_load_agent(p + (size_t)j * 2 * a.Cout);
+    a.stats_coarse[(size_t)grp * 2 * a.Cout + (size_t)st * a.Cout + c] = sum;
+  }
+}
 // conv_pw.hip: persistent producer / consumer kernel for pure-GEMM (1x1, stride 1) problems
 bool vfs_conv_pw_eligible(const ConvArgs& a, int mode);
 int vfs_conv_pw_dispatch(const ConvArgs& a, int mode, hipStream_t stream);

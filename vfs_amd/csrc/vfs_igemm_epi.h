@@ -216,6 +216,42 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const int m0, 
       }
     }
   }
+  // ---- forward statistics rows.  Plain: written after the output rows (the end of the epilogue).  With COARSE rows (vfs_conv.h)
+  // the row leaves BEFORE the output stores - behind them, the release that must precede the ticket would wait for the whole
+  // store drain (one in-order counter) - and the ticket's atomic is in flight while the output rows are stored; its result is
+  // looked at when they are out.
+  const bool coarse = do_stats && a.coarse_log2 > 0 && a.stats_coarse != nullptr;      // uniform
+  unsigned my_ticket = 0;
+  auto stats_rows_out = [&]() {
+    if (!mstats) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x1 = s1[tm][r], x2 = s2[tm][r];
+          x1 = row16_sum(x1);   // VALU (DPP) reduction over the 16 pixel lanes
+          x2 = row16_sum(x2);
+          if (lr == 0) {
+            int cl = wc * WC + tm * 16 + lq * 4 + r;
+            sRed[wp][cl][0] = x1;
+            sRed[wp][cl][1] = x2;
+          }
+        }
+    }
+    __syncthreads();
+    if (t < BC && c0 + t < a.Cout) {
+      float* dst = a.stats + (size_t)pb * 2 * a.Cout;
+      const float v0 = sRed[0][t][0] + sRed[1][t][0], v1 = sRed[0][t][1] + sRed[1][t][1];
+      if (coarse) { vfs_store_agent(dst + c0 + t, v0); vfs_store_agent(dst + a.Cout + c0 + t, v1); }
+      else { dst[c0 + t] = v0; dst[a.Cout + c0 + t] = v1; }
+    }
+    if (coarse) {
+      vfs_release_workgroup();      // this wave's row stores have been performed (nothing else of this wave is in flight yet)
+      __syncthreads();
+      if (t == 0) my_ticket = vfs_ticket_agent(&a.stats_tickets[(pb >> a.coarse_log2) * ((a.Cout + BC - 1) / BC) + c0 / BC]);
+    }
+  };
+  if (coarse) stats_rows_out();
   {
     const int ch = lane % CPR, c = c0 + wc * WC + ch * 8;
     // statistics group of this wave's 64 rows (blocks never straddle groups); a wave whose rows all lie past M - a single ragged
@@ -260,27 +296,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const int m0, 
       }
     }
   }
-  if (do_stats) {
-    if (!mstats) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x1 = s1[tm][r], x2 = s2[tm][r];
-        x1 = row16_sum(x1);   // VALU (DPP) reduction over the 16 pixel lanes
-        x2 = row16_sum(x2);
-        if (lr == 0) {
-          int cl = wc * WC + tm * 16 + lq * 4 + r;
-          sRed[wp][cl][0] = x1;
-          sRed[wp][cl][1] = x2;
-        }
-      }
-    }
-    __syncthreads();
-    if (t < BC && c0 + t < a.Cout) {
-      float* dst = a.stats + (size_t)pb * 2 * a.Cout;
-      dst[c0 + t] = sRed[0][t][0] + sRed[1][t][0];
-      dst[a.Cout + c0 + t] = sRed[0][t][1] + sRed[1][t][1];
-    }
+  if (do_stats && !coarse) stats_rows_out();
+  if (coarse) {
+    const int L = a.coarse_log2, grp = pb >> L, row0 = grp << L, npb = (Mc + 127) >> 7;
+    const int nrow = min(1 << L, npb - row0);
+    vfs_stats_coarsen_finish(a, my_ticket, grp, row0, nrow, nrow, grp * ((a.Cout + BC - 1) / BC) + c0 / BC, c0, min(BC, a.Cout - c0));
   }
 }

@@ -21,6 +21,8 @@ from .packing import (igemm_ksplit, bn_fold_eligible, build_pack_table, build_re
 BF16 = torch.bfloat16
 
 FIN_FUSE = os.environ.get('VFS_FIN_FUSE', '1') == '1'      # BatchNorm statistics finished in the apply kernels' prologue
+COARSE_ROWS = int(os.environ.get('VFS_COARSE_ROWS', '0'))      # conv launches sum their statistics rows in groups (vfs_conv_fwd_coarse): 0 off, 1 implicit-GEMM kernels, 2 halo kernels too
+TILES_PER_TICKET = [1 << 16]      # capacity (uint32 words) of the shared ticket buffer
 FIN_MAX_ROWS = int(os.environ.get('VFS_FIN_MAX_ROWS', '128'))   # ... for at most this many statistics rows per group
 # timing experiments only: kernel families (Engine.timed labels) whose launches are dropped - results are garbage, the step
 # time shows what the family costs on the critical path (no kernel here has data-dependent control flow)
@@ -275,6 +277,17 @@ class Engine:
         else:
             want_rows = want_stats
         partial = self.ws('ws.stats', G * nblk_g * 2 * u.cout, torch.float32, dev) if want_rows else None
+        # large maps (more than FIN_MAX_ROWS statistics rows per group): the conv launch sums its rows in groups of 2^L itself, so
+        # that the bn_act behind it can finish the statistics in its prologue and the reduction launch in between disappears
+        coarse_l2, coarse_rows = 0, None
+        if (COARSE_ROWS and want_rows and fused and defer_fin and FIN_FUSE and train and not self.collectives_on and in_bn is None
+                and u.kind != 'stem' and u.dil == 1 and nblk_g > FIN_MAX_ROWS and (COARSE_ROWS >= 2 or self.conv_kind(u, N, H, W) == 'conv_igemm')):
+            L = 1
+            while (nblk_g >> L) > FIN_MAX_ROWS:
+                L += 1
+            if nblk_g % (1 << L) == 0 and L <= 8 and G * (nblk_g >> L) * ((u.cout + 63) // 64) <= TILES_PER_TICKET[0]:
+                coarse_l2 = L
+                coarse_rows = self.ws('ws.stats_coarse', G * (nblk_g >> L) * 2 * u.cout, torch.float32, dev)
         bias = u.bias.data if u.bias is not None else None
         groups = [(0, N, partial)] if fused else [
             (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_rows else None) for g in range(G)]
@@ -300,6 +313,9 @@ class Engine:
                 if ks > 1:      # few pixels, long reduction (the head's Linear layers): split-K fills the chip
                     self.timed('conv_igemm', work, dev, lib.conv_fwd_splitk, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
                                self.ksplit_ws(ksws, dev), ks, nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
+                elif coarse_l2:     # ... and the statistics rows summed in groups by the launch itself (vfs_conv_fwd_coarse)
+                    self.timed(self.conv_kind(u, nn_, H, W), work, dev, lib.conv_fwd_coarse, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
+                               coarse_rows, self.stats_tickets(dev), coarse_l2, nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
                 else:
                     self.timed(self.conv_kind(u, nn_, H, W), work, dev, lib.conv_fwd, x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], bias, part,
                                nn_, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, s)
@@ -309,7 +325,9 @@ class Engine:
             if train:
                 u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
                 u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
-                if (defer_fin and FIN_FUSE and fused and not raw_stats and not self.collectives_on and u.kind != 'stem'
+                if coarse_l2:
+                    self._pending_fin = (u, coarse_rows, nblk_g >> coarse_l2, float(mpg))
+                elif (defer_fin and FIN_FUSE and fused and not raw_stats and not self.collectives_on and u.kind != 'stem'
                         and nblk_g <= FIN_MAX_ROWS):
                     # the caller's next launch is bn_act on this output: it finishes the statistics in its prologue
                     self._pending_fin = (u, partial, nblk_g, float(mpg))
@@ -446,6 +464,15 @@ class Engine:
         self.timed('bn_bwd_apply', (0.0, abytes), dev, lib.bn_bwd_apply, g, ymask, raw, u.bnp, u.bsums, dx, gm, M, C, mpg,
                    float(mpg * self.world), rl, s)
         return dx, gm
+
+    def stats_tickets(self, dev):
+        """uint32 tickets of the coarse statistics rows: zero once, every launch leaves them at zero"""
+        t = self.bufs.get('ws.stats_tickets')
+        if t is None or t.device != dev:
+            t = torch.zeros(TILES_PER_TICKET[0], dtype=torch.int32, device=dev)
+            self.bufs['ws.stats_tickets'] = t
+            self.generation += 1
+        return t
 
     def zero_sums(self, C, dev):
         """double[1][2][C] of zeros (never written): BatchNorm backward without the batch-statistic terms"""
