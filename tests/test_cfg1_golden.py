@@ -245,7 +245,11 @@ def test_hip_train_step_end_to_end_vs_fp32_oracle_32_frames_per_view(gpu_backend
     table, failed = {}, []
     wl = max(d['loss'] for _, d in draws)
     table['loss error HIP / largest draw'] = (mine['loss'], wl)
-    if not mine['loss'] <= 3.0 * wl + 2e-4:      # ONE scalar per draw (draws: 6e-5 .. 5e-4, MI355X: 9.4e-4 on a loss of 1.99)
+    # ONE scalar per draw: four draws under-sample its scatter.  tools/parity_loss_scatter.py (round 5, advisor finding r04: the HIP
+    # loss sat ~2x outside the four draws): TWELVE emulation draws of the ResNet-18 step (three statistics variants x one-ulp input
+    # jitters) land 5.7e-5 .. 1.1e-3 from the fp32 loss, median 4.4e-4 (profiles/r05_parity_loss_scatter_r18.json) - the MI355X's
+    # 9.4e-4 (ResNet-18) / 4.0e-4 (ResNet-50) is inside that range; the bar is 3 x the largest of the four draws run here + 2e-4
+    if not mine['loss'] <= 3.0 * wl + 2e-4:
         failed.append(('loss', mine['loss'], wl))
     for v in range(2):
         k = f'feat{v}'

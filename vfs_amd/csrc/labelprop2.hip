@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
     const float thr_e = (a.dbg & 16) ? -INFINITY : lp2_dec(sThr[myq]) - a.margin;      // (dbg 16, tests: list EVERY in-mask candidate with its s~)
     unsigned long long hot = 0;      // lanes with a score above the threshold: sixteen compares, OR-ed on the scalar side
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) hot |= __ballot(tot[rg] >= thr_e);
+    for (int rg = 0; rg < 16; ++rg) hot |= __ballot(q_in && tot[rg] >= thr_e);      // (queries past the map have no threshold: they must not keep the slow path alive in every edge tile)
     if (hot != 0 && !(a.dbg & 4)) {      // (dbg 4: what-if timing without the lists)
       const int fid = cf * HW;
       // every passing candidate is listed; the query's running top 10 is fed with this lane's BEST TWO of them (four lanes hold a
@@ -769,7 +769,11 @@ int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
   if (!(a.temperature > 0.f)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: temperature > 0");
   // |s~ - s| <= EPS for unit rows: 3 * 2^-16 (the dropped lo.lo product and the two representation remainders, Cauchy-Schwarz) +
   // 4 * C * 2^-24 (C roundings of the exact chain, <= 3 C of the matrix unit's partial sums); margin = 2 EPS
-  a.margin = 2.0f * (3.0f / 65536.0f + 4.0f * (float)a.C / 16777216.0f);
+  // + 2^-21: the total order is applied to fl(s / temperature), and a correctly rounded division keeps a STRICT order only across a
+  // gap of more than one ulp of the quotient (2^-23 relative): with the extra 2^-21 (|s| <= 1) a pruned candidate's exact score
+  // lies more than four ulps below each of its ten betters, so it cannot tie with one of them after the division either
+  // (round 4 advisor finding: the proof was stated on s, the order on s / temperature)
+  a.margin = 2.0f * (3.0f / 65536.0f + 4.0f * (float)a.C / 16777216.0f) + 1.0f / 2097152.0f;
   a.nsplit = vfs_lp2_splits(a.H, a.W, a.nkeys);
   // the list workspace (LP2_MAX_SPLIT x LP2_MAX_CAP entries per query) is shared out among the splits in use: the first steps of a
   // clip have few key frames (few splits) and cold thresholds (long lists)
