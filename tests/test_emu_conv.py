@@ -504,6 +504,7 @@ def test_ring_upfront_reads_bit_identical(backend):
     outs = []
     for flag in (0, 1):
         lib.set_option(b'igemm_ring_upfront', flag)
+        lib.set_option(b'igemm_ring_mfma32', 0)      # (the default ring runs 32x32x16 MFMAs: another K grouping on the hardware)
         try:
             y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=backend.dev)
             st = torch.full((1, 2, Cout), float('nan'), device=backend.dev)
@@ -511,6 +512,7 @@ def test_ring_upfront_reads_bit_identical(backend):
             outs.append((y.cpu(), st.cpu()))
         finally:
             lib.set_option(b'igemm_ring_upfront', 0)
+            lib.set_option(b'igemm_ring_mfma32', 1)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert relerr(nchw(outs[1][0]), F.conv2d(nchw(x.cpu()), w)) < 6e-3
 
@@ -598,3 +600,45 @@ def test_conv_forward_coarse_statistics_rows(backend, N, H, W, Cin, Cout, k, L):
         for r in range(nblk):      # row order, fp32
             want[r >> L] = want[r >> L] + fine[r]
         assert torch.equal(c1.cpu(), want), float((c1.cpu() - want).abs().max())
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 8, 8, 512, 256), (3, 7, 7, 1024, 64), (1, 5, 5, 320, 128), (4, 8, 8, 256, 512)])
+def test_ring_on_32x32_mfma(backend, N, H, W, Cin, Cout):
+    """the pure-GEMM DMA ring on v_mfma_f32_32x32x16_bf16 (PIPE 5: lean DMA issue, accumulators handed to the shared epilogue
+    through an LDS transposition) against the 16x16x32 ring: forward (+ statistics rows) and dgrad (+ residual) equal to fp32
+    rounding of another K grouping (bit-identical on the emulator, whose MFMAs are k-ordered fmaf chains), both against torch"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wf, wd = pack(backend, w)
+    dy = rb(torch.randn(N, Cout, H, W, generator=g))
+    add = rb(torch.randn(N, Cin, H, W, generator=g))
+    M = N * H * W
+    outs = []
+    for flag in (1, 0):
+        lib.set_option(b'igemm_ring_mfma32', flag)
+        try:
+            y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+            st = torch.full(((M + 127) // 128, 2, Cout), float('nan'), device=dev)
+            lib.conv_fwd(d(nhwc(x)), wf, y, None, st, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, None)
+            res = [y.float().cpu(), st.cpu()]
+            if Cout % 64 == 0 and Cout >= 256:
+                dx = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=dev)
+                lib.conv_dgrad(d(nhwc(dy)), wd, dx, d(nhwc(add)), N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, None)
+                res.append(dx.float().cpu())
+            outs.append(res)
+        finally:
+            lib.set_option(b'igemm_ring_mfma32', 1)
+    for a_, b_ in zip(outs[0], outs[1]):
+        if backend.name == 'emu':
+            assert torch.equal(a_, b_)
+        else:
+            assert torch.isfinite(a_).all() and relerr(a_, b_) < 8e-3
+    assert relerr(nchw(outs[0][0].to(torch.bfloat16)), F.conv2d(x, w)) < 6e-3
+    yf = outs[0][0].reshape(M, Cout).double()
+    assert torch.allclose(outs[0][1][:, 0].double().sum(0), yf.sum(0), rtol=1e-4, atol=5e-3)
+    if len(outs[0]) > 2:
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w).backward(dy)
+        assert relerr(nchw(outs[0][2].to(torch.bfloat16)), xr.grad + add) < 6e-3

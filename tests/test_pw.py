@@ -25,6 +25,7 @@ def both(lib, fn):
     sums whose grouping follows the tile"""
     outs = []
     lib.set_option(b'igemm_narrow_below', 0)
+    lib.set_option(b'igemm_ring_mfma32', 0)      # (the plain kernel's ring on 16x16x32 MFMAs, as the persistent kernel's K-steps)
     for flag in (2, 0):
         lib.set_option(b'igemm_pw', flag)
         try:
@@ -32,6 +33,7 @@ def both(lib, fn):
         finally:
             lib.set_option(b'igemm_pw', 0)
     lib.set_option(b'igemm_narrow_below', 513)
+    lib.set_option(b'igemm_ring_mfma32', 1)
     return outs
 
 

@@ -248,8 +248,16 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       const int c = c0 + row < a.Cout ? c0 + row : c0;
       wvo[q] = (unsigned)(((size_t)c * g.Ktot) * 2 + chunk * 16);
     }
+    const vfs_lds_t lds_x = vfs_lds_addr(&sX[0][0]), lds_w = vfs_lds_addr(&sW[0][0]);
     auto issue = [&](int kt, int st) {
-      if (pure) {
+      if (pure && PIPE == 5) {      // lean issue (4 instructions per piece instead of 10: LDS address as a scalar, m0 not saved)
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+          vfs_dma16_async_at(xrw, lds_x + (vfs_lds_t)((st * (BP * 64) + (wave_u * XQ + q) * 512) * 2), xvo[q], (unsigned)kt * 128u);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+          vfs_dma16_async_at(wrw, lds_w + (vfs_lds_t)((st * (BC * 64) + (wave_u * WQ + q) * 512) * 2), wvo[q], (unsigned)kt * 128u);
+      } else if (pure) {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) vfs_dma16_async(xrw, sX[st] + (wave_u * XQ + q) * 512, xvo[q], (unsigned)kt * 128u);
 #pragma unroll
@@ -268,6 +276,16 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
 #pragma unroll
     for (int d = 0; d < RING - 1; ++d)
       if (kbeg + d < kend) issue(kbeg + d, d);
+    constexpr int QM = WC / 32, QN = 2;       // PIPE 5: 32 x 32 tiles of the wave (WC channels x 64 pixels)
+    vfs_f32x16 acc32[PIPE == 5 ? QM : 1][PIPE == 5 ? QN : 1];
+    if (PIPE == 5) {
+#pragma unroll
+      for (int i = 0; i < QM; ++i)
+#pragma unroll
+        for (int j = 0; j < QN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    }
     int st = 0;
     for (int kt = kbeg; kt < kend; ++kt) {
       // this wave's pieces of step kt have landed: at most the pieces of the later steps already issued stay in flight
@@ -277,12 +295,37 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       const int nst = st == 0 ? RING - 1 : st - 1;   // the stage step kt - 1 used
       if (kt + RING - 1 < kend) issue(kt + RING - 1, nst);
       __builtin_amdgcn_sched_barrier(0);
-      if (PIPE == 4) mma_kstep_upfront<TM, TN>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);     // opt-in schedule, own instantiation
+      if (PIPE == 5) mma_kstep32<PIPE == 5 ? QM : 1, PIPE == 5 ? QN : 1>(sW[st], sX[st], wc * WC, wp * 64, lane, acc32);
+      else if (PIPE == 4) mma_kstep_upfront<TM, TN>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);     // opt-in schedule, own instantiation
       else mma_kstep<TM, TN, false>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
       __builtin_amdgcn_sched_barrier(0);
       st = st == RING - 1 ? 0 : st + 1;
     }
     __syncthreads();                         // the epilogue re-uses the arena
+    if (PIPE == 5) {
+      // 32 x 32 accumulators -> the 16 x 16 layout the epilogue is written for, through a wave-private fp32 slab in the idle ring:
+      // tile (i, j), register 4 q + r of lane l = channel 32 i + 8 q + 4 (l / 32) + r, pixel 32 j + l % 32 of the wave's tile
+      constexpr int TR = WC + 4;
+      static_assert(PIPE != 5 || OPER * 2 >= 4 * 64 * TR * 4, "transposition slab does not fit the ring");
+      float* slab32 = reinterpret_cast<float*>(smem) + wave * (64 * TR);
+      const int l32 = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int i = 0; i < QM; ++i)
+#pragma unroll
+        for (int j = 0; j < QN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(&slab32[(32 * j + l32) * TR + 32 * i + 8 * q + 4 * h]) =
+                (f32x4){acc32[PIPE == 5 ? i : 0][PIPE == 5 ? j : 0][4 * q], acc32[PIPE == 5 ? i : 0][PIPE == 5 ? j : 0][4 * q + 1],
+                        acc32[PIPE == 5 ? i : 0][PIPE == 5 ? j : 0][4 * q + 2], acc32[PIPE == 5 ? i : 0][PIPE == 5 ? j : 0][4 * q + 3]};
+      __builtin_amdgcn_wave_barrier();
+      const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = *reinterpret_cast<const f32x4*>(&slab32[(tn * 16 + lr) * TR + tm * 16 + lq * 4]);
+      __syncthreads();                       // the epilogue's output stage overlaps the other waves' slabs
+    }
   } else if (kend > kbeg) {
     load_tiles(kbeg);
     store_tiles(0);
@@ -350,6 +393,7 @@ int vfs_option_igemm_ring_upfront = 0;  // ring variant: all fragment reads of a
 int vfs_option_igemm_ring_fbn = 1;      // the DMA ring also for dgrads with fused BatchNorm-backward statistics (A/B knob)
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
 int vfs_option_igemm_ring_gather = 0;      // DMA ring for GATHERED problems (3x3 / strided forward, stride-1 and stride-2 dgrad classes) with at most this many tiles (0: off)
+int vfs_option_igemm_ring_mfma32 = 1;   // the pure-GEMM DMA ring on 32x32x16 MFMAs with the lean DMA issue (PIPE 5; 0: PIPE 3, A/B knob)
 int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
 
 template <int BC, int MODE, int PIPE = 0, bool FBN = false>
@@ -403,6 +447,11 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   if (ring && vfs_option_igemm_ring_upfront && !a.bn.partial) {
     if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 4>(a, stream) : launch_igemm<64, GATHER_FWD, 4>(a, stream);
     return wide ? launch_igemm<128, GATHER_DGRAD, 4>(a, stream) : launch_igemm<64, GATHER_DGRAD, 4>(a, stream);
+  }
+  if (ring && vfs_option_igemm_ring_mfma32) {
+    if (a.bn.partial) return wide ? launch_igemm<128, GATHER_DGRAD, 5, true>(a, stream) : launch_igemm<64, GATHER_DGRAD, 5, true>(a, stream);
+    if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 5>(a, stream) : launch_igemm<64, GATHER_FWD, 5>(a, stream);
+    return wide ? launch_igemm<128, GATHER_DGRAD, 5>(a, stream) : launch_igemm<64, GATHER_DGRAD, 5>(a, stream);
   }
   if (ring && a.bn.partial)   // the deep-stage dgrads that also emit BatchNorm-backward statistics (round 2: they had been left on the register pipeline)
     return wide ? launch_igemm<128, GATHER_DGRAD, 3, true>(a, stream) : launch_igemm<64, GATHER_DGRAD, 3, true>(a, stream);

@@ -344,6 +344,29 @@ __device__ __forceinline__ void mma_kstep_upfront(const bf16_t* __restrict__ sA,
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][tm], bfr[kk][tn], acc[tm][tn], 0, 0, 0);
 }
 
+// The same K-step on v_mfma_f32_32x32x16_bf16 (round 5: tools/probe_mfma_rate.hip - in this pattern the 16x16x32 shape sustains
+// 1.47 PFLOP/s chip-wide, the 32x32x16 shape 2.43): QM x QN tiles of 32 x 32, four 16-deep sub-steps.  A fragment = 32 rows
+// (lane % 32) x 8 k (chunk 2 ks + lane / 32 of the swizzled 128-byte row): the 16 lanes of a ds_read_b128 group hit 16 distinct
+// 16-byte slots of the 64 banks (rows r, r + 1 share a chunk column 128 bytes apart, other row pairs another column).
+typedef __attribute__((ext_vector_type(16))) float vfs_f32x16;
+template <int QM, int QN>
+__device__ __forceinline__ void mma_kstep32(const bf16_t* __restrict__ sA, const bf16_t* __restrict__ sB, int rowA0, int rowB0, int lane,
+                                            vfs_f32x16 (&acc)[QM][QN]) {
+  const int l32 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bf16x8 af[QM], bfr[QN];
+#pragma unroll
+    for (int i = 0; i < QM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off(rowA0 + i * 32 + l32, ks * 2 + h));
+#pragma unroll
+    for (int j = 0; j < QN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off(rowB0 + j * 32 + l32, ks * 2 + h));
+#pragma unroll
+    for (int i = 0; i < QM; ++i)
+#pragma unroll
+      for (int j = 0; j < QN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  }
+}
+
 // one 64-deep K-step of MFMAs for a wave: acc[tm][tn] += A(rowsA + tm*16) x B(rowsB + tn*16)
 template <int TM, int TN, bool TSWZ>
 __device__ __forceinline__ void mma_kstep(const bf16_t* __restrict__ sA, const bf16_t* __restrict__ sB,
