@@ -101,7 +101,7 @@ def stage_cuda_collectives_through_host():
 
 
 # kernel name (prefix after "void ") -> bench.py's family label, for the committed rocprofv3 --stats CSV of the TIMED schedule
-KERNEL_FAMILY = (('conv_igemm_kernel', 'conv_igemm'), ('conv3x3_halo_kernel', 'conv3x3_halo'), ('stem_fwd_direct_kernel', 'stem_fwd'),
+KERNEL_FAMILY = (('conv_igemm_kernel', 'conv_igemm'), ('conv_skinny_kernel', 'conv_igemm'), ('conv_pw_kernel', 'conv_igemm'), ('conv3x3_halo_kernel', 'conv3x3_halo'), ('stem_fwd_direct_kernel', 'stem_fwd'),
                  ('conv_wgrad_kernel', 'conv_wgrad'), ('conv3x3_wgrad_halo_kernel', 'conv3x3_wgrad_halo'), ('stem_wgrad_fused_kernel', 'stem_wgrad'),
                  ('wgrad_reduce_', 'wgrad_reduce'), ('bn_act_kernel', 'bn_act'), ('bn_bwd_apply_kernel', 'bn_bwd_apply'),
                  ('bn_bwd_reduce_kernel', 'bn_bwd_reduce'), ('stem_pool_bn_bwd_reduce', 'bn_bwd_reduce'), ('bn_reduce_', 'bn_stats'),
@@ -317,7 +317,7 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
 
         # HBM bytes per launch from the committed PMC passes of this workload (tools/gpu_pmc.sh <model> davis + make_traffic_json.py)
         tclasses, tsource = {}, None
-        for tag in ('r04', 'r03'):
+        for tag in ('r05', 'r04', 'r03'):
             tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_davis_{args.model}.json')
             if args.precision == 'fp32' and os.path.exists(tpath):
                 tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
@@ -606,7 +606,7 @@ def main():
         # HBM bytes per launch of every family from the committed PMC passes (tools/gpu_pmc.sh + make_traffic_json.py:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as the guide prescribes for gfx950)
         tclasses, tsource = {}, None
-        for tag in ('r04', 'r03', 'r02', 'r01'):
+        for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
             tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_{args.model}.json')
             if os.path.exists(tpath):
                 tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)

@@ -2,7 +2,7 @@
 # HBM traffic of the bench kernels from the L2 memory-side counters (separate passes per guide)
 # usage: tools/gpu_pmc.sh <r18|r50> [davis]   (davis: the fp32 DAVIS workload instead of the train step -> gpurun_out/pmc_davis_<model>.json)
 MODEL=${1:-r18}; WORK=${2:-train}
-if [ "$WORK" = davis ]; then BARGS="--workload davis --precision fp32 --steps 30 --warmup 0 --no-cpu-baseline --no-roofline"; OUT=davis_$MODEL
+if [ "$WORK" = davis ]; then BARGS="--workload davis --precision fp32 --steps 49 --warmup 0 --no-cpu-baseline --no-roofline"; OUT=davis_$MODEL
 else BARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-davis"; OUT=$MODEL; fi
 mkdir -p gpurun_out && cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

@@ -7,7 +7,7 @@ MODEL=${1:-r50}; TAG=${2:-prof}; WORK=${3:-train}
 mkdir -p gpurun_out && cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 if [ "$WORK" = davis ]; then
-  BARGS="--workload davis --precision fp32 --steps 30 --warmup 2 --no-cpu-baseline --no-roofline"; NAME=davis_$MODEL; PASSES=62      # propagated frames: 2 warm-up + 30 untimed + 30 timed
+  BARGS="--workload davis --precision fp32 --steps 49 --warmup 2 --no-cpu-baseline --no-roofline"; NAME=davis_$MODEL; PASSES=140      # propagated frames: 2 warm-up + 49 untimed + 49 timed + 2 x 20 (the steady-state leg)
 else
   BARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-davis"; NAME=bench_$MODEL; PASSES=9      # 2 recording passes + 2 + 5
 fi

@@ -9,7 +9,7 @@ import os
 import sys
 
 CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels launched under them
-    'conv_igemm': ('conv_igemm_kernel',),
+    'conv_igemm': ('conv_igemm_kernel', 'conv_skinny_kernel', 'conv_pw_kernel'),
     'conv3x3_halo': ('conv3x3_halo_kernel',),
     'stem_fwd': ('stem_fwd_direct_kernel',),
     'conv_wgrad': ('conv_wgrad_kernel',),          # (the table-driven reduction of the partials is its own class)
@@ -65,7 +65,7 @@ def main():
         kernels[name] = {'calls': v['calls'], 'fetch_bytes_per_launch': 2.0 * v['sum'] * 1024 / v['calls'],
                          'write_bytes_per_launch': w['sum'] * 1024 / max(w['calls'], 1)}
     classes = aggregate(kernels)
-    cmd = (f'bench.py --workload davis --model {model[6:]} --precision fp32 --steps 30 --warmup 0` (tools/gpu_pmc.sh {model[6:]} davis: '
+    cmd = (f'bench.py --workload davis --model {model[6:]} --precision fp32 --steps 49 --warmup 0` (tools/gpu_pmc.sh {model[6:]} davis: '
            'every launch of the warm-up, the untimed and the timed pass over the 31-frame clip)' if model.startswith('davis_') else
            f'VFS_GRAPHS=0 VFS_SIDE_STREAM=0 bench.py --model {model} --steps 3 --warmup 1` (tools/gpu_pmc.sh)')
     out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `' + cmd + '; '
