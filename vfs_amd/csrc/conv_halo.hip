@@ -445,7 +445,20 @@ __global__ __launch_bounds__(256, NW > 2 ? 1 : 2) void conv3x3_halo_kernel(ConvA
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if HALO_WHATIF & 64
+  typedef __attribute__((ext_vector_type(16))) float wf32x16;
+  wf32x16 wacc[2][2] = {};
+#endif
   auto mma = [&](const bf16x8* af, const bf16x8* bf) {
+#if HALO_WHATIF & 64      // timing only (WRONG results): the same FLOP on eight 32x32x16 MFMAs per k-step instead of sixteen 16x16x32
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2 * i + h], bf[2 * j + h], wacc[i][j], 0, 0, 0);
+    return;
+#endif
 #if HALO_WHATIF & 4
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(af[tm]), "v"(bf[tm]));
@@ -631,6 +644,14 @@ __global__ __launch_bounds__(256, NW > 2 ? 1 : 2) void conv3x3_halo_kernel(ConvA
 
   // the loop's final barrier has passed: no wave reads the patch / weight tiles any more
   if (HALO_WHATIF & 16) return;
+#if HALO_WHATIF & 64
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[2 * i + (e >> 3)][2 * j + ((e >> 2) & 1)][e & 3] += wacc[i][j][e];
+#endif
   halo_epilogue_dispatch<BC, SMALLW, RAGGED>(a, acc, &sRed[0][0][0], smem, tile, tn0, y0, x0, c0, wc, wp, lr, lq, t);
 }
 

@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(ConvArgs a) {
 bool vfs_conv_skinny_eligible(const ConvArgs& a, int mode) {
   if (!vfs_option_igemm_skinny || (mode != GATHER_FWD && mode != GATHER_DGRAD)) return false;
   if (a.g.KH * a.g.KW != 1 || a.g.stride != 1 || a.g.pad != 0 || a.g.H != a.g.Ho || a.g.W != a.g.Wo || a.ksplit > 1) return false;
-  return a.g.M <= 128 && a.g.Ktot % 128 == 0 && a.Cout % 16 == 0 && !a.stats && !a.bn.partial && !a.add_mask && a.g.C == a.g.Ktot;
+  // Linear layers only (1 x 1 "maps"): a backbone convolution on a tiny map keeps ONE kernel whatever its epilogue operands are -
+  // the step's A/B switches (bit-packed mask on / off, ...) must not move a layer between kernels with different summation orders
+  return a.g.H == 1 && a.g.W == 1 && a.g.M <= 128 && a.g.Ktot % 128 == 0 && a.Cout % 16 == 0 && !a.stats && !a.bn.partial && !a.add_mask &&
+         a.g.C == a.g.Ktot;
 }
 
 int vfs_conv_skinny_dispatch(const ConvArgs& a, hipStream_t stream) {
