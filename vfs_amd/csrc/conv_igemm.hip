@@ -28,6 +28,12 @@
 
 #define OOB_OFFSET 0xFFFFFFF0u   // >= any num_records: the load returns zeros
 #define XCD_SWIZZLE 1
+#ifndef IGEMM_WHATIF
+#define IGEMM_WHATIF 0     // what-if builds of the PIPE 5 ring (WRONG results, timing only): 1 no MFMAs, 2 no DMA waits, 4 no DMA issue in the loop, 8 no epilogue
+#endif
+#ifndef IGEMM_RING5
+#define IGEMM_RING5 3      // stages of the PIPE 5 ring (what-if builds: tools/make_variant_lib.sh ... -DIGEMM_RING5=5)
+#endif
 
 // ONEK ("single buffer"): ONE operand buffer instead of two - the arena shrinks from 64 to 37 KB and, with the
 // smaller register budget, three to four workgroups share a CU instead of two.  The 1x1 convolutions are HBM-bound
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   constexpr bool CAN_BN = FBN;
   // one arena [weight tiles | pixel tiles]; after the K loop the epilogue re-uses it as output stage
   constexpr int SROW = WC + 8;                    // staged pixel row: WC channels + 16 bytes of padding
-  constexpr int NBUF = PIPE >= 3 ? 3 : (ONEK ? 1 : 2);     // PIPE 4 = PIPE 3 with mma_kstep_upfront
+  constexpr int NBUF = PIPE == 5 ? (BC == 128 && IGEMM_RING5 > 4 ? 4 : IGEMM_RING5) : PIPE >= 3 ? 3 : (ONEK ? 1 : 2);     // PIPE 4 = PIPE 3 with mma_kstep_upfront
   constexpr int OPER = NBUF * (BC * 64 + BP * 64);
   constexpr int STAGE = 4 * 64 * SROW + (CAN_BN ? 4 * (64 / (WC / 8)) * 2 * WC * 2 : 0);   // + statistics rows (floats)
   constexpr int SMEM = OPER > STAGE ? OPER : STAGE;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
         for (int q = 0; q < WQ; ++q) vfs_dma16_async(wrw, sW[st] + (wave_u * WQ + q) * 512, wvo[q], (unsigned)wcol);
       }
     };
-    constexpr int RING = 3;
+    constexpr int RING = NBUF;
 #pragma unroll
     for (int d = 0; d < RING - 1; ++d)
       if (kbeg + d < kend) issue(kbeg + d, d);
@@ -290,18 +296,25 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     for (int kt = kbeg; kt < kend; ++kt) {
       // this wave's pieces of step kt have landed: at most the pieces of the later steps already issued stay in flight
       const int ahead = min(RING - 2, kend - 1 - kt);
-      if (ahead >= 2) vfs_dma_wait<2 * NPW>(); else if (ahead == 1) vfs_dma_wait<NPW>(); else vfs_dma_wait<0>();
+      if (PIPE == 5 && (IGEMM_WHATIF & 2)) {} else if (ahead >= 4) vfs_dma_wait<4 * NPW>(); else if (ahead == 3) vfs_dma_wait<3 * NPW>(); else if (ahead == 2) vfs_dma_wait<2 * NPW>(); else if (ahead == 1) vfs_dma_wait<NPW>(); else vfs_dma_wait<0>();
       __syncthreads();                       // ... everybody's have, and everybody is done with step kt - 1
       const int nst = st == 0 ? RING - 1 : st - 1;   // the stage step kt - 1 used
-      if (kt + RING - 1 < kend) issue(kt + RING - 1, nst);
+      if (!(PIPE == 5 && (IGEMM_WHATIF & 4)) && kt + RING - 1 < kend) issue(kt + RING - 1, nst);
       __builtin_amdgcn_sched_barrier(0);
-      if (PIPE == 5) mma_kstep32<PIPE == 5 ? QM : 1, PIPE == 5 ? QN : 1>(sW[st], sX[st], wc * WC, wp * 64, lane, acc32);
+      if (PIPE == 5 && (IGEMM_WHATIF & 1)) {} else if (PIPE == 5) mma_kstep32<PIPE == 5 ? QM : 1, PIPE == 5 ? QN : 1>(sW[st], sX[st], wc * WC, wp * 64, lane, acc32);
       else if (PIPE == 4) mma_kstep_upfront<TM, TN>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);     // opt-in schedule, own instantiation
       else mma_kstep<TM, TN, false>(sW[st], sX[st], wc * WC, wp * 64, lane, acc);
       __builtin_amdgcn_sched_barrier(0);
       st = st == RING - 1 ? 0 : st + 1;
     }
     __syncthreads();                         // the epilogue re-uses the arena
+    if (PIPE == 5 && (IGEMM_WHATIF & 8)) {
+      float sum = 0.f;
+      for (int i = 0; i < QM; ++i) for (int j = 0; j < QN; ++j) for (int e = 0; e < 16; ++e) sum += acc32[PIPE == 5 ? i : 0][PIPE == 5 ? j : 0][e];
+      if (sum == 12345.678f) a.out[0] = (bf16_t)0;
+      vfs_dma_wait<0>();
+      return;
+    }
     if (PIPE == 5) {
       // 32 x 32 accumulators -> the 16 x 16 layout the epilogue is written for, through a wave-private fp32 slab in the idle ring:
       // tile (i, j), register 4 q + r of lane l = channel 32 i + 8 q + 4 (l / 32) + r, pixel 32 j + l % 32 of the wave's tile
