@@ -31,6 +31,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef LP2_PF
+#define LP2_PF 0      // 1: key fragments requested half a stage ahead into a second register set (round 5: measured level, MEASUREMENTS.md)
+#endif
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ---------------------------------------------------------------------------------------------
@@ -395,10 +399,88 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
   int slot = 0;                      // ring slot of the stage about to be consumed
   __syncthreads();                   // sThr / sCnt initialised
 
+#if LP2_PF
+  // Fragment pipeline (round 5, opt-in build -DLP2_PF=1): the compiler reads every key fragment just in time - two register quads, an `s_waitcnt lgkmcnt(0)`
+  // in front of every second MFMA.  Here the fragments of a
+  // HALF stage (16 channels: hi and lo rows of both key halves, four quads) are requested one half stage ahead into the other of two
+  // register sets, across stage and key-block boundaries (the first half of the next block waits through the epilogue).
+  const int R0 = 32 * kh + li, R1 = 32 * (kh ^ 1) + li, sw0 = (R0 >> 1) & 7, sw1 = (R1 >> 1) & 7;
+  bf16x8 F[2][4];
+  auto read_half = [&](bf16x8 (&f)[4], const unsigned char* st, int p) {
+    f[0] = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((4 * p + kgrp) ^ sw0) << 4));
+    f[1] = *reinterpret_cast<const bf16x8*>(st + R0 * 128 + (((4 * p + 2 + kgrp) ^ sw0) << 4));
+    f[2] = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((4 * p + kgrp) ^ sw1) << 4));
+    f[3] = *reinterpret_cast<const bf16x8*>(st + R1 * 128 + (((4 * p + 2 + kgrp) ^ sw1) << 4));
+  };
+  static_assert(RING == 3, "the fragment pipeline is written for the three-stage ring");
+  vfs_dma_wait<8>();                 // stage 0 of the first block has landed (stage 1 in flight)
+  read_half(F[0], ring, 0);
+#endif
+
   for (int blk = 0; blk < total_blocks; ++blk) {
     f32x16 a00, a01, a10, a11;      // [key half][query half] partial scores over this wave's channels
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a00[r] = 0.f; a01[r] = 0.f; a10[r] = 0.f; a11[r] = 0.f; }
+#if LP2_PF
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      // ---- first half: request the second half's fragments, refill the slot stage s - 1 used, multiply
+      const int pslot = slot == 0 ? RING - 1 : slot - 1, nslot = slot == RING - 1 ? 0 : slot + 1;
+      read_half(F[1], ring + slot * SBYTES, 1);
+      bool dma = true;
+      unsigned soff = (unsigned)(s + RING - 1) * 128u;
+      if (s + RING - 1 >= NST) {      // (compile time) a stage of the NEXT block
+        if (s + RING - 1 == NST && has_next && !(a.dbg & 2)) {
+          off = nw.tab ? lp2_offsets_tab(nw, sKeyTab, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off)
+                       : lp2_offsets(nw, lp2_block_of(ni, nw.nkb, stag), lane, W, rowb, lane_off);
+          rs = lp2_frame_rsrc(a.hl, nw.slot, HW, rowb);
+        }
+        dma = has_next;
+        soff = (unsigned)(s + RING - 1 - NST) * 128u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma) lp2_issue(rs, off, ring + pslot * SBYTES, soff);
+      {
+        const int g = 2 * s;
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][0], qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][0], qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][2], qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][2], qh1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][0], ql0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][0], ql1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][2], ql0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][2], ql1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][1], qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][1], qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][3], qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0][3], qh1[g], a11, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- second half: the NEXT stage has landed (the one requested above may stay in flight); request its first half, multiply
+      if (s + 1 < NST || has_next) {
+        if (s + 2 <= NST - 1 || has_next) vfs_dma_wait<8>(); else vfs_dma_wait<0>();
+        read_half(F[0], ring + nslot * SBYTES, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int g = 2 * s + 1;
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][0], qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][0], qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][2], qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][2], qh1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][0], ql0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][0], ql1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][2], ql0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][2], ql1[g], a11, 0, 0, 0);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][1], qh0[g], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][1], qh1[g], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][3], qh0[g], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1][3], qh1[g], a11, 0, 0, 0);
+      }
+      slot = nslot;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
       // stage (blk, s) has landed once at most the stages requested after it are still in flight: RING - 2 of them, fewer at the end
@@ -463,6 +545,8 @@ __global__ __launch_bounds__(256, 1) void lp2_score_kernel(Lp2Args a) {
       slot = slot == RING - 1 ? 0 : slot + 1;
       __builtin_amdgcn_sched_barrier(0);      // no motion across stages: the register file is full (Q tile 256 + scores 64 + the stage in flight 32)
     }
+
+#endif
 
     // ---- the four channel quarters of the 64 x 64 score block meet: tile (kt, qt) belongs to wave kt + 2 qt
     const int kb = lp2_block_of(ci, cw.nkb, stag);
