@@ -155,6 +155,38 @@ def test_wgrad_pixel_step_counts(backend, M_img, nsplit, pps):
     assert relerr(grad.cpu(), wr.grad) < 3e-4
 
 
+@pytest.mark.parametrize('M_img,Cin,Cout,nsplit,pps', [(8, 128, 128, 1, 64), (16, 128, 128, 1, 128), (24, 256, 128, 1, 192), (40, 128, 256, 1, 320),
+                                                    (40, 128, 128, 2, 192), (72, 256, 256, 3, 192), (33, 128, 128, 1, 320), (64, 128, 128, 1, 512),
+                                                    (50, 256, 128, 4, 128)])
+def test_wgrad_ring_matches_staged_kernel(backend, M_img, Cin, Cout, nsplit, pps):
+    """the LDS-DMA ring of the 1x1 weight gradient (conv_wgrad_ring_kernel: unpadded, XOR-swizzled stages, 1-8 steps per split,
+    splits and steps that run past M, several k-column / cout tiles) against the register-staged kernel: bit-identical partials
+    and gradients; and against autograd"""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    N, H, W = 1, M_img, 8
+    M = N * H * W
+    assert nsplit * pps >= M
+    g = torch.Generator().manual_seed(M + nsplit + Cin)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1)
+    dy = rb(torch.randn(N, Cout, H, W, generator=g))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, 1, 0).backward(dy)
+    outs = []
+    try:
+        for ring in (1, 0):
+            lib.set_option(b'wgrad_ring', ring)
+            partial = torch.full((nsplit, Cout, Cin), float('nan'), device=dev)
+            grad = torch.zeros(Cout, Cin, 1, 1, device=dev)
+            lib.conv_wgrad(d(nhwc(dy)), d(nhwc(x)), partial, grad, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, nsplit, pps, None)
+            outs.append((partial.cpu(), grad.cpu()))
+    finally:
+        lib.set_option(b'wgrad_ring', 1)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert relerr(outs[0][1], wr.grad) < 3e-4
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', CASES)
 def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
     run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)

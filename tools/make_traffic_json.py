@@ -12,7 +12,7 @@ CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels
     'conv_igemm': ('conv_igemm_kernel', 'conv_skinny_kernel', 'conv_pw_kernel'),
     'conv3x3_halo': ('conv3x3_halo_kernel',),
     'stem_fwd': ('stem_fwd_direct_kernel',),
-    'conv_wgrad': ('conv_wgrad_kernel',),          # (the table-driven reduction of the partials is its own class)
+    'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_ring_kernel'),          # (the table-driven reduction of the partials is its own class)
     'conv3x3_wgrad_halo': ('conv3x3_wgrad_halo_kernel',),
     'stem_wgrad': ('stem_wgrad_fused_kernel',),
     'wgrad_reduce': ('wgrad_reduce_',),

@@ -247,6 +247,125 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the 1x1 / stride-1 weight gradient (LIN = 1 above) on an LDS-DMA ring.  The register-staged kernel keeps ONE 32 KB
+// batch of loads in flight per workgroup and runs one workgroup per CU on the small maps (16 splits x 16 tiles): every 64-pixel
+// step waits a memory latency (~31 us for 16 steps where the operands take 9 us at the HBM rate).  Here wave w copies tile w
+// of a stage (x: k-column halves 0 / 1, dY: cout halves 0 / 1; 64 pixel rows x 128 bytes each) with eight 1 KB `buffer_load ...
+// lds` pieces, WGR_RING - 1 stages ahead, no VGPR staging and one barrier per step.  The rows land UNPADDED (a wave-wide DMA
+// piece writes 1 KB contiguously); the 16-byte chunks of a row are XOR-swizzled with the row index (the lane picks WHICH
+// global chunk it fetches, csrc/labelprop2.hip) so that the transpose reads of a 16-lane group - four rows x 32 bytes - hit four
+// distinct 8-bank sets.  Same MFMA order over the pixels as the staged kernel: bit-identical partials.
+#ifndef WGR_RING
+#define WGR_RING 4
+#endif
+__device__ __forceinline__ bf16x8 wg_tr_frag_b(const unsigned char* tile, int lo_off, int hi_off) {      // byte offsets
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + lo_off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + hi_off));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+__global__ __launch_bounds__(256, 1) void conv_wgrad_ring_kernel(WgradArgs a) {
+  constexpr int RING = WGR_RING, TB = 64 * 128, SB = 4 * TB;      // tile / stage bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char sRing[RING][SB];
+  const ConvGeom g = a.g;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nkb = g.Ktot >> 7, ncb = a.Cout >> 7;
+  int b = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int kb = b % nkb; b /= nkb;
+  const int cb = b % ncb; b /= ncb;
+  const int split = b;
+  const int pix_begin = split * a.pix_per_split;
+  const int iters = a.pix_per_split >> 6;
+
+  // ---- the wave's copy job: tile `wave` of every stage
+  const bool is_x = wave < 2;
+  const unsigned cdim = is_x ? (unsigned)g.C : (unsigned)a.Cout;
+  const vfs_rsrc_words rs = is_x ? vfs_make_rsrc_words(a.x, (unsigned)((size_t)g.M * g.C * 2))
+                                 : vfs_make_rsrc_words(a.dy, (unsigned)((size_t)g.M * a.Cout * 2));
+  const int prow = lane >> 3, cpos = lane & 7;
+  const unsigned ch0 = (is_x ? (unsigned)kb : (unsigned)cb) * 128u + (unsigned)(wave & 1) * 64u + (unsigned)((cpos ^ prow) << 3);
+  unsigned voff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) voff[j] = (unsigned)((((size_t)pix_begin + 8 * j + prow) * cdim + ch0) * 2);
+  const unsigned sstep = 64u * cdim * 2u;
+  const vfs_lds_t ring0 = vfs_lds_addr(&sRing[0][0]) + (vfs_lds_t)(wave * TB);
+  auto issue = [&](int it, int stg) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vfs_dma16_async_at(rs, ring0 + (vfs_lds_t)(stg * SB + j * 1024), voff[j], (unsigned)it * sstep);
+  };
+
+  // ---- fragment geometry (as in the staged kernel); byte offsets inside a swizzled tile for (tm | tn, lo | hi)
+  const int l16 = lane & 15, h2 = lane >> 5;
+  const int pl = 8 * h2 + (l16 >> 2), chq = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+  int foff[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = pl + 4 * hh, ch = chq + 32 * q;
+      foff[q][hh] = row * 128 + ((((ch >> 3) ^ (row & 7))) << 4) + (ch & 7) * 2;
+    }
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+
+#pragma unroll
+  for (int d = 0; d < RING - 1; ++d)
+    if (d < iters) issue(d, d);
+  int stg = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int ahead = min(RING - 2, iters - 1 - it);
+    if (ahead >= 3) vfs_dma_wait<24>(); else if (ahead == 2) vfs_dma_wait<16>(); else if (ahead == 1) vfs_dma_wait<8>(); else vfs_dma_wait<0>();
+    __syncthreads();                       // everybody's pieces of step `it` have landed, everybody is done with step it - 1
+    if (it + RING - 1 < iters) issue(it + RING - 1, stg == 0 ? RING - 1 : stg - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* sa = &sRing[stg][wm * TB];
+    const unsigned char* sd = &sRing[stg][(2 + wn) * TB];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) af[tm] = wg_tr_frag_b(sa, st * 2048 + foff[tm][0], st * 2048 + foff[tm][1]);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) bfr[tn] = wg_tr_frag_b(sd, st * 2048 + foff[tn][0], st * 2048 + foff[tn][1]);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stg = stg == RING - 1 ? 0 : stg + 1;
+  }
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int cout = cb * 128 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kc = kb * 128 + wm * 64 + tm * 32 + 8 * q + 4 * h2;
+        *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
+            (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
+      }
+  }
+}
+
+int vfs_option_wgrad_ring = 1;  // the LDS-DMA ring for 1x1 / stride-1 weight gradients with 128 | C, 128 | Cout (0: the register-staged kernel, A/B knob)
 int vfs_option_wgrad_xcd = 1;   // XCD-aware block order of the generic weight-gradient kernel (A/B knob)
 int vfs_option_wgrad_lin2 = 1;  // ... and its generalisation to evenly tiled 3x3 / stride-2 problems (A/B knob)
 int vfs_option_wgrad_lin = 1;   // the linear-address path for 1x1 / stride-1 problems (A/B knob)
@@ -270,6 +389,13 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
   const size_t rows = (size_t)a.g.M + a.pix_per_split, widest = (size_t)(a.g.C > a.Cout ? a.g.C : a.Cout);
   const bool lin = vfs_option_wgrad_lin && mode == GATHER_FWD && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
                    a.g.H == a.g.Ho && a.g.W == a.g.Wo && rows * widest * 2 < 0xFFF00000ull;
+  if (lin && vfs_option_wgrad_ring && a.g.Ktot % 128 == 0 && a.Cout % 128 == 0) {
+    WgradArgs b = a;
+    const int tiles = (a.g.Ktot >> 7) * (a.Cout >> 7);
+    b.xcd_swizzle = vfs_option_wgrad_xcd && tiles > 1 && tiles * a.nsplit >= 16;
+    hipLaunchKernelGGL(conv_wgrad_ring_kernel, dim3(tiles * a.nsplit), dim3(256), 0, stream, b);
+    return vfs_check_launch("conv_wgrad_ring");
+  }
   if (lin) return wide ? launch_wgrad<128, GATHER_FWD, 1>(a, stream) : launch_wgrad<64, GATHER_FWD, 1>(a, stream);
   // evenly tiled 3x3 / 1x1 with stride 1 or 2 (LIN = 2)
   const size_t inrows = (size_t)a.g.N * a.g.H * a.g.W + (size_t)a.pix_per_split * a.g.stride * a.g.stride + 4 * (size_t)a.g.W;
