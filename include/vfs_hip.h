@@ -37,6 +37,10 @@ int vfs_abi_version(void);
  * "igemm_narrow_below" (64-channel tiles when the 128-channel tiling has fewer tiles than this, default 513),
  * "igemm_mfma_stats" (forward statistics rows on the matrix cores, default 1),
  * "wgrad_lin" (linear-address path of the generic weight gradient for 1x1 / stride-1 problems, default 1),
+ * "wgrad_lin2" (the same for evenly tiled 3x3 / stride-2 problems, default 1), "wgrad_ring" (LDS-DMA ring for the 1x1 / stride-1
+ * weight gradients with 128 | C and 128 | Cout, default 1), "halo_deep_max" (deep schedule of the 3x3 halo kernels for launches of at
+ * most this many workgroups, default 256), "igemm_skinny" (skinny GEMM for <= 128-row Linear layers, default 1), "igemm_ring_mfma32"
+ * (the ring on 32x32x16 MFMAs, default 1), "igemm_ring_gather", "igemm_pw", "igemm_pw_min_tiles" (measured, off by default),
  * "wgrad_xcd" / "halo_xcd" (XCD-aware block order of the weight-gradient kernels / the 3x3 halo kernels, default 1),
  * "halo_min_fill", "bn_chunk_rows", "bn_wide" / "bn_wide_min_mb" (plain BatchNorm apply passes on >= 128-channel tensors of at least
  * that many MB stream whole pixel rows per workgroup, default 1 / 8), "lpx_target" (workgroups the KEY FRAMES of the fp32 label propagation are split
