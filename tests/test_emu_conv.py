@@ -205,9 +205,11 @@ def test_conv_single_buffer_variant(backend, N, H, W, Cin, Cout, k, stride, pad)
         backend.lib.set_option(b'igemm_ring_tiles', 512)
 
 
-@pytest.mark.parametrize('shape', [(48, 40, 3, 3), (70, 33, 1, 1), (5, 3, 5, 5), (64, 64, 3, 3), (130, 257, 1, 1)])
+@pytest.mark.parametrize('shape', [(48, 40, 3, 3), (70, 33, 1, 1), (5, 3, 5, 5), (64, 64, 3, 3), (130, 257, 1, 1),
+                                   (128, 192, 1, 1), (64, 128, 3, 3), (96, 64, 3, 3), (192, 64, 1, 1)])
 def test_pack_weights_ragged(backend, shape):
-    """tiled LDS transpose of the weight repack on tile-ragged / odd shapes, several tensors per launch"""
+    """tiled LDS transpose of the weight repack on tile-ragged / odd shapes, several tensors per launch; the last four shapes (and
+    the second tensor of (64, 64, 3, 3)) take the 16-byte tile variants (kinds 2 / 3 of the pack table)"""
     g = torch.Generator().manual_seed(shape[0])
     dev = backend.dev
     ws = [torch.randn(*shape, generator=g), torch.randn(shape[1], shape[0], 1, 1, generator=g)]

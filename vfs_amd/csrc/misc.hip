@@ -94,6 +94,87 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, int tile, bf16_t* s
   }
 }
 
+
+// Round 5: the two shapes that hold all but a few thousand of a ResNet's weights, with 16-byte global accesses and whole tiles in
+// flight (the generic tile below moves 4 bytes per lane in two dependent phases: 1.9 TB/s over 305 MB, 164 us at the start of
+// every ResNet-50 step).  T = 1, 64 | Cout, 64 | Cin: a 64 x 64 tile - wf is the converted row itself (8 bytes per lane straight
+// from the registers), wd the transpose through LDS (a lane gathers 8 couts of one cin: 16-byte stores, 128-byte row segments).
+// T = 9, 32 | Cout, 64 | Cin: a 32 x 64 x 9 tile - rows of 576 contiguous floats in, wf [cout][tap][64 cin] and wd [cin][tap][32 cout]
+// gathered from the staged tile with 16-byte stores.
+typedef __attribute__((ext_vector_type(2))) uint32_t pk_u32x2;
+__device__ __forceinline__ void pack_tile_1x1_64(const PackDesc& d, int tile, bf16_t* sT) {
+  constexpr int P = 66;                             // bf16 per staged row: 33 dwords (odd)
+  const int t = threadIdx.x;
+  const int tiles_ci = d.Cin >> 6;
+  const int co0 = (tile / tiles_ci) << 6, ci0 = (tile % tiles_ci) << 6;
+  const int r0 = t >> 4, c4 = (t & 15) << 2;
+  f32x4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(d.w + (size_t)(co0 + r0 + 16 * i) * d.Cin + ci0 + c4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 16 * i;
+    const uint32_t lo = pack2bf(v[i][0], v[i][1]), hi = pack2bf(v[i][2], v[i][3]);
+    *reinterpret_cast<pk_u32x2*>(d.wf + (size_t)(co0 + r) * d.Cin + ci0 + c4) = (pk_u32x2){lo, hi};
+    *reinterpret_cast<uint32_t*>(&sT[r * P + c4]) = lo;
+    *reinterpret_cast<uint32_t*>(&sT[r * P + c4 + 2]) = hi;
+  }
+  if (!d.wd) return;
+  __syncthreads();
+  const int co8 = (t & 7) << 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = (t >> 3) + 32 * i;
+    uint32_t w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)sT[(co8 + 2 * j) * P + ci] | ((uint32_t)sT[(co8 + 2 * j + 1) * P + ci] << 16);
+    *reinterpret_cast<u32x4*>(d.wd + (size_t)(ci0 + ci) * d.Cout + co0 + co8) = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+  }
+}
+__device__ __forceinline__ void pack_tile_3x3_32x64(const PackDesc& d, int tile, bf16_t* sT) {
+  constexpr int RL = 64 * 9, P = RL + 2;            // staged row: 576 elements + pad (289 dwords, odd)
+  const int t = threadIdx.x;
+  const int tiles_ci = d.Cin >> 6;
+  const int co0 = (tile / tiles_ci) << 5, ci0 = (tile % tiles_ci) << 6;
+  // in: 32 rows x 144 float4; lane task q = t + 256 i -> row q / 144, float4 q % 144
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int q = t + 256 * (9 * half + i), r = q / 144, k4 = q - r * 144;
+      v[i] = *reinterpret_cast<const f32x4*>(d.w + ((size_t)(co0 + r) * d.Cin + ci0) * 9 + 4 * k4);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int q = t + 256 * (9 * half + i), r = q / 144, k4 = q - r * 144;
+      *reinterpret_cast<uint32_t*>(&sT[r * P + 4 * k4]) = pack2bf(v[i][0], v[i][1]);
+      *reinterpret_cast<uint32_t*>(&sT[r * P + 4 * k4 + 2]) = pack2bf(v[i][2], v[i][3]);
+    }
+  }
+  __syncthreads();
+  // wf[cout][tap][cin]: 288 (cout, tap) rows of 64 cin = 8 lanes x 8 cin
+  for (int q = t; q < 288 * 8; q += 256) {
+    const int row = q >> 3, c8 = (q & 7) << 3, r = row / 9, tap = row - r * 9;
+    const bf16_t* src = sT + r * P + c8 * 9 + tap;
+    uint32_t w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)src[(2 * j) * 9] | ((uint32_t)src[(2 * j + 1) * 9] << 16);
+    *reinterpret_cast<u32x4*>(d.wf + ((size_t)(co0 + r) * 9 + tap) * d.Cin + ci0 + c8) = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+  }
+  if (!d.wd) return;
+  // wd[cin][tap][cout]: 576 (cin, tap) rows of 32 cout = 4 lanes x 8 cout
+  for (int q = t; q < 576 * 4; q += 256) {
+    const int row = q >> 2, co8 = (q & 3) << 3;       // row = ci * 9 + tap = the staged column
+    const bf16_t* src = sT + co8 * P + row;
+    uint32_t w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)src[(2 * j) * P] | ((uint32_t)src[(2 * j + 1) * P] << 16);
+    const int ci = row / 9, tap = row - ci * 9;
+    *reinterpret_cast<u32x4*>(d.wd + ((size_t)(ci0 + ci) * 9 + tap) * d.Cout + co0 + co8) = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+  }
+}
+
 #define PACK_MAX_T 25
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ table, int n) {
   __shared__ __attribute__((aligned(16))) bf16_t sT[PACK_TC * (PACK_TC * PACK_MAX_T + 2)];
@@ -119,6 +200,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __res
     return;
   }
   const int KT = d.KH * d.KW;
+  if (d.kind == 2) { pack_tile_1x1_64(d, tile, sT); return; }
+  if (d.kind == 3) { pack_tile_3x3_32x64(d, tile, sT); return; }
   if (KT == 1) pack_tile<1>(d, tile, sT, 1);
   else if (KT == 9) pack_tile<9>(d, tile, sT, 9);
   else pack_tile<0>(d, tile, sT, KT);

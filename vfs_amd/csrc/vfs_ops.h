@@ -141,8 +141,9 @@ struct PackDesc {
   bf16_t* wd;       // kind 0: [Cin][KH][KW][Cout] or null
   long long start;  // first global element index of this tensor (informational)
   int Cout, Cin, KH, KW;
-  int kind;         // 0: conv / linear   1: 7x7 stem
-  int tile_start;   // first workgroup of this tensor: 32x32 (cout x cin) tiles, or 256-element pieces (stem)
+  int kind;         // 0: conv / linear   1: 7x7 stem   2: 1x1 with 64 | Cout, 64 | Cin (64 x 64 tiles)   3: 3x3 with 32 | Cout, 64 | Cin (32 x 64 tiles);
+                    // 2 and 3 are kind 0 with 16-byte accesses (w, wf, wd 16-byte aligned): same results, chosen by the table builder
+  int tile_start;   // first workgroup of this tensor: 32x32 (cout x cin) tiles (kind 0), 256-element pieces (stem), the tiles above (2, 3)
 };
 int vfs_pack_weights_launch(const PackDesc* table, int ntensors, long long total_tiles, hipStream_t s);
 

@@ -7,22 +7,31 @@ import torch
 PACK_DTYPE = np.dtype([('w', '<u8'), ('wf', '<u8'), ('wd', '<u8'), ('start', '<i8'), ('Cout', '<i4'),
                        ('Cin', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('kind', '<i4'), ('tile_start', '<i4')])
 assert PACK_DTYPE.itemsize == 56
+FAST_PACK = os.environ.get('VFS_FAST_PACK', '1') == '1'      # 16-byte tile variants of the weight packing (A/B switch)
 
 
 def build_pack_table(entries, device):
     """entries: list of (w_fp32[Cout,Cin,KH,KW] tensor, wf bf16 tensor, wd bf16 tensor|None, kind).
     Returns (table uint8 tensor on device, ntensors, total_tiles): one workgroup per 32x32
-    (cout x cin) tile of a tensor, per 256 elements for the stem (csrc/misc.hip)."""
+    (cout x cin) tile of a tensor, per 256 elements for the stem, per 64x64 / 32x64 tile for the aligned 1x1 / 3x3 shapes
+    (kinds 2 / 3, csrc/misc.hip)."""
     arr = np.zeros(len(entries), PACK_DTYPE)
     start = 0
     tiles = 0
     for i, (w, wf, wd, kind) in enumerate(entries):
         shp = list(w.shape) + [1, 1]
         assert kind == 1 or shp[2] * shp[3] <= 25
+        aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (w, wf, wd))
+        ntiles = (w.numel() + 255) // 256 if kind == 1 else ((shp[0] + 31) // 32) * ((shp[1] + 31) // 32)
+        if kind == 0 and aligned and FAST_PACK:      # the two shapes that hold a ResNet's weights: 16-byte accesses (csrc/misc.hip)
+            if shp[2] * shp[3] == 1 and shp[0] % 64 == 0 and shp[1] % 64 == 0:
+                kind, ntiles = 2, (shp[0] // 64) * (shp[1] // 64)
+            elif shp[2] == 3 and shp[3] == 3 and shp[0] % 32 == 0 and shp[1] % 64 == 0:
+                kind, ntiles = 3, (shp[0] // 32) * (shp[1] // 64)
         arr[i] = (w.data_ptr(), wf.data_ptr(), 0 if wd is None else wd.data_ptr(), start,
                   shp[0], shp[1], shp[2], shp[3], kind, tiles)
         start += w.numel()
-        tiles += (w.numel() + 255) // 256 if kind == 1 else ((shp[0] + 31) // 32) * ((shp[1] + 31) // 32)
+        tiles += ntiles
     t = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
     return t, len(entries), tiles
 
