@@ -59,7 +59,9 @@ int vfs_imgs_to_nhwc4(const float* imgs, vfs_bf16* out, int B, int V, int T, int
  * desc: device array of ntensors records {w, wf, wd, start, Cout, Cin, KH, KW, kind, tile_start}
  * (8-byte pointers/int64 then 6 int32; kind 1 = 7x7 stem -> [64][8][8][4]).  One workgroup per
  * 32x32 (cout x cin) tile of a tensor (per 256 elements of the stem); tile_start = running sum,
- * total_tiles = its end (KH*KW <= 25 except the stem). */
+ * total_tiles = its end (KH*KW <= 25 except the stem).  kind 2 / 3 = kind 0 with 16-byte accesses for the shapes that hold a
+ * ResNet's weights - 2: 1x1 with 64 | Cout, 64 | Cin (one workgroup per 64 x 64 tile), 3: 3x3 with 32 | Cout, 64 | Cin (per 32 x 64
+ * tile); w, wf, wd 16-byte aligned; identical results (the table builder of vfs_amd/packing.py chooses them). */
 int vfs_pack_weights(const void* desc, int ntensors, long long total_tiles, vfs_stream_t stream);
 
 /* ---- convolution / linear: torch conv2d & linear call sites ---------------------------------
