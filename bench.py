@@ -159,6 +159,29 @@ def cpu_baseline_subprocess(depth, size, threads, timeout=240):
         return dict(value=None, unit='frame-pairs/s', cores=threads, kind='port', sample=f'timed out after {timeout}s')
 
 
+def extra_train_leg(model, size, batch, steps, warmup, timeout=300):
+    """one more training configuration of BASELINE.json (configs[1]: ResNet-18 T = 4 at 256^2, configs[4]: ResNet-50 at 512^2) through
+    THIS script in a child process (its own engine and buffers, the GPU is idle meanwhile): the child's JSON line, cut down to what
+    a reader of the headline line needs - value, ms_per_step, the step-level roofline and the dominant kernel family"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--model', model, '--size', str(size), '--batch', str(batch), '--steps', str(steps),
+           '--warmup', str(warmup), '--no-cpu-baseline', '--no-davis', '--no-extra-legs']
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        line = next((ln for ln in reversed(out.stdout.splitlines()) if ln.startswith('{')), None)
+        if line is None:
+            return {'value': None, 'error': out.stderr[-300:]}
+        r = json.loads(line)
+        rf = r.get('roofline') or {}
+        return {'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': r['steps'],
+                'warmup': r['warmup'], 'dtype': r['dtype'], 'config': r['config'], 'loss': r.get('loss'), 'step_roofline': r.get('step_roofline'),
+                'roofline': {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches_per_step',
+                                                    'avg_launch_ms', 'kernel_ms_per_step', 'traffic_source')} if rf else None,
+                'command': ' '.join(['python', 'bench.py'] + cmd[2:])}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'error': f'timed out after {timeout}s'}
+
+
 def cpu_baseline(depth, size, threads):
     """The oracle (CPU restatement of the reference's PyTorch path, fp32) timed on the host cores
     on a bounded sample of the same workload."""
@@ -379,6 +402,7 @@ def main():
     ap.add_argument('--no-davis', action='store_true', help='train workload: skip the DAVIS leg appended to the JSON line (N = 1 only)')
     ap.add_argument('--davis-frames', type=int, default=49, help='propagated frames of the appended DAVIS leg (49: the T = 50 clip of BASELINE configs[3] / SURVEY 8(d) Cfg 4)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true', help='default line (ResNet-50, 256^2, N = 1): skip the appended ResNet-18 (configs[1]) and ResNet-50 512^2 (configs[4]) legs (--no-davis skips them too)')
     ap.add_argument('--min-seconds', type=float, default=0.0,
                     help='make the timed region at least this long: the number of timed steps is raised to ceil(min_seconds / step time) '
                          '(a lease-side GPU-busy monitor sampling every few seconds can then corroborate the figure); the JSON reports '
@@ -686,6 +710,16 @@ def main():
         # - its own metric / value / roofline / cpu_baseline under the key "davis" of the same JSON line
         log(f'DAVIS leg: R{depth} {args.precision}, {args.davis_frames} propagated frames ...')
         res['davis'] = bench_davis(args, depth, dev, world, rank, steps=args.davis_frames, warmup=2)
+    if world == 1 and rank == 0 and not args.no_extra_legs and not args.no_davis and args.model == 'r50' and args.size == 256:
+        # BASELINE.json configs[1] and configs[4] beside the headline: after the timed region, each in its own
+        # process, a few seconds of GPU time each
+        del model, opt, imgs, batch
+        eng.bufs.clear()
+        torch.cuda.empty_cache()
+        log('extra leg: ResNet-18 r2_1xNx8 config (T = 4), 256^2 ...')
+        res['r18'] = extra_train_leg('r18', 256, args.batch, 10, 3)
+        log('extra leg: ResNet-50 at 512^2 ...')
+        res['r50_512'] = extra_train_leg('r50', 512, args.batch, 6, 2)
     if rank == 0:
         print(json.dumps(res))
     if dist.is_initialized():

@@ -13,7 +13,8 @@
  *     [Cin][KH][KW][Cout] (dgrad); master parameters / gradients: fp32 in the reference's
  *     layouts (OIHW conv, [out][in] linear) so state_dicts stay interchangeable
  *   - return 0 on success, negative on error; vfs_last_error() gives the message
- *   - thread-safe per stream; one process per GPU
+ *   - thread-safe per stream; one process per GPU.  The operator entry points below read no mutable library state except the A/B
+ *     switchboard of include/vfs_hip_tuning.h, which a production caller never touches (every knob defaults to the measured-best path)
  */
 #ifndef VFS_HIP_H
 #define VFS_HIP_H
@@ -27,26 +28,7 @@ typedef uint16_t vfs_bf16;
 
 const char* vfs_last_error(void);
 int vfs_abi_version(void);
-/* tuning knobs for A/B measurements: "halo" (1 = 3x3/stride-1 convs use the halo-tile kernels),
- * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default), "bn_ticket",
- * "igemm_onek" (single-buffer implicit-GEMM variant: 0 never, 1 one-K-step problems, 2 every 1x1 (default), 3 all),
- * "igemm_ring_tiles" (1x1 problems with at most this many tiles use the LDS-DMA ring, default 512, 0 = off),
- * "igemm_ring_upfront" (ring variant: all fragment reads of a K-step before its MFMAs; default 0: measured, no gain),
- * "igemm_ring_fbn" (the ring also for dgrads with fused BatchNorm-backward statistics, default 1),
- * "igemm_bc" (64 forces the 64-channel tile), "igemm_xcd" (XCD-aware tile order, default 1),
- * "igemm_narrow_below" (64-channel tiles when the 128-channel tiling has fewer tiles than this, default 513),
- * "igemm_mfma_stats" (forward statistics rows on the matrix cores, default 1),
- * "wgrad_lin" (linear-address path of the generic weight gradient for 1x1 / stride-1 problems, default 1),
- * "wgrad_lin2" (the same for evenly tiled 3x3 / stride-2 problems, default 1), "wgrad_ring" (LDS-DMA ring for the 1x1 / stride-1
- * weight gradients with 128 | C and 128 | Cout, default 1), "halo_deep_max" (deep schedule of the 3x3 halo kernels for launches of at
- * most this many workgroups, default 256), "igemm_skinny" (skinny GEMM for <= 128-row Linear layers, default 1), "igemm_ring_mfma32"
- * (the ring on 32x32x16 MFMAs, default 1), "igemm_ring_gather", "igemm_pw", "igemm_pw_min_tiles" (measured, off by default),
- * "wgrad_xcd" / "halo_xcd" (XCD-aware block order of the weight-gradient kernels / the 3x3 halo kernels, default 1),
- * "halo_min_fill", "bn_chunk_rows", "bn_wide" / "bn_wide_min_mb" (plain BatchNorm apply passes on >= 128-channel tensors of at least
- * that many MB stream whole pixel rows per workgroup, default 1 / 8), "lpx_target" (workgroups the KEY FRAMES of the fp32 label propagation are split
- * into; 0 = by channel count), "lpx_wgs" / "lpx_minb" (workgroups reached by also splitting a key frame's window, with at least
- * lpx_minb 64-key blocks each; 0 = 3072 for C >= 512, < 0 = never; default minb 4) */
-int vfs_set_option(const char* name, int value);
+/* (Measurement knobs - vfs_set_option - are NOT part of this contract: include/vfs_hip_tuning.h.) */
 
 /* ---- input / parameter layout -------------------------------------------------------------
  * imgs fp32 [B][2][3][T][H][W] (pipelines/formating.py:248-258) -> bf16 NHWC4 frames
@@ -151,6 +133,19 @@ int vfs_conv_wgrad(const vfs_bf16* dy, const vfs_bf16* x, float* partial, float*
                    int nsplit, int pix_per_split, vfs_stream_t stream);
 int vfs_stem_wgrad(const vfs_bf16* dy, const vfs_bf16* x4, float* partial, float* grad, int N, int H,
                    int Wp, int Ho, int Wo, int nsplit, int pix_per_split, vfs_stream_t stream);
+/* Round 6 - vfs_conv_wgrad / vfs_conv_wgrad_bnin with the split-K reduction INSIDE the launch (one launch per layer instead of
+ * two): the last workgroup of a (k-column, cout) tile to arrive - a device-scope ticket per tile - adds the tile's partials in
+ * ascending split order (run-to-run bit-identical, whichever workgroup arrives last) into grad.  Same operands as vfs_conv_wgrad
+ * (torch autograd of F.conv2d / F.linear wrt the weight, resnet.py:163-191,221-230; sim_siam_head.py:78-111); in_bnp / in_npg as in
+ * vfs_conv_wgrad_bnin or NULL / 0; grad must be given.  partial: workspace of nsplit * Cout * roundup(KH*KW*Cin, 128) floats (the
+ * launch's own layout: whole 128-byte lines per wave, written and read back with device-scope accesses; its contents mean nothing
+ * to the caller).  tickets: unsigned[vfs_wgrad_tickets()] in device memory, ZERO before the
+ * first launch; every launch leaves it zero, so one array serves all launches of a stream (launches that may overlap on different
+ * streams need their own).  Gradients equal the two-launch form's up to the fp32 summation order of the splits. */
+int vfs_wgrad_tickets(void);
+int vfs_conv_wgrad_inl(const vfs_bf16* dy, const vfs_bf16* x, const float* in_bnp, int in_npg, float* partial, float* grad,
+                       unsigned* tickets, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                       int pad, int nsplit, int pix_per_split, vfs_stream_t stream);
 /* db[Cout] += column sums of dy[M][Cout] (linear bias gradient) */
 int vfs_bias_grad(const vfs_bf16* dy, float* db, int M, int C, vfs_stream_t stream);
 
@@ -390,9 +385,12 @@ int vfs_labelprop_f32(const float* fbank, const float* sbank, float* out, void* 
  *   vfs_split_rows_bf16x2: hl [P][C/16][16 hi | 16 lo] bf16 from unit rows x [P][C] fp32 (C % 16 == 0), once per frame;
  *   vfs_labelprop_f32_2pass: hlbank = the split copy of fbank (same frame indexing).  unit_rows = 0 (test_cfg.with_norm=False),
  *   hlbank = NULL or C not in {256, 512, 1024} -> the dense kernel; a candidate list that overflows -> the dense kernel redoes
- *   the frame, decided on the device.  workspace: at least vfs_labelprop_f32_2pass_workspace_bytes(H, W) */
+ *   the frame, decided on the device.  workspace: vfs_labelprop_f32_2pass_workspace_bytes(H, W) for the full list capacity (4608
+ *   entries per query: 237 MB at 60 x 107), or vfs_labelprop_f32_2pass_workspace_bytes_for(H, W, entries_per_query >= 16) - the launch
+ *   derives the capacity from workspace_bytes; fewer entries trade memory for dense redos of the first frames of a clip. */
 int vfs_split_rows_bf16x2(const float* x, vfs_bf16* hl, long long P, int C, vfs_stream_t stream);
 int vfs_labelprop_f32_2pass_workspace_bytes(int H, int W, long long* bytes);
+int vfs_labelprop_f32_2pass_workspace_bytes_for(int H, int W, int entries_per_query, long long* bytes);
 int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const float* sbank, float* out, void* workspace,
                             long long workspace_bytes, int qframe, const int* kslot, int nkeys, int H, int W, int C, int CO,
                             int radius, int non_mask_len, int topk, float temperature, int unit_rows, vfs_stream_t stream);

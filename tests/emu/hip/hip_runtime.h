@@ -499,6 +499,14 @@ inline void raw_buffer_store_b32(unsigned v, rsrc_t r, unsigned voff, unsigned s
   if (o + 4 <= r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 4);      // out of range: dropped, as the hardware
 }
 }  // namespace emu
+namespace emu {
+inline void raw_buffer_store_b128(v4u v, rsrc_t r, unsigned voff, unsigned soff, int aux) {
+  (void)aux;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 16 <= r.num_records) memcpy(const_cast<char*>(r.base) + o, &v, 16);      // out of range: dropped, as the hardware
+}
+}  // namespace emu
+#define __builtin_amdgcn_raw_buffer_store_b128 emu::raw_buffer_store_b128
 #define __builtin_amdgcn_raw_buffer_load_b32 emu::raw_buffer_load_b32
 #define __builtin_amdgcn_raw_buffer_store_b32 emu::raw_buffer_store_b32
 #define __amdgpu_buffer_rsrc_t emu::rsrc_t

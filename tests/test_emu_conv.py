@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from tests.emu_util import pack_relu_mask, nchw, nhwc, rb, relerr
-from vfs_amd.packing import build_pack_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible, wgrad_splits
+from vfs_amd.packing import build_pack_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible, wgrad_inl_floats, wgrad_splits
 
 
 def pack(be, w, stem=False):
@@ -71,6 +71,19 @@ def run_conv_case(be, N, H, W, Cin, Cout, k, stride, pad, wgrad_blocks=12):
     grad = torch.ones(Cout, Cin, k, k, device=be.dev)
     lib.conv_wgrad(d(nhwc(dy)), xh, partial, grad, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, nsplit, pps, None)
     assert relerr(grad.cpu() - 1.0, wr.grad) < 3e-4    # fp32 accumulate / fp32 output, accumulates into grad
+    if Cin % 4 == 0:
+        # round 6: the same gradient with the split-K reduction inside the launch (vfs_conv_wgrad_inl: the last workgroup of a tile
+        # sums the partials in split order): equal to the two-launch form up to the fp32 order of the splits, run-to-run
+        # bit-identical, tickets left at zero
+        tickets = torch.zeros(lib.cfunc('wgrad_tickets')(), dtype=torch.int32, device=be.dev)
+        gi = [torch.ones(Cout, Cin, k, k, device=be.dev) for _ in range(2)]
+        wsi = torch.empty(wgrad_inl_floats(nsplit, Cout, k * k * Cin), device=be.dev)
+        for gq in gi:
+            wsi.fill_(float('nan'))
+            lib.conv_wgrad_inl(d(nhwc(dy)), xh, None, 0, wsi, gq, tickets, N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, nsplit, pps, None)
+        assert torch.equal(gi[0].cpu(), gi[1].cpu())
+        assert int(tickets.cpu().abs().sum()) == 0
+        assert relerr(gi[0].cpu(), grad.cpu()) < 2e-6
 
 
 CASES = [  # N, H, W, Cin, Cout, k, stride, pad
@@ -371,6 +384,10 @@ def test_conv_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):
     lib.conv_wgrad(dy, act, partial, g0, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nsplit, pps, None)
     lib.conv_wgrad_bnin(dy, rawd, bnpd, npg, partial, g1, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nsplit, pps, None)
     assert torch.equal(g1.cpu(), g0.cpu())
+    tickets = torch.zeros(lib.cfunc('wgrad_tickets')(), dtype=torch.int32, device=dev)
+    g2 = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    lib.conv_wgrad_inl(dy, rawd, bnpd, npg, partial, g2, tickets, N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nsplit, pps, None)      # in-launch reduction
+    assert relerr(g2.cpu(), g0.cpu()) < 2e-6 and int(tickets.cpu().abs().sum()) == 0
     with pytest.raises(Exception):       # only the halo-tile shapes fold the input BatchNorm
         lib.conv_fwd_bnin(rawd, bnpd, npg, wf, y1, None, st1, N, H, W, Cin, H // 2, W // 2, Cout, 3, 3, 2, 1, None)
 

@@ -153,3 +153,44 @@ def test_command_tape_records_and_checks_return_codes():
         tape.replay()                                       # the failing call was recorded too
     with pytest.raises(AttributeError):
         rec.no_such_entry_point
+
+
+def test_no_compiler_generated_m0_use_in_lds_dma_kernels(tmp_path):
+    """advisor r05: vfs_dma16_async_at (csrc/vfs_common.h) writes m0 from inline asm without saving it and declares the clobber,
+    which clang warns it cannot honour for a reserved register.  That is safe exactly as long as the COMPILER keeps nothing of its own
+    in m0 in those kernels (s_movrel / v_movrel / s_set_gpr_idx indexing, readlane-by-m0, LDS-direct, builtin LDS-DMA).  Build-time
+    check: every source that issues LDS-DMA pieces is compiled to gfx950 assembly and each line that mentions m0 must be one of
+    ours - `s_mov_b32 m0, <lds address>` in front of a `buffer_load_dword* ... lds`, or the save / restore pair of
+    vfs_dma16_async."""
+    import re
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    srcs = [s for s in build._sources() if re.search(r'vfs_dma16_async', open(s).read())]
+    assert len(srcs) >= 4
+
+    def asm(src):
+        out = tmp_path / (os.path.basename(src) + '.s')
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-w', '-o', str(out), src])
+        return src, out.read_text().splitlines()
+
+    with ThreadPoolExecutor(4) as ex:
+        for src, lines in ex.map(asm, srcs):
+            code = [ln.split(';')[0].strip() for ln in lines]
+            code = [c for c in code if c and not c.startswith('.') and not c.endswith(':')]      # instructions only
+            mine = 0
+            for i, c in enumerate(code):
+                if not re.search(r'\bm0\b', c):
+                    continue
+                nxt, prv = code[i + 1:i + 3], code[max(0, i - 1):i]
+                setup = re.match(r's_mov_b32 m0, \S+$', c) and len(nxt) == 2 and nxt[0].startswith('s_nop') and \
+                    re.match(r'buffer_load_dword\S* .* lds$', nxt[1])                                          # ours: m0 <- LDS address, s_nop, the DMA piece
+                save = re.match(r's_mov_b32 \S+, m0$', c) and nxt and re.match(r's_mov_b32 m0, \S+$', nxt[0])      # vfs_dma16_async: save ...
+                restore = re.match(r's_mov_b32 m0, \S+$', c) and prv and re.match(r'buffer_load_dword\S* .* lds$', prv[0])      # ... and restore
+                step = re.match(r's_add_u32 m0, m0, 0x[0-9a-f]+$', c) and len(nxt) == 2 and nxt[0].startswith('s_nop') and \
+                    re.match(r'buffer_load_dword\S* .* lds$', nxt[1])      # labelprop2.hip: eight pieces of one stage, m0 stepped in place
+                assert setup or save or restore or step, f'{os.path.basename(src)}: compiler-generated m0 use: {code[max(0, i - 2):i + 3]}'
+                mine += 1
+            assert mine > 0, f'{os.path.basename(src)}: no LDS-DMA m0 set-up found (the check looks at the wrong thing)'

@@ -205,6 +205,33 @@ def test_list_overflow_falls_back_to_dense(backend):
     run_2pass(backend, feats, seg, 12, 16, 5, [0, 1, 2], 3, expect_fallback=False)
 
 
+def test_small_workspace_trades_list_capacity_for_dense_redos(backend):
+    """round 6: the list capacity follows the workspace the caller passes -
+    vfs_labelprop_f32_2pass_workspace_bytes_for(H, W, entries per query); 16 entries cannot hold the first key block's candidates
+    (overflow -> the dense kernel redoes the frame), 4608 is the full capacity; same bits either way"""
+    lib = backend.hostlib
+    H, W = 12, 16
+    feats, seg = _features(4, H, W, 256, 3, seed=5, smooth=4.0)
+    fb, hl = _unit_bank(lib, feats)
+    ks = (ctypes.c_int * 3)(0, 1, 2)
+    want = X.labelprop(fb.numpy(), seg.numpy(), 3, [0, 1, 2], H, W, 5, 10, 0.07)
+    sizes = {}
+    for entries, fallback in ((16, 1), (4608, 0)):
+        n = torch.zeros(1, dtype=torch.int64)
+        lib.labelprop_f32_2pass_workspace_bytes_for(H, W, entries, n)
+        sizes[entries] = int(n.item())
+        ws = torch.zeros((int(n.item()) + 3) // 4)
+        out = torch.full((H * W, 3), float('nan'))
+        lib.labelprop_f32_2pass(fb, hl, seg, out, ws, int(n.item()), 3, ks, 3, H, W, 256, 3, 5, 0, 10, 0.07, 1, None)
+        assert same_bits(out.numpy(), want)
+        assert int(ws.view(torch.int32)[(int(n.item()) - 16) // 4]) == fallback
+    full = torch.zeros(1, dtype=torch.int64)
+    lib.labelprop_f32_2pass_workspace_bytes(H, W, full)
+    assert sizes[4608] == int(full.item()) and sizes[4608] - sizes[16] == (4608 - 16) * H * W * 8
+    with pytest.raises(Exception):      # less than the 16-entry minimum
+        lib.labelprop_f32_2pass(fb, hl, seg, out, ws, sizes[16] - 64, 3, ks, 3, H, W, 256, 3, 5, 0, 10, 0.07, 1, None)
+
+
 def test_dense_paths_of_the_entry_point(backend):
     """unit_rows = 0, hlbank = NULL or an uncovered channel count: the entry point is the dense kernel"""
     lib = backend.hostlib

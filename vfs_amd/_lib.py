@@ -8,15 +8,16 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'vfs_hip.h')
+TUNING_HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'vfs_hip_tuning.h')      # vfs_set_option: the A/B switchboard, not part of the operator contract
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libvfs_hip.so')
 
 _CT = {'int': ctypes.c_int, 'long long': ctypes.c_longlong, 'float': ctypes.c_float,
        'double': ctypes.c_double, 'vfs_stream_t': ctypes.c_void_p}
 
 
-def parse_header(path=HEADER):
-    """-> {name: (restype, [(ctype, argname), ...])} for every prototype in the header."""
-    src = open(path).read()
+def parse_header(path=None):
+    """-> {name: (restype, [(ctype, argname), ...])} for every prototype in the header(s)."""
+    src = open(path).read() if path else open(HEADER).read() + open(TUNING_HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     protos = {}
     for m in re.finditer(r'\b(int|const char\*)\s+(vfs_\w+)\s*\(([^)]*)\)\s*;', src):
@@ -60,6 +61,11 @@ class VfsLib:
 
     def last_error(self):
         return self._fns['vfs_last_error']().decode()
+
+    def stream_index(self, name):
+        """position of the `vfs_stream_t stream` argument of entry point `name` (without the vfs_ prefix), None if it has none"""
+        args = self.protos.get('vfs_' + name, (None, []))[1]
+        return next((i for i, (_, an) in enumerate(args) if an == 'stream'), None)
 
     def cfunc(self, name):
         """the raw ctypes function of entry point `name` (without the vfs_ prefix), or None"""
@@ -122,8 +128,8 @@ class Tape:
 
     host_seconds = 0.0      # diagnostics: host time spent replaying tapes (all tapes of the process)
     slowest = None
-    timing = None           # bench.py: a list -> every C-ABI launch of a replay is bracketed by events ON ITS OWN STREAM (the last
-                            # argument of every launch entry point) and (family, flop, bytes, e0, e1) is appended: per-kernel
+    timing = None           # bench.py: a list -> every C-ABI launch of a replay is bracketed by events ON ITS OWN STREAM (the
+                            # `vfs_stream_t stream` argument of its prototype) and (family, flop, e0, e1, bytes) is appended: per-kernel
                             # durations of the schedule that is actually timed (two streams, overlapping), not of an eager stand-in
     _streams = {}
     event_pool = None       # optional list of pre-created timing events (creating one costs more than recording it)
@@ -136,7 +142,8 @@ class Tape:
             if name is None:
                 fn(*args)
                 continue
-            sp = args[-1] if args and (args[-1] is None or isinstance(args[-1], int)) else None
+            si = self.lib.stream_index(name)      # from the header's prototype (advisor r05: not "the last argument if it looks like one")
+            sp = args[si] if si is not None else None
             st = Tape._streams.get(sp)
             if st is None:
                 st = torch.cuda.ExternalStream(sp) if sp else torch.cuda.default_stream()

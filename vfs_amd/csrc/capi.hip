@@ -2,9 +2,11 @@
 #include <string.h>
 
 #include "../../include/vfs_hip.h"
+#include "../../include/vfs_hip_tuning.h"
 #include "vfs_conv.h"
 #include "vfs_ops.h"
 #include "vfs_p2p.h"
+#include "vfs_wgrad_tail.h"
 
 static thread_local char g_err[512] = "";
 
@@ -259,6 +261,23 @@ int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* 
     return VFS_OK;
   }
   return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
+}
+
+int vfs_wgrad_tickets(void) { return VFS_WGRAD_TICKETS; }
+int vfs_conv_wgrad_inl(const vfs_bf16* dy, const vfs_bf16* x, const float* in_bnp, int in_npg, float* partial, float* grad,
+                       unsigned* tickets, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                       int pad, int nsplit, int pix_per_split, vfs_stream_t stream) {
+  if (!grad || !tickets || !partial) return vfs_set_error(VFS_ERR_ARG, "conv_wgrad_inl: partial, grad and tickets must be given");
+  if (in_bnp && in_npg <= 0) return vfs_set_error(VFS_ERR_ARG, "conv_wgrad_inl: images per BatchNorm group of the input");
+  WgradArgs a;
+  a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
+  a.dy = dy; a.x = x; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
+  a.in_bnp = in_bnp; a.in_npg = in_bnp ? in_npg : 0;
+  a.grad = grad; a.tickets = tickets;
+  if (vfs_option_halo && vfs_wgrad_halo_eligible(a, GATHER_FWD) && !(in_bnp && vfs_small_map(H, W) && in_npg % 2))
+    return vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);
+  if (in_bnp) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_inl: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
+  return vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
 }
 
 int vfs_stem_wgrad(const vfs_bf16* dy, const vfs_bf16* x4, float* partial, float* grad, int N, int H, int Wp, int Ho, int Wo,
@@ -620,13 +639,22 @@ int vfs_split_rows_bf16x2(const float* x, vfs_bf16* hl, long long P, int C, vfs_
   if (!x || !hl) return vfs_set_error(VFS_ERR_ARG, "split_rows_bf16x2: null buffer");
   return vfs_split_rows_bf16x2_launch(x, hl, P, C, S(stream));
 }
-static long long lp2_lists_bytes(int H, int W) { return (long long)LP2_MAX_SPLIT * H * W * LP2_MAX_CAP * 8; }
+static long long lp2_lists_bytes(int H, int W, int entries) { return (long long)entries * H * W * 8; }
 static long long lp2_counts_bytes(int H, int W) { return ((long long)(LP2_MAX_SPLIT + 1) * H * W * 4 + 15) / 16 * 16; }      // counts + thresholds
-int vfs_labelprop_f32_2pass_workspace_bytes(int H, int W, long long* bytes) {
+// workspace: [dense kernel's partial lists][candidate lists: `entries` per query, shared out among the key-frame splits in use]
+// [counts + thresholds][16 bytes of flags].  Round 6: the list area follows the workspace the caller passes (vfs_labelprop_f32_2pass
+// derives the entries per query from workspace_bytes) - 4608 entries (237 MB at 60 x 107) is what never overflowed on the bench
+// clips, fewer entries trade memory for dense redos of the first frames of a clip (cold thresholds, long lists).
+int vfs_labelprop_f32_2pass_workspace_bytes_for(int H, int W, int entries_per_query, long long* bytes) {
   long long dense = 0;
-  if (!bytes || vfs_labelprop_workspace_bytes(H, W, &dense) != VFS_OK) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass_workspace_bytes: bad argument");
-  *bytes = dense + lp2_lists_bytes(H, W) + lp2_counts_bytes(H, W) + 16;
+  if (!bytes || entries_per_query < 16 || vfs_labelprop_workspace_bytes(H, W, &dense) != VFS_OK)
+    return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass_workspace_bytes: bad argument (at least 16 list entries per query)");
+  if (entries_per_query > LP2_MAX_SPLIT * LP2_MAX_CAP) entries_per_query = LP2_MAX_SPLIT * LP2_MAX_CAP;
+  *bytes = dense + lp2_lists_bytes(H, W, entries_per_query) + lp2_counts_bytes(H, W) + 16;
   return VFS_OK;
+}
+int vfs_labelprop_f32_2pass_workspace_bytes(int H, int W, long long* bytes) {
+  return vfs_labelprop_f32_2pass_workspace_bytes_for(H, W, LP2_MAX_SPLIT * LP2_MAX_CAP, bytes);
 }
 int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const float* sbank, float* out, void* workspace,
                             long long workspace_bytes, int qframe, const int* kslot, int nkeys, int H, int W, int C, int CO, int radius,
@@ -637,16 +665,18 @@ int vfs_labelprop_f32_2pass(const float* fbank, const vfs_bf16* hlbank, const fl
   if (nkeys < 1 || nkeys > LP_MAX_KEYS) return vfs_set_error(VFS_ERR_SHAPE, "labelprop_f32_2pass: 1 <= nkeys <= 64");
   if (non_mask_len < 0 || non_mask_len >= nkeys + (radius <= 0)) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: 0 <= non_mask_len < nkeys");
   long long need = 0, dense = 0;
-  if (vfs_labelprop_f32_2pass_workspace_bytes(H, W, &need) != VFS_OK || vfs_labelprop_workspace_bytes(H, W, &dense) != VFS_OK || !workspace ||
+  if (vfs_labelprop_f32_2pass_workspace_bytes_for(H, W, 16, &need) != VFS_OK || vfs_labelprop_workspace_bytes(H, W, &dense) != VFS_OK || !workspace ||
       workspace_bytes < need)
-    return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: workspace smaller than vfs_labelprop_f32_2pass_workspace_bytes(H, W)");
+    return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: workspace smaller than vfs_labelprop_f32_2pass_workspace_bytes_for(H, W, 16)");
   Lp2Args p;
   p.fbank = fbank; p.hl = hlbank; p.sbank = sbank; p.out = out;
+  const long long entries = (workspace_bytes - dense - lp2_counts_bytes(H, W) - 16) / ((long long)H * W * 8);
+  p.entries = (int)(entries > LP2_MAX_SPLIT * LP2_MAX_CAP ? LP2_MAX_SPLIT * LP2_MAX_CAP : entries);
   char* ws = (char*)workspace + dense;
   p.lists = (unsigned long long*)ws;
-  p.counts = (int*)(ws + lp2_lists_bytes(H, W));
+  p.counts = (int*)(ws + lp2_lists_bytes(H, W, p.entries));
   p.gthr = p.counts + (size_t)LP2_MAX_SPLIT * H * W;
-  p.flags = (int*)(ws + lp2_lists_bytes(H, W) + lp2_counts_bytes(H, W));
+  p.flags = (int*)(ws + lp2_lists_bytes(H, W, p.entries) + lp2_counts_bytes(H, W));
   p.qframe = qframe; p.nkeys = nkeys;
   for (int i = 0; i < LP_MAX_KEYS; ++i) p.kslot[i] = i < nkeys ? kslot[i] : 0;
   p.H = H; p.W = W; p.C = C; p.CO = CO; p.radius = radius; p.topk = topk; p.non_mask_len = non_mask_len; p.temperature = temperature;

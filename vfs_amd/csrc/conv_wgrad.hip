@@ -12,6 +12,7 @@
 // scatters into the reference's OIHW parameter layout.
 #include "vfs_conv.h"
 #include "vfs_ops.h"
+#include "vfs_wgrad_tail.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define WG_RS 72   // LDS row pitch of a [pixel][64 channels] tile: 144 B (see conv_wgrad_halo.hip)
@@ -232,18 +233,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 
   // D[k-column][cout] (32 x 32 tiles): register 4 q + r of lane l = k-column 8 q + 4 (l / 32) + r, cout l % 32 -> 16-byte stores
+  if (MODE != GATHER_FWD || !a.tickets) {
 #pragma unroll
-  for (int tn = 0; tn < QN; ++tn) {
-    const int cout = cb * BCW + wn * (BCW / 2) + tn * 32 + (lane & 31);
+    for (int tn = 0; tn < QN; ++tn) {
+      const int cout = cb * BCW + wn * (BCW / 2) + tn * 32 + (lane & 31);
+#pragma unroll
+      for (int tm = 0; tm < QM; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kc = kb * BKC + wm * 64 + tm * 32 + 8 * q + 4 * h2;
+          if (kc < g.Ktot)
+            *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
+                (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
+        }
+    }
+    return;
+  }
+  // in-launch split-K reduction (vfs_wgrad_tail.h): partials as register images, the last split of this (kb, cb) tile to arrive sums
+  // all of them in split order
+  constexpr int NI = QN * QM * 4;
+  const int tile = cb * nkb + kb, ntiles = nkb * ncb;
+  const __amdgpu_buffer_rsrc_t prs = wgt_partial_rsrc(a, ntiles, NI);
+#pragma unroll
+  for (int tn = 0; tn < QN; ++tn)
 #pragma unroll
     for (int tm = 0; tm < QM; ++tm)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kc = kb * BKC + wm * 64 + tm * 32 + 8 * q + 4 * h2;
-        if (kc < g.Ktot)
-          *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
-              (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
-      }
+      for (int q = 0; q < 4; ++q)
+        if (kb * BKC + wm * 64 + tm * 32 < g.Ktot)      // (whole 32-column tiles: Ktot % 64 == 0)
+          wgt_store_piece(prs, wgt_piece_off(split, tile, ntiles, NI, (tn * QM + tm) * 4 + q),
+                          (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]});
+  if (!wgt_last_arriver(a, tile)) return;
+  const unsigned sstride = (unsigned)((size_t)ntiles * NI * 4096);
+  // four 16-byte pieces (one 32 x 32 accumulator tile) at a time: 16 loads in flight per lane, the registers of the main loop suffice
+#pragma unroll 1
+  for (int tt = 0; tt < QN * QM; ++tt) {
+    const int tn = tt / QM, tm = tt - tn * QM;
+    const int cout = cb * BCW + wn * (BCW / 2) + tn * 32 + (lane & 31);
+    const bool ok = kb * BKC + wm * 64 + tm * 32 < g.Ktot;
+    unsigned off[4];
+    f32x4 sum[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q] = ok ? wgt_piece_off(0, tile, ntiles, NI, tt * 4 + q) : WGT_SKIP;
+    wgt_sum_splits<4>(a, prs, sstride, off, sum);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ok) wgt_add_grad(a, cout, kb * BKC + wm * 64 + tm * 32 + 8 * q + 4 * h2, sum[q]);
   }
 }
 
@@ -351,17 +386,45 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ring_kernel(WgradArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     stg = stg == RING - 1 ? 0 : stg + 1;
   }
+  if (!a.tickets) {
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int cout = cb * 128 + wn * 64 + tn * 32 + (lane & 31);
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cout = cb * 128 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kc = kb * 128 + wm * 64 + tm * 32 + 8 * q + 4 * h2;
+          *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
+              (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
+        }
+    }
+    return;
+  }
+  // in-launch split-K reduction (vfs_wgrad_tail.h)
+  const int tile = cb * nkb + kb, ntiles = nkb * ncb;
+  const __amdgpu_buffer_rsrc_t prs = wgt_partial_rsrc(a, ntiles, 16);
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kc = kb * 128 + wm * 64 + tm * 32 + 8 * q + 4 * h2;
-        *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) =
-            (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
-      }
+      for (int q = 0; q < 4; ++q)
+        wgt_store_piece(prs, wgt_piece_off(split, tile, ntiles, 16, (tn * 2 + tm) * 4 + q),
+                        (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]});
+  if (!wgt_last_arriver(a, tile)) return;
+  const unsigned sstride = (unsigned)((size_t)ntiles * 16 * 4096);
+#pragma unroll 1
+  for (int tt = 0; tt < 4; ++tt) {
+    const int tn = tt >> 1, tm = tt & 1;
+    const int cout = cb * 128 + wn * 64 + tn * 32 + (lane & 31);
+    unsigned off[4];
+    f32x4 sum[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q] = wgt_piece_off(0, tile, ntiles, 16, tt * 4 + q);
+    wgt_sum_splits<4>(a, prs, sstride, off, sum);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wgt_add_grad(a, cout, kb * 128 + wm * 64 + tm * 32 + 8 * q + 4 * h2, sum[q]);
   }
 }
 
@@ -384,6 +447,9 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
   if (a.g.Ktot % 64 || a.Cout % 64 || a.pix_per_split % 64 || a.nsplit < 1)
     return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: K%64, Cout%64, pix_per_split%64");
   if ((long long)a.pix_per_split * a.nsplit < a.g.M) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: splits do not cover M");
+  if (a.tickets && (mode != GATHER_FWD || !a.grad || ((a.g.Ktot + 127) / 128) * (a.Cout / 64) > VFS_WGRAD_TICKETS || a.g.C % 4 ||
+                    (size_t)a.nsplit * a.Cout * ((a.g.Ktot + 127) / 128 * 128) * 4 >= 0xFFFFFFF0ull))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: the in-launch reduction takes forward-layout problems with a gradient, Cin % 4 == 0, at most 4096 tiles and < 4 GiB of partials");
   const bool wide = (a.Cout % 128 == 0);
   // 1x1 / stride 1 / no padding with 32-bit row offsets (the last split may run past M by less than pix_per_split rows)
   const size_t rows = (size_t)a.g.M + a.pix_per_split, widest = (size_t)(a.g.C > a.Cout ? a.g.C : a.Cout);

@@ -14,6 +14,7 @@
 // fragments of a 32-pixel k-step are reused by the nine taps; nine accumulator sets (144 VGPRs)
 // stay in registers.  Split-K over tile ranges, fp32 partials in the layout wgrad_reduce expects.
 #include "vfs_conv.h"
+#include "vfs_wgrad_tail.h"
 
 #define OOB_OFFSET 0xFFFFFFF0u
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -197,17 +198,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
   }
 
   // D[cin][cout]: lane holds 4 consecutive cin of cout = lane&15 -> one 16-byte store
+  if (!a.tickets) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int cout = cb * 64 + wn * 32 + tn * 16 + lr;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const int kc = tp * g.C + cc * 64 + wm * 32 + tm * 16 + lq * 4;
+          *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) = acc[tp][tm][tn];
+        }
+      }
+    return;
+  }
+  // in-launch split-K reduction (vfs_wgrad_tail.h): partials as register images (36 pieces per thread); the last split of this
+  // (cin chunk, cout block) tile to arrive sums all of them in split order, one tap (four pieces) at a time
+  const int tile = cb * nchunk + cc, nwt = nchunk * ncb;
+  const __amdgpu_buffer_rsrc_t prs = wgt_partial_rsrc(a, nwt, 36);
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int cout = cb * 64 + wn * 32 + tn * 16 + lr;
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) wgt_store_piece(prs, wgt_piece_off(split, tile, nwt, 36, tp * 4 + tn * 2 + tm), acc[tp][tm][tn]);
+  if (!wgt_last_arriver(a, tile)) return;
+  const unsigned sstride = (unsigned)((size_t)nwt * 36 * 4096);
+#pragma unroll 1
+  for (int tp = 0; tp < 9; ++tp) {
+    unsigned off[4];
+    f32x4 sum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) off[i] = wgt_piece_off(0, tile, nwt, 36, tp * 4 + i);
+    wgt_sum_splits<4>(a, prs, sstride, off, sum);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
-        const int kc = tp * g.C + cc * 64 + wm * 32 + tm * 16 + lq * 4;
-        *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Cout + cout) * g.Ktot + kc) = acc[tp][tm][tn];
+        const int cout = cb * 64 + wn * 32 + tn * 16 + lr, kc = tp * g.C + cc * 64 + wm * 32 + tm * 16 + lq * 4;
+        wgt_add_grad(a, cout, kc, sum[tn * 2 + tm]);
       }
-    }
+  }
 }
 
 bool vfs_wgrad_halo_eligible(const WgradArgs& a, int mode) {
@@ -233,6 +264,8 @@ int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsp
   const int blocks = (a.g.C >> 6) * (a.Cout >> 6) * b.nsplit;
   b.xcd_swizzle = vfs_option_wgrad_xcd && (a.g.C >> 6) * (a.Cout >> 6) > 1 && blocks >= 16;
   if (a.in_bnp && (a.g.N + a.in_npg - 1) / a.in_npg > 8) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: more than 8 BatchNorm groups");
+  if (b.tickets && (!b.grad || (a.g.C >> 6) * (a.Cout >> 6) > VFS_WGRAD_TICKETS || (size_t)b.nsplit * a.Cout * a.g.Ktot * 4 >= 0xFFFFFFF0ull))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: the in-launch reduction takes a gradient, at most 4096 tiles and < 4 GiB of partials");
   if (smallw) {
     if (a.in_bnp) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);
     else hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, b, tps, ntiles);

@@ -861,7 +861,8 @@ int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s) {
   a.nsplit = vfs_lp2_splits(a.H, a.W, a.nkeys);
   // the list workspace (LP2_MAX_SPLIT x LP2_MAX_CAP entries per query) is shared out among the splits in use: the first steps of a
   // clip have few key frames (few splits) and cold thresholds (long lists)
-  a.cap = min(vfs_option_lp2_cap > 0 ? vfs_option_lp2_cap : LP2_LIST_MAX, min(LP2_LIST_MAX, LP2_MAX_SPLIT * LP2_MAX_CAP / a.nsplit));
+  a.cap = min(vfs_option_lp2_cap > 0 ? vfs_option_lp2_cap : LP2_LIST_MAX, min(LP2_LIST_MAX, a.entries / a.nsplit));
+  if (a.cap < 1) return vfs_set_error(VFS_ERR_ARG, "labelprop_f32_2pass: the workspace holds less than one list entry per (key-frame split, query)");
   const int tiles = ((a.H + 7) / 8) * ((a.W + 7) / 8);
   if (hipMemsetAsync(a.flags, 0, sizeof(int), s) != hipSuccess) return vfs_set_error(VFS_ERR_LAUNCH, "labelprop_f32_2pass: hipMemsetAsync");
   hipLaunchKernelGGL(lp2_seed_kernel, dim3((a.H * a.W + 3) / 4), dim3(256), 0, s, a);

@@ -90,6 +90,11 @@ struct WgradArgs {
   const float* in_bnp; // optional: x is a RAW conv output, relu(x*scale+shift) is applied while staging (halo kernel)
   int in_npg;
   int xcd_swizzle = 0; // generic kernel: XCD-aware logical block order (set by the dispatcher)
+  // optional in-launch split-K reduction (round 6, vfs_wgrad_tail.h): the last workgroup of a (k-column, cout) tile to arrive sums the
+  // tile's partials in split order and adds them to grad (reference OIHW layout); tickets: unsigned[VFS_WGRAD_TICKETS], zero before
+  // the first launch, left at zero.  tickets == nullptr: partials only (the caller launches wgrad_reduce).
+  float* grad = nullptr;
+  unsigned* tickets = nullptr;
 };
 
 // relu(x*scale + shift) on one 16-byte vector (8 channels), rounded to bf16 exactly as bn_act_kernel does

@@ -300,6 +300,7 @@ struct Lp2Args {
   int H, W, C, CO, radius, topk, non_mask_len;
   float temperature, margin;
   int cap, nsplit, xcd_order, dbg, trim;
+  int entries;               // list entries per query the workspace holds (shared out among the splits: cap <= entries / nsplit)
 };
 int vfs_split_rows_bf16x2_launch(const float* x, bf16_t* hl, long long P, int C, hipStream_t s);
 int vfs_labelprop_f32_2pass_launch(Lp2Args a, hipStream_t s);

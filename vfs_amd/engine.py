@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from ._lib import Tape, TapeLib, get_lib
 from .packing import (igemm_ksplit, bn_fold_eligible, build_pack_table, build_reduce_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible,
-                      wgrad_splits)
+                      wgrad_inl_floats, wgrad_splits)
 
 BF16 = torch.bfloat16
 
@@ -31,6 +31,7 @@ MASK_BITS = os.environ.get('VFS_MASK_BITS', '1') == '1'   # residual joins also 
 NOMASK = os.environ.get('VFS_DEBUG_NOMASK') == '1'     # what-if timing: BatchNorm backward without reading the activation as ReLU mask
 SKIP = frozenset(filter(None, os.environ.get('VFS_DEBUG_SKIP', '').split(',')))
 KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's Linear layers (slower as measured)
+WGRAD_INL = os.environ.get('VFS_WGRAD_INL', '0') == '1'      # round 6, opt-in: split-K reduction of the weight gradients inside the launch (vfs_conv_wgrad_inl) - measured SLOWER (R50 7.97 -> 10.8 ms: device-scope sc1 accesses move ~0.2 TB/s, MEASUREMENTS.md); default: kernel + wgrad_reduce
 
 
 class ConvUnit:
@@ -52,6 +53,7 @@ class ConvUnit:
 class Engine:
     def __init__(self, lib=None):
         self.lib = lib if lib is not None else get_lib()
+        self.n_wgrad_tickets = int(self.lib.cfunc('wgrad_tickets')())      # size of the ticket array of vfs_conv_wgrad_inl
         self.bufs = {}
         self.units = []
         self._pack = None
@@ -611,6 +613,16 @@ class Engine:
             return self.buf(f'{u.name}.wpart', (nsplit * cout * ktot,), torch.float32, dev)
         return self.ws('ws.wgrad', nsplit * cout * ktot, torch.float32, dev)
 
+    def wgrad_tickets(self, dev):
+        """uint32 tickets of the in-launch split-K reductions (vfs_conv_wgrad_inl): zero once, every launch leaves them at zero;
+        shared by all weight-gradient launches - they run one after the other on the side stream"""
+        t = self.bufs.get('ws.wgrad_tickets')
+        if t is None or t.device != dev:
+            t = torch.zeros(self.n_wgrad_tickets, dtype=torch.int32, device=dev)
+            self.bufs['ws.wgrad_tickets'] = t
+            self.generation += 1
+        return t
+
     def wgrad_target(self, u, partial, nsplit, cout, ktot, cin, k, stem):
         """the `grad` argument of the weight-gradient entry points: the gradient itself, or None (= reduce later)"""
         if not self.defer_wgrad:
@@ -657,7 +669,9 @@ class Engine:
         ktot = u.k * u.k * u.cin
         halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
-        partial = self.wgrad_partial(u, nsplit, u.cout, ktot, dev) if u.weight.requires_grad else None
+        inl = (WGRAD_INL and not self.defer_wgrad and u.cin % 4 == 0 and ((ktot + 127) // 128) * (u.cout // 64) <= self.n_wgrad_tickets)
+        partial = ((self.ws('ws.wgrad', wgrad_inl_floats(nsplit, u.cout, ktot), torch.float32, dev) if inl else self.wgrad_partial(u, nsplit, u.cout, ktot, dev))
+                   if u.weight.requires_grad else None)
         flops = 2.0 * M * u.cout * ktot
         # ALGORITHMIC bytes: dY + x once, the fp32 gradient read-modify-write.  (The fp32 split-K partials - written by the
         # kernel, re-read by the reduction: 8 * nsplit * Cout * Ktot bytes - are implementation traffic; they show up in the
@@ -672,7 +686,12 @@ class Engine:
             wtarget = self.wgrad_target(u, partial, nsplit, u.cout, ktot, u.cin, u.k, 0)
             with self.on_side_stream(dev):
                 ss = self.stream(dev)
-                if x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
+                if inl:
+                    # one launch: the last workgroup of a tile sums the split-K partials itself (the launches of ONE stream share the tickets)
+                    inb = x_in_bn if x_in_bn is not None else (None, 0)
+                    self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad_inl, dx, x_in, inb[0], inb[1],
+                               partial, wtarget, self.wgrad_tickets(dev), N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
+                elif x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
                     self.timed('conv3x3_wgrad_halo', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
                                wtarget, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
                 else:

@@ -202,7 +202,13 @@ def forward_test_hip(tracker, imgs, ref_seg_map, img_meta):
         pairs = mask_pairs(h, w, radius)
         partial = eng.ws('ws.segpost', 64 * CO * 2, F32, dev)
         nbytes = torch.zeros(1, dtype=torch.int64)
-        (eng.lib.labelprop_f32_2pass_workspace_bytes if hl is not None else eng.lib.labelprop_workspace_bytes)(h, w, nbytes)
+        entries = int(tc.get('lp2_entries', os.environ.get('VFS_LP2_ENTRIES', 0)))      # list entries per query of the two-pass kernels (0: full capacity, 237 MB at 60 x 107)
+        if hl is None:
+            eng.lib.labelprop_workspace_bytes(h, w, nbytes)
+        elif entries > 0:
+            eng.lib.labelprop_f32_2pass_workspace_bytes_for(h, w, entries, nbytes)
+        else:
+            eng.lib.labelprop_f32_2pass_workspace_bytes(h, w, nbytes)
         lpws = eng.ws('ws.labelprop', (int(nbytes.item()) + 3) // 4, F32, dev)
         for f in range(1, clip_len):
             key_start = max(0, f - precede)

@@ -3,6 +3,8 @@ weight_decay; dampening 0): one HIP launch per contiguous range of TRAINABLE par
 configs).  Parameters with requires_grad=False are never touched - the reference's optimizer does not hold them, so
 they get neither weight decay nor momentum.  The momentum arena is exposed through `state[p]['momentum_buffer']`
 (views), so `state_dict()` / `load_state_dict()` - what mmcv's checkpoint hook and `--resume-from` use - carry it."""
+import os
+
 import torch
 
 from .engine import bump_params_epoch, shared_engine
@@ -64,6 +66,28 @@ class SGD(torch.optim.Optimizer):
         for lo, hi in segs:
             eng.timed('sgd', (0.0, 20.0 * (hi - lo)), flat.device, eng.lib.sgd_step, flat[lo:hi], g[lo:hi], self._buf[lo:hi], hi - lo,
                       float(grp['lr']), float(grp['momentum']), float(grp['weight_decay']), skip, eng.stream(flat.device))
+        if skip is not None:
+            self._watch_exchange(x)
+
+    def _watch_exchange(self, x, every=int(os.environ.get('VFS_P2P_CHECK_EVERY', '50'))):
+        """the error word of the SyncBN window exchange is sticky: once set, every later update is skipped on every rank (the word is
+        MAX-reduced over the ranks, trackers.py).  A consumer that never reads the log values would then train as a silent no-op
+        (advisor r05): every `every` steps a copy of the word is queued to pinned memory and the copy queued `every` steps earlier -
+        long complete, no stall - is looked at; a set word raises here, at most 2 x `every` steps after the failed exchange."""
+        self._xsteps = getattr(self, '_xsteps', 0) + 1
+        if self._xsteps % every:
+            return
+        pend = getattr(self, '_xpending', None)
+        if pend is not None:
+            pend[1].synchronize()
+            if int(pend[0][0]):
+                raise RuntimeError('SyncBN P2P exchange: a peer did not arrive within the spin limit (VFS_P2P_SPIN) in an earlier step; every '
+                                   'update since has been skipped on all ranks - stop, or restart from the last checkpoint')
+        host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        host.copy_(x.state[1:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._xpending = (host, ev)
 
     def load_state_dict(self, state_dict):
         """torch's loader replaces the state tensors by copies: put them back into the momentum arena"""

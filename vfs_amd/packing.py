@@ -134,6 +134,11 @@ def igemm_ksplit(M, Cout, Ktot, target_blocks=256):
     return ks, 1024 + tiles * ks * 128 * bc
 
 
+def wgrad_inl_floats(nsplit, Cout, Ktot):
+    """workspace (floats) of vfs_conv_wgrad_inl: the generic kernel's tiles are 128 k-columns wide"""
+    return nsplit * Cout * ((Ktot + 127) // 128 * 128)
+
+
 def wgrad_splits(M, Cout, Ktot, target_blocks=256, halo_geom=None):
     """Split-K plan for the wgrad kernels: (nsplit, pix_per_split).  halo_geom = (N, H, W, Cin)
     selects the plan of the 3x3 halo kernel (workgroup = 64 cin x 64 cout x 9 taps, split over
