@@ -340,7 +340,7 @@ def bench_davis(args, depth, dev, world, rank, steps=None, warmup=None):
 
         # HBM bytes per launch from the committed PMC passes of this workload (tools/gpu_pmc.sh <model> davis + make_traffic_json.py)
         tclasses, tsource = {}, None
-        for tag in ('r05', 'r04', 'r03'):
+        for tag in ('r06', 'r05', 'r04', 'r03'):
             tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_davis_{args.model}.json')
             if args.precision == 'fp32' and os.path.exists(tpath):
                 tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
@@ -585,7 +585,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'ResNet-{depth} SimSiam (VFS) forward_train+backward+SGD, imgs [{B},2,3,{T},{args.size},'
-                               f'{args.size}] per GPU (configs[{1 if depth == 18 else 2}] shape), SyncBN, fp32 master weights',
+                               f'{args.size}] per GPU (configs[{1 if depth == 18 else (4 if args.size == 512 else 2)}] shape), SyncBN, fp32 master weights',
                    'frame_pairs_per_step': pairs_per_step, 'parallelism': f'dp{world}'},
         'loss': out['log_vars']['loss'],
         'launch_mode': ('hipGraph replay (forward chain + backward chain)' if (world == 1 and os.environ.get('VFS_GRAPHS', '0') == '1')
@@ -630,8 +630,8 @@ def main():
         # HBM bytes per launch of every family from the committed PMC passes (tools/gpu_pmc.sh + make_traffic_json.py:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as the guide prescribes for gfx950)
         tclasses, tsource = {}, None
-        for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
-            tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_{args.model}.json')
+        for tag in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
+            tpath = os.path.join(REPO, 'profiles', f'{tag}_traffic_{args.model}{"" if args.size == 256 else "_" + str(args.size)}.json')
             if os.path.exists(tpath):
                 tclasses, tsource = json.load(open(tpath)).get('classes', {}), os.path.relpath(tpath, REPO)
                 break

@@ -301,6 +301,30 @@ int vfs_bn_reduce_partials_xchg(const float* partial, double* sums, double* scra
 int vfs_bn_bwd_sums_paramgrad_xchg(const float* partial, double* sums, double* scratch, float* dgamma,
                                    float* dbeta, int G, int bpg, int C, const void* peers, int rank, int world,
                                    void* state, long long spin_limit, vfs_stream_t stream);
+/* Round 6 - the exchange FOLDED into the apply passes of vfs_bn_act_fin_mask / vfs_bn_bwd_apply_fin (small row counts: the 16x16 /
+ * 8x8 stages): `partial` holds the LOCAL statistics rows; the first workgroup of every 64-channel slab sums them, exchanges the
+ * slab's G*2*64 sums with the peers' workgroups of the same slab through the windows and releases the slab's other workgroups, which
+ * wait on a device-scope word instead of summing rows.  sums / bnp / running statistics (forward) and sums (backward) come from the
+ * totals over the ranks, count = GLOBAL element count; dgamma / dbeta stay local sums.  Replaces vfs_bn_reduce_partials_xchg +
+ * vfs_bn_act_fin (forward) and vfs_bn_bwd_sums_paramgrad_xchg + vfs_bn_bwd_apply (backward): one dependent launch less per BatchNorm
+ * layer and direction - the SyncBN step costs what the single-GPU step costs plus the exchange latency.  G*2*min(C,64) <= 256
+ * (two views), C <= 4096, G*2*C <= 8192.  state: (4 + 64) x uint64 in device memory, zero-initialised ({exchange counter, error
+ * flag, workgroup ticket, chain counter, slab_ready[64]}); peers / rank / world / spin_limit as vfs_bn_reduce_partials_xchg.
+ * seq (0 .. 4094) numbers the folded exchanges of one launch chain: the exchange's epoch is state[3] * 4096 + seq + 1, and every rank
+ * must issue the same (chain, seq) sequence - vfs_p2p_chain_start(state) (one single-thread launch: state[3] += 1) goes to the head
+ * of every chain that is recorded once and replayed (the recorded seq values repeat, the chain counter does not); a caller that
+ * launches eagerly may simply count seq up and never start a chain.  Same torch call sites: SyncBatchNorm forward / backward
+ * (configs/r*_*.py:9,15; apis/train.py:58-66). */
+int vfs_p2p_chain_start(void* state, vfs_stream_t stream);
+int vfs_bn_act_fin_xchg(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp,
+                        double* sums, float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres,
+                        const float* rbnp, vfs_bf16* y, uint8_t* mask_bits, long long M, int C, int mpg, int relu,
+                        double count, float eps, float momentum, const void* peers, int rank, int world, void* state,
+                        long long spin_limit, int seq, vfs_stream_t stream);
+int vfs_bn_bwd_apply_fin_xchg(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, const float* partial,
+                              int bpg, double* sums, float* dgamma, float* dbeta, vfs_bf16* dx, vfs_bf16* gm, long long M,
+                              int C, int mpg, double count, int relu, const void* peers, int rank, int world, void* state,
+                              long long spin_limit, int seq, vfs_stream_t stream);
 int vfs_p2p_alloc(void** window);
 int vfs_p2p_free(void* window);
 int vfs_p2p_export(void* window, void* handle64);

@@ -158,6 +158,97 @@ def test_reductions_with_exchange_tail_two_threads_emulator(emu_backend, G, bpg,
         lib.p2p_free(w)
 
 
+@pytest.mark.parametrize('world,G,rows,C,ppr', [(2, 2, 6, 128, 32), (3, 2, 16, 256, 128), (2, 1, 33, 64, 16), (2, 2, 3, 32, 64)])
+def test_apply_passes_with_folded_exchange_threads_emulator(emu_backend, world, G, rows, C, ppr):
+    """round 6: vfs_bn_act_fin_xchg / vfs_bn_bwd_apply_fin_xchg - the window exchange folded into the apply pass (the first
+    workgroup of every 64-channel slab exchanges its slab's sums with the peers' workgroups of the same slab, the others wait on a
+    device-scope word).  `world` ranks on host threads, each with its own tensor and statistics rows.  Expected results from the
+    unfolded pieces: the rank's LOCAL sums (vfs_bn_act_fin on its own rows), added over the ranks in rank order, then
+    vfs_bn_act_fin(partial = NULL) / vfs_bn_bwd_apply on those totals with the global count - the folded launch must give the
+    same bits (outputs, bnp, sums, running statistics; backward: dx, gm, sums; dgamma / dbeta stay LOCAL sums).  Three launch
+    pairs with rising sequence numbers (the host numbers the folded exchanges of a chain), then the same numbers again behind a
+    vfs_p2p_chain_start - what a replayed launch chain does."""
+    from tests.emu_util import rb
+    lib = emu_backend.lib
+    wins, mapped = _windows(lib, world)
+    peers = torch.tensor(mapped, dtype=torch.int64)
+    g = torch.Generator().manual_seed(world * 100 + rows * 7 + C)
+    mpg = rows * ppr
+    M = G * mpg
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    xs, parts, ress, gys, bparts = [], [], [], [], []
+    for r in range(world):
+        x = rb(torch.randn(M, C, generator=g) * 1.3 + 0.2 * r)
+        xs.append(x.to(torch.bfloat16))
+        parts.append(torch.stack([x.view(G * rows, ppr, C).sum(1), (x * x).view(G * rows, ppr, C).sum(1)], dim=1).contiguous())
+        ress.append(rb(torch.randn(M, C, generator=g)).to(torch.bfloat16))
+        gys.append(rb(torch.randn(M, C, generator=g)).to(torch.bfloat16))
+        bparts.append((torch.randn(G * rows, 2, C, generator=g) * 3).contiguous())
+    cnt = float(mpg * world)
+    # ---- expected, from the unfolded pieces
+    loc, bloc = [], []
+    for r in range(world):
+        sums, bs = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(G, 2, C, dtype=torch.float64)
+        lib.bn_act_fin(xs[r], parts[r], rows, gamma, beta, torch.zeros(G, 4, C), sums, torch.zeros(C), torch.ones(C), None, None, None,
+                       torch.empty(M, C, dtype=torch.bfloat16), M, C, mpg, 1, float(mpg), 1e-5, 0.1, None)
+        lib.bn_bwd_apply_fin(gys[r], None, xs[r], torch.ones(G, 4, C), bparts[r], rows, bs, torch.zeros(C), torch.zeros(C),
+                             torch.empty(M, C, dtype=torch.bfloat16), None, M, C, mpg, float(mpg), 1, None)
+        loc.append(sums)
+        bloc.append(bs)
+    tot, btot = loc[0].clone(), bloc[0].clone()
+    for r in range(1, world):
+        tot, btot = tot + loc[r], btot + bloc[r]
+    want = []
+    for r in range(world):
+        rm, rv, bnp = torch.full((C,), 0.25), torch.full((C,), 1.5), torch.zeros(G, 4, C)
+        y = torch.empty(M, C, dtype=torch.bfloat16)
+        lib.bn_act_fin(xs[r], None, 0, gamma, beta, bnp, tot.clone(), rm, rv, ress[r], None, None, y, M, C, mpg, 1, cnt, 1e-5, 0.1, None)
+        dx, gm = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+        lib.bn_bwd_apply(gys[r], None, xs[r], bnp, btot, dx, gm, M, C, mpg, cnt, 1, None)
+        want.append((y, bnp, rm, rv, dx, gm))
+    # ---- the folded launches, one thread per rank
+    states = [torch.zeros(4 + 64, dtype=torch.int64) for _ in range(world)]
+    got = [None] * world
+
+    def rank_main(r):
+        for it in range(6):
+            if it == 3:      # a second "chain" with the same sequence numbers, as a replayed launch chain issues them
+                lib.p2p_chain_start(states[r], None)
+            rm, rv, bnp, sums = torch.full((C,), 0.25), torch.full((C,), 1.5), torch.zeros(G, 4, C), torch.zeros(G, 2, C, dtype=torch.float64)
+            y = torch.empty(M, C, dtype=torch.bfloat16)
+            lib.bn_act_fin_xchg(xs[r], parts[r], rows, gamma, beta, bnp, sums, rm, rv, ress[r], None, None, y, None, M, C, mpg, 1, cnt, 1e-5, 0.1,
+                                peers, r, world, states[r], 1 << 40, 2 * (it % 3), None)
+            bs, dg, db = torch.zeros(G, 2, C, dtype=torch.float64), torch.full((C,), 0.5), torch.full((C,), -0.25)
+            dx, gm = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+            lib.bn_bwd_apply_fin_xchg(gys[r], None, xs[r], bnp, bparts[r], rows, bs, dg, db, dx, gm, M, C, mpg, cnt, 1,
+                                      peers, r, world, states[r], 1 << 40, 2 * (it % 3) + 1, None)
+            got[r] = (y, bnp, rm, rv, dx, gm, sums, bs, dg, db)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for r in range(world):
+        y, bnp, rm, rv, dx, gm, sums, bs, dg, db = got[r]
+        wy, wbnp, wrm, wrv, wdx, wgm = want[r]
+        assert torch.equal(sums, tot) and torch.equal(bs, btot), r
+        assert torch.equal(bnp, wbnp) and torch.equal(rm, wrm) and torch.equal(rv, wrv), r
+        assert torch.equal(y.view(torch.int16), wy.view(torch.int16)), r
+        assert torch.equal(dx.view(torch.int16), wdx.view(torch.int16)) and torch.equal(gm.view(torch.int16), wgm.view(torch.int16)), r
+        assert torch.allclose(db.double(), -0.25 + bloc[r][:, 0].sum(0), rtol=1e-6, atol=1e-6)      # local sums
+        assert torch.allclose(dg.double(), 0.5 + bloc[r][:, 1].sum(0), rtol=1e-6, atol=1e-6)
+        assert int(states[r][0]) == 0 and int(states[r][1]) == 0 and int(states[r][3]) == 1      # (the folded exchanges have their own epoch sequence: chain counter, host-assigned numbers)
+    # a lost peer: rank 0 alone, bounded spin -> error word, NaN statistics, no hang
+    lone_state = torch.zeros(4 + 64, dtype=torch.int64)
+    bnp, sums = torch.zeros(G, 4, C), torch.zeros(G, 2, C, dtype=torch.float64)
+    lib.bn_act_fin_xchg(xs[0], parts[0], rows, gamma, beta, bnp, sums, torch.zeros(C), torch.ones(C), None, None, None,
+                        torch.empty(M, C, dtype=torch.bfloat16), None, M, C, mpg, 1, cnt, 1e-5, 0.1, peers, 0, world, lone_state, 200, 9, None)
+    assert int(lone_state[1]) == 1 and torch.isnan(sums).all()
+    for w in wins:
+        lib.p2p_free(w)
+
+
 def test_argument_checks(emu_backend):
     from vfs_amd._lib import VfsError
     lib = emu_backend.lib
@@ -220,7 +311,7 @@ def test_two_processes_one_gpu_train_steps_equal_collective_path(gpu_backend, tm
     """3 data-parallel steps (eager, recorded, replayed) of the shallow R18 on two processes sharing cuda:0: SyncBN statistics through
     the P2P windows vs through gloo all-reduces (gradients through gloo in both) - every parameter, gradient and running statistic
     bit-equal, and the two ranks in lock-step"""
-    p2p = _run_two(tmp_path, 'p2p', 'train', dict(VFS_SYNCBN_P2P='1', VFS_TEST_STEPS='3'))
+    p2p = _run_two(tmp_path, 'p2p', 'train', dict(VFS_SYNCBN_P2P='1', VFS_FIN_XCHG='0', VFS_TEST_STEPS='3'))      # (the exchange as the tail of the reduction launches: the same summation order as the collective path)
     coll = _run_two(tmp_path, 'coll', 'train', dict(VFS_SYNCBN_P2P='0', VFS_TEST_STEPS='3'))
     assert int(p2p[0]['p2p_active']) == 1 and int(coll[0]['p2p_active']) == 0
     assert int(p2p[0]['p2p_exchanges']) > 0
@@ -232,6 +323,32 @@ def test_two_processes_one_gpu_train_steps_equal_collective_path(gpu_backend, tm
         if k.startswith(('param/', 'grad/', 'buf/')):
             assert np.array_equal(p2p[0][k], p2p[1][k]), k
     assert n > 50
+
+
+@pytest.mark.gpu
+def test_two_processes_one_gpu_train_steps_folded_exchange(gpu_backend, tmp_path):
+    """round 6, the default N > 1 path: the window exchange folded into the BatchNorm apply launches (vfs_bn_act_fin_xchg /
+    vfs_bn_bwd_apply_fin_xchg - the slab leads of the two processes exchange their sums, the other workgroups wait on a device-scope
+    word).  3 data-parallel steps (eager, recorded, replayed): the two ranks stay in lock-step BIT FOR BIT (every rank adds the same
+    numbers in the same order), and the run equals the collective-library run up to the summation order of the statistics rows
+    (the apply pass's prologue sums them four rows at a time, the reduction launch eight: fp64 sums of fp32 rows, last-bit
+    differences) - parameters to 1e-5 of their scale after three steps."""
+    fold = _run_two(tmp_path, 'fold', 'train', dict(VFS_SYNCBN_P2P='1', VFS_FIN_XCHG='1', VFS_TEST_STEPS='3'))
+    coll = _run_two(tmp_path, 'coll2', 'train', dict(VFS_SYNCBN_P2P='0', VFS_TEST_STEPS='3'))
+    assert int(fold[0]['p2p_active']) == 1 and int(fold[0]['p2p_exchanges']) > 0
+    assert int(fold[0]['p2p_exchanges']) == int(fold[1]['p2p_exchanges'])
+    n, worst = 0, 0.0
+    for k in coll[0].files:
+        if k.startswith(('param/', 'grad/', 'buf/')):
+            assert np.array_equal(fold[0][k], fold[1][k]), k
+        if k.startswith(('param/', 'buf/')):
+            a, b = fold[0][k].astype(np.float64), coll[0][k].astype(np.float64)
+            worst = max(worst, float(np.abs(a - b).max() / max(1e-12, np.abs(b).max())))
+            n += 1
+    assert n > 50 and worst < 1e-5, worst
+    for k in coll[0].files:
+        if k.startswith('log/'):
+            assert abs(float(fold[0][k]) - float(coll[0][k])) < 1e-5 * max(1.0, abs(float(coll[0][k]))), k
 
 
 @pytest.mark.gpu

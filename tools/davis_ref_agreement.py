@@ -11,10 +11,11 @@ features, value maps) and output are seen.  Per propagated frame f:
                     on the reference's value maps of this step: differences made by THIS step alone
   classification    a label can only flip where the reference's own float64 argmax margin m(p) (top-2 classes of the normalised,
                     upsampled scores) is smaller than what the two runs' soft labels differ by around p: every free-running pixel
-                    mismatch must satisfy  m(p) <= 4 d_in(p) / r_min + 1e-6  (d_in = largest soft-label difference of this frame
-                    between the reference and the oracle's free run over the four feature positions p interpolates; r_min =
-                    smallest max - min of a class channel, the min-max normalisation's divisor) - otherwise it is UNEXPLAINED
-                    (must be 0).  Its cause is then one of
+                    mismatch must satisfy  m(p) <= 4 (d_in(p) + g_in) / r_min + 1e-6  (d_in = largest soft-label difference of this
+                    frame between the reference and the oracle's free run over the four feature positions p interpolates; g_in =
+                    how far the class channels' extremes over the whole map differ between the two runs - the min-max
+                    normalisation couples every pixel to them; r_min = smallest max - min of a class channel, the normalisation's
+                    divisor) - otherwise it is UNEXPLAINED (must be 0).  Its cause is then one of
       topk-tie   p interpolates a query whose teacher-forced output differs by more than QDIFF: the top-10 membership of that query
                  changed in THIS step; every such query's exact (float64, on the reference's features) 10th and 11th affinities
                  lie closer than TOL_AFF (checked for all of them: gaps_over_tol must be 0)
@@ -145,12 +146,20 @@ def main():
             idx = torch.from_numpy(np.nonzero(sel.reshape(-1))[0])
             t2 = up.reshape(CO, -1)[:, idx].topk(2, dim=0)[0]
             margin.reshape(-1)[idx.numpy()] = (t2[0] - t2[1]).numpy()
-        explained = margin <= 4.0 * d_in / r_min + 1e-6
+        # the min-max normalisation couples every pixel to the channel's extremes over the WHOLE map: a soft-label difference at the
+        # pixel that holds a channel's maximum rescales that channel everywhere
+        def extremes(o):
+            u = F.interpolate(torch.from_numpy(np.ascontiguousarray(o.T)).double().reshape(1, CO, h, w), size=(H, W), mode='bilinear', align_corners=False)[0].reshape(CO, -1)
+            return u.min(1)[0], u.max(1)[0]
+        (mnA, mxA), (mnB, mxB), (mnT, mxT) = extremes(oA), extremes(sbankB[f]), extremes(oTF)
+        g_in = float(((mnA - mnB).abs() + (mxA - mxB).abs()).max())
+        g_tf = float(((mnA - mnT).abs() + (mxA - mxT).abs()).max())
+        explained = margin <= 4.0 * (d_in + g_in) / r_min + 1e-6
         c_topk = free & explained & fp
         c_round = free & explained & ~fp & (d_tf >= 0.5 * d_in)
         c_prop = free & explained & ~fp & (d_tf < 0.5 * d_in)
         c_unexpl = free & ~explained
-        tf_unexpl = tf_pix & ~(margin <= 4.0 * d_tf / r_min + 1e-6)      # the same necessary condition for the teacher-forced flips
+        tf_unexpl = tf_pix & ~(margin <= 4.0 * (d_tf + g_tf) / r_min + 1e-6)      # the same necessary condition for the teacher-forced flips
         rows.append(dict(frame=f, keys=Tk, free_mismatch=int(free.sum()), teacher_forced_mismatch=int(tf_pix.sum()),
                          queries_differ=int(qbad.sum()), max_gap_10_11=float(gaps.max()) if gaps.size else 0.0,
                          gaps_over_tol=int((gaps >= TOL_AFF).sum()), postprocess_mismatch=post_diff,

@@ -456,13 +456,36 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
   if (FIN) {
     __shared__ double red[4][2][64], sums_s[2][64];
     __shared__ float coef[2][64];
+    __shared__ double xloc[256];                 // folded exchange: the lead's sums [g][row][channel of the slab]
+    __shared__ int s_failed;
     const int t = threadIdx.x, cslab = a.C < 64 ? a.C : 64;
     const bool lead = blockIdx.x == 0;            // first block of group 0: writes bnp / sums / running statistics
+    const bool xch = f.x.peers != nullptr;        // SyncBN: the slab leads exchange their sums with the peers' leads (vfs_p2p.h)
     const int c = blockIdx.y * cslab + t;
+    P2PSlab sl;
+    sl.slab = blockIdx.y; sl.cslab = cslab; sl.C = a.C;
+    sl.epoch = xch ? p2p_fold_epoch(f.x) : 0ull;
     float rm = 0.f, rv = 0.f;
     if (lead && t < cslab) { rm = f.running_mean ? f.running_mean[c] : 0.f; rv = f.running_var ? f.running_var[c] : 0.f; }
+    if (xch && lead) {                            // local sums of every group -> sums over the ranks
+      for (int g = 0; g < f.G; ++g) {
+        slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+        if (t < cslab) { xloc[(2 * g) * cslab + t] = sums_s[0][t]; xloc[(2 * g + 1) * cslab + t] = sums_s[1][t]; }
+      }
+      __syncthreads();
+      p2p_exchange_slab(xloc, f.G * 2 * cslab, sl, f.x, &s_failed);
+    } else if (xch) {
+      p2p_slab_wait(f.x, sl);                     // the lead of this slab has published the sums over the ranks
+    }
     for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
-      if (f.partial) {
+      if (xch) {
+        __syncthreads();
+        if (t < cslab) {
+          sums_s[0][t] = lead ? xloc[(2 * g) * cslab + t] : vfs_load_agent(f.sums + ((size_t)g * 2 + 0) * a.C + c);
+          sums_s[1][t] = lead ? xloc[(2 * g + 1) * cslab + t] : vfs_load_agent(f.sums + ((size_t)g * 2 + 1) * a.C + c);
+        }
+        __syncthreads();
+      } else if (f.partial) {
         slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
       } else {                                    // SyncBN: f.sums already holds the all-reduced totals
         __syncthreads();
@@ -482,7 +505,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
         if (lead) {
           float* o = f.bnp + (size_t)g * 4 * a.C;
           o[c] = scale; o[a.C + c] = shift; o[2 * a.C + c] = (float)mean; o[3 * a.C + c] = invstd;
-          if (f.partial) {
+          if (xch) {
+            vfs_store_agent(f.sums + ((size_t)g * 2 + 0) * a.C + c, sums_s[0][t]);
+            vfs_store_agent(f.sums + ((size_t)g * 2 + 1) * a.C + c, sums_s[1][t]);
+          } else if (f.partial) {
             f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
             f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
           }
@@ -491,6 +517,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, BnFin f, int p
         }
       }
     }
+    if (xch && lead) p2p_slab_release(f.x, sl);  // the slab's other workgroups may go
     if (lead && t < cslab) {
       if (f.running_mean) f.running_mean[c] = rm;
       if (f.running_var) f.running_var[c] = rv;
@@ -748,20 +775,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
   double s1d[8], s2d[8];
   if (FIN) {
     __shared__ double red[4][2][64], sums_s[2][64], mine[2][64];
+    __shared__ double xloc[256];                 // folded exchange: the lead's sums [g][row][channel of the slab]
+    __shared__ int s_failed;
     const int t = threadIdx.x, cslab = a.C < 64 ? a.C : 64;
     const bool lead = blockIdx.x == 0;            // writes sums, accumulates dgamma / dbeta over the groups
+    const bool xch = f.x.peers != nullptr;        // SyncBN: S1 / S2 over all ranks (vfs_p2p.h); dgamma / dbeta stay LOCAL sums
     const int c = blockIdx.y * cslab + t;
+    P2PSlab sl;
+    sl.slab = blockIdx.y; sl.cslab = cslab; sl.C = a.C;
+    sl.epoch = xch ? p2p_fold_epoch(f.x) : 0ull;
     double g1 = 0.0, g2 = 0.0;
-    for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
-      slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+    if (xch && !lead) {
+      p2p_slab_wait(f.x, sl);
       if (t < cslab) {
-        if (g == s.gi) { mine[0][t] = sums_s[0][t]; mine[1][t] = sums_s[1][t]; }
-        if (lead) {
-          f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
-          f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
-          g1 += sums_s[0][t];
-          g2 += sums_s[1][t];
+        mine[0][t] = vfs_load_agent(f.sums + ((size_t)s.gi * 2 + 0) * a.C + c);
+        mine[1][t] = vfs_load_agent(f.sums + ((size_t)s.gi * 2 + 1) * a.C + c);
+      }
+    } else {
+      for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
+        slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+        if (t < cslab) {
+          if (g == s.gi) { mine[0][t] = sums_s[0][t]; mine[1][t] = sums_s[1][t]; }
+          if (lead) {
+            if (xch) { xloc[(2 * g) * cslab + t] = sums_s[0][t]; xloc[(2 * g + 1) * cslab + t] = sums_s[1][t]; }
+            else {
+              f.sums[((size_t)g * 2 + 0) * a.C + c] = sums_s[0][t];
+              f.sums[((size_t)g * 2 + 1) * a.C + c] = sums_s[1][t];
+            }
+            g1 += sums_s[0][t];
+            g2 += sums_s[1][t];
+          }
         }
+      }
+      if (xch) {                                  // (lead) local sums -> sums over the ranks, published to the slab
+        __syncthreads();
+        p2p_exchange_slab(xloc, f.G * 2 * cslab, sl, f.x, &s_failed);
+        if (t < cslab) {
+          for (int g = 0; g < f.G; ++g) {
+            vfs_store_agent(f.sums + ((size_t)g * 2 + 0) * a.C + c, xloc[(2 * g) * cslab + t]);
+            vfs_store_agent(f.sums + ((size_t)g * 2 + 1) * a.C + c, xloc[(2 * g + 1) * cslab + t]);
+          }
+          mine[0][t] = xloc[(2 * s.gi) * cslab + t];
+          mine[1][t] = xloc[(2 * s.gi + 1) * cslab + t];
+        }
+        p2p_slab_release(f.x, sl);
       }
     }
     if (lead && t < cslab) {
@@ -1055,7 +1112,17 @@ static int fin_check(const BnFin& f, long long M, int mpg, const char* who, bool
   if (!(rows || (sums_ok && !f.partial)) || !f.sums || f.G <= 0 || (long long)f.G * mpg != M) return vfs_set_error(VFS_ERR_ARG, who);
   return VFS_OK;
 }
+// the folded SyncBN exchange (BnFin::x): what the windows and the slab layout can hold
+static int fin_xchg_check(const BnFin& f, int C, const char* who) {
+  if (!f.x.peers) return VFS_OK;
+  const int cslab = C < 64 ? C : 64, slabs = C < 64 ? 1 : C / 64;
+  if (!f.partial || f.G * 2 * cslab > 256 || slabs > P2P_MAXSLAB || f.G * 2 * C > P2P_MAXN || f.x.world < 1 || f.x.world > P2P_MAXW ||
+      f.x.rank < 0 || f.x.rank >= f.x.world || !f.x.state)
+    return vfs_set_error(VFS_ERR_ARG, who);
+  return VFS_OK;
+}
 int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s) {
+  if (fin_xchg_check(f, a.C, "bn_act_fin_xchg: statistics rows, G*2*min(C,64) <= 256, C <= 4096, G*2*C <= 8192, world <= 8, state set")) return VFS_ERR_ARG;
   if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: C must be 8*2^k below 64, a multiple of 64 above");
   if (a.M <= 0) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin: empty");
   if (fin_check(f, a.M, a.mpg, "bn_act_fin: statistics rows / groups", true) || !f.gamma || !f.beta || !f.bnp)
@@ -1092,6 +1159,7 @@ int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
   return vfs_check_launch("bn_bwd_apply");
 }
 int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s) {
+  if (fin_xchg_check(f, a.C, "bn_bwd_apply_fin_xchg: statistics rows, G*2*min(C,64) <= 256, C <= 4096, G*2*C <= 8192, world <= 8, state set")) return VFS_ERR_ARG;
   if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_fin: C must be 8*2^k below 64, a multiple of 64 above");
   if (a.M <= 0) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_fin: empty");
   if (fin_check(f, a.M, a.mpg, "bn_bwd_apply_fin: statistics rows / groups") || !f.dgamma || !f.dbeta)

@@ -352,6 +352,49 @@ int vfs_bn_act_fin_mask(const vfs_bf16* x, const float* partial, int bpg, const 
   f.running_mean = running_mean; f.running_var = running_var; f.count = count; f.eps = eps; f.momentum = momentum;
   return vfs_bn_act_fin_launch(a, f, S(stream));
 }
+static P2PTail make_tail(const void* peers, int rank, int world, void* state, long long spin_limit) {
+  P2PTail x;
+  x.peers = (void* const*)peers; x.rank = rank; x.world = world; x.state = (unsigned long long*)state;
+  x.spin_limit = (unsigned long long)(spin_limit < 1 ? 1 : spin_limit);
+  return x;
+}
+int vfs_bn_act_fin_xchg(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp, double* sums,
+                        float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
+                        uint8_t* mask_bits, long long M, int C, int mpg, int relu, double count, float eps, float momentum,
+                        const void* peers, int rank, int world, void* state, long long spin_limit, int seq, vfs_stream_t stream) {
+  if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "bn_act_fin_xchg: M % mpg");
+  if (seq < 0 || seq >= 4095) return vfs_set_error(VFS_ERR_ARG, "bn_act_fin_xchg: 0 <= seq < 4095");
+  if (!peers || !state || !partial) return vfs_set_error(VFS_ERR_ARG, "bn_act_fin_xchg: statistics rows, peers and state must be given");
+  BnActArgs a;
+  a.x = x; a.bnp = bnp; a.res = res; a.rres = rres; a.rbnp = rbnp; a.y = y; a.M = M; a.C = C; a.mpg = mpg; a.relu = relu;
+  a.mbits = mask_bits;
+  BnFin f;
+  f.partial = partial; f.bpg = bpg; f.G = (int)(M / mpg); f.gamma = gamma; f.beta = beta; f.bnp = bnp; f.sums = sums;
+  f.running_mean = running_mean; f.running_var = running_var; f.count = count; f.eps = eps; f.momentum = momentum;
+  f.x = make_tail(peers, rank, world, state, spin_limit);
+  f.x.seq = seq;
+  return vfs_bn_act_fin_launch(a, f, S(stream));
+}
+int vfs_bn_bwd_apply_fin_xchg(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, const float* partial, int bpg,
+                              double* sums, float* dgamma, float* dbeta, vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg,
+                              double count, int relu, const void* peers, int rank, int world, void* state, long long spin_limit,
+                              int seq, vfs_stream_t stream) {
+  if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_fin_xchg: M % mpg");
+  if (seq < 0 || seq >= 4095) return vfs_set_error(VFS_ERR_ARG, "bn_bwd_apply_fin_xchg: 0 <= seq < 4095");
+  if (!peers || !state || !partial) return vfs_set_error(VFS_ERR_ARG, "bn_bwd_apply_fin_xchg: statistics rows, peers and state must be given");
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.dx = dx; a.gm = gm; a.M = M; a.C = C; a.mpg = mpg; a.count = count; a.relu = relu;
+  BnFin f;
+  f.partial = partial; f.bpg = bpg; f.G = (int)(M / mpg); f.sums = sums; f.dgamma = dgamma; f.dbeta = dbeta;
+  f.x = make_tail(peers, rank, world, state, spin_limit);
+  f.x.seq = seq;
+  return vfs_bn_bwd_apply_fin_launch(a, f, S(stream));
+}
+int vfs_p2p_chain_start(void* state, vfs_stream_t stream) {
+  if (!state) return vfs_set_error(VFS_ERR_ARG, "p2p_chain_start: null state");
+  return vfs_p2p_chain_start_launch((unsigned long long*)state, S(stream));
+}
 int vfs_bn_act_fin(const vfs_bf16* x, const float* partial, int bpg, const float* gamma, const float* beta, float* bnp, double* sums,
                    float* running_mean, float* running_var, const vfs_bf16* res, const vfs_bf16* rres, const float* rbnp, vfs_bf16* y,
                    long long M, int C, int mpg, int relu, double count, float eps, float momentum, vfs_stream_t stream) {
@@ -489,15 +532,6 @@ int vfs_cosine_loss_bwd(const vfs_bf16* p1, const vfs_bf16* z1, const vfs_bf16* 
   return vfs_cosine_loss_bwd_launch(a, S(stream));
 }
 
-static P2PTail make_tail(const void* peers, int rank, int world, void* state, long long spin_limit) {
-  P2PTail x;
-  x.peers = reinterpret_cast<void* const*>(peers);
-  x.state = reinterpret_cast<unsigned long long*>(state);
-  x.spin_limit = (unsigned long long)spin_limit;
-  x.rank = rank;
-  x.world = world;
-  return x;
-}
 int vfs_bn_reduce_partials_xchg(const float* partial, double* sums, double* scratch, int G, int bpg, int C, const void* peers, int rank,
                                 int world, void* state, long long spin_limit, vfs_stream_t stream) {
   if (!partial || !sums || !peers || !state || spin_limit <= 0) return vfs_set_error(VFS_ERR_ARG, "bn_reduce_partials_xchg: bad argument");

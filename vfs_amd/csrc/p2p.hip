@@ -29,6 +29,13 @@ __global__ __launch_bounds__(256) void p2p_allreduce_f64_kernel(double* __restri
   p2p_exchange_body(buf, n, peers, rank, world, state, phase, spin_limit, &failed);
 }
 
+// one launch at the head of every launch chain that contains folded exchanges (vfs_p2p.h): state[3] counts the chains
+__global__ void p2p_chain_start_kernel(unsigned long long* state) { state[3] = state[3] + 1ull; }
+int vfs_p2p_chain_start_launch(unsigned long long* state, hipStream_t s) {
+  hipLaunchKernelGGL(p2p_chain_start_kernel, dim3(1), dim3(1), 0, s, state);
+  return vfs_check_launch("p2p_chain_start");
+}
+
 int vfs_p2p_window_bytes_host(long long* bytes, int* max_doubles, int* max_world) {
   *bytes = (long long)p2p_window_bytes();
   *max_doubles = P2P_MAXN;

@@ -1,6 +1,7 @@
 // Argument structs + host launchers of the element-wise / reduction kernels (bn.hip, misc.hip).
 #pragma once
 #include "vfs_common.h"
+#include "vfs_p2p.h"
 
 // y = [relu]( x*scale + shift  [+ res]  [+ rres*rscale + rshift] )
 struct BnActArgs {
@@ -36,6 +37,10 @@ struct BnFin {
   // backward outputs (accumulated)
   float* dgamma = nullptr;
   float* dbeta = nullptr;
+  // SyncBN, round 6: the window exchange folded into this launch (vfs_p2p.h, "exchange FOLDED"): x.peers set -> `partial` holds the
+  // LOCAL statistics rows, the slab leads exchange their sums, `sums` and every coefficient come from the sums over the ranks and
+  // `count` is the global element count; dgamma / dbeta stay local sums (they travel with the gradient buckets)
+  P2PTail x;
 };
 
 // stem: y = maxpool3x3/s2/p1( relu( x*scale + shift ) ), argmax position (0..8, first maximum in
@@ -99,7 +104,6 @@ int vfs_stem_pool_bn_bwd_reduce_launch(const StemBwdArgs& a, int nblk, hipStream
 int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s);
 int vfs_stem_wgrad_fused_launch(const StemBwdArgs& a, const bf16_t* x4, int Hin, int Win, float* partial, int nblocks,
                                 hipStream_t stream);
-struct P2PTail;      // vfs_p2p.h: the SyncBN window exchange run by the last workgroup of a reduction (nullptr: none)
 int vfs_bn_reduce_partials_launch(const float* partial, double* sums, double* scratch, int G, int bpg, int C, hipStream_t s,
                                   const P2PTail* tail = nullptr);
 int vfs_bn_reduce_fused_launch(int mode, const float* partial, double* sums, double* scratch, int G, int bpg, int C,
@@ -178,6 +182,7 @@ int vfs_p2p_free_host(void* ptr);
 int vfs_p2p_export_host(void* ptr, void* handle64);
 int vfs_p2p_import_host(const void* handle64, void** ptr);
 int vfs_p2p_unimport_host(void* ptr);
+int vfs_p2p_chain_start_launch(unsigned long long* state, hipStream_t s);
 int vfs_p2p_allreduce_f64_launch(double* buf, int n, void* const* peers, int rank, int world, unsigned long long* state, int phase,
                                  unsigned long long spin_limit, hipStream_t s);
 // simloss.hip: CosineSimLoss on spatial inputs (pairwise affinity on the matrix cores, fp32)

@@ -24,6 +24,7 @@ FIN_FUSE = os.environ.get('VFS_FIN_FUSE', '1') == '1'      # BatchNorm statistic
 COARSE_ROWS = int(os.environ.get('VFS_COARSE_ROWS', '0'))      # conv launches sum their statistics rows in groups (vfs_conv_fwd_coarse): 0 off, 1 implicit-GEMM kernels, 2 halo kernels too
 TILES_PER_TICKET = [1 << 16]      # capacity (uint32 words) of the shared ticket buffer
 FIN_MAX_ROWS = int(os.environ.get('VFS_FIN_MAX_ROWS', '128'))   # ... for at most this many statistics rows per group
+FIN_XCHG = os.environ.get('VFS_FIN_XCHG', '0') == '1'      # SyncBN (round 6, opt-in): ... and the window exchange folded into the same launch (vfs_bn_act_fin_xchg / vfs_bn_bwd_apply_fin_xchg) - measured LEVEL with the reduction + exchange launch of rounds 3-5 on one GPU (8.92 vs 8.88 ms), and its waiting workgroups hold their CUs, so the default stays 0
 # timing experiments only: kernel families (Engine.timed labels) whose launches are dropped - results are garbage, the step
 # time shows what the family costs on the critical path (no kernel here has data-dependent control flow)
 MASK_ADD = os.environ.get('VFS_MASK_ADD', '1') == '1'     # with MASK_BITS: the identity-branch gradient g * (y > 0) is applied on the fly (vfs_conv_dgrad_maskadd), never written
@@ -210,6 +211,21 @@ class Engine:
             x.close()
         return self._p2p
 
+    def p2p_chain_start(self, dev):
+        """head of a launch chain (forward / backward of a train step): the folded SyncBN exchanges of the chain are numbered from 0
+        and the chain counter in device memory moves on (vfs_p2p_chain_start; recorded on the tape like any other call)"""
+        self._xseq = 0
+        if not (self.collectives_on and FIN_XCHG and FIN_FUSE):
+            return
+        x = self.p2p_exchange(dev)
+        if x is not None:
+            self.lib.p2p_chain_start(x.state, self.stream(dev))
+
+    def next_xseq(self):
+        n = getattr(self, '_xseq', 0)
+        self._xseq = n + 1
+        return n
+
     def _all_reduce(self, t):
         dist.all_reduce(t, group=self.process_group)
 
@@ -338,14 +354,20 @@ class Engine:
                                               G, mpg, u.cout, float(mpg), float(bn.eps), float(bn.momentum), s)
                 elif self.collectives_on:     # SyncBN: statistics are summed over the ranks between the two stages
                     x = self.p2p_exchange(dev)
-                    if x is not None and x.fits(u.sums):      # rows -> sums -> window exchange, one launch
+                    if (x is not None and x.fits(u.sums) and FIN_XCHG and defer_fin and FIN_FUSE and fused and u.kind != 'stem' and nblk_g <= FIN_MAX_ROWS
+                            and G * 2 * min(u.cout, 64) <= 256 and u.cout <= 4096):
+                        # few rows: the bn_act behind this launch sums them in its prologue AND runs the window exchange there
+                        self._pending_fin = (u, partial, nblk_g, float(mpg * self.world), x)
+                    elif x is not None and x.fits(u.sums):      # rows -> sums -> window exchange, one launch
                         self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_reduce_partials_xchg, partial, u.sums,
                                    self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, *x.tail_args(), s)
                     else:
                         self.timed('bn_stats', (0.0, 8.0 * G * nblk_g * u.cout), dev, lib.bn_reduce_partials, partial, u.sums,
                                    self.bn_scratch(G, u.cout, dev), G, nblk_g, u.cout, s)
                         self.allreduce(u.sums)
-                    if defer_fin and FIN_FUSE and u.kind != 'stem':
+                    if getattr(self, '_pending_fin', None) is not None:
+                        pass
+                    elif defer_fin and FIN_FUSE and u.kind != 'stem':
                         # the bn_act that follows turns the all-reduced sums into scale / shift itself (any size)
                         self._pending_fin = (u, None, 0, float(mpg * self.world))
                     else:
@@ -413,6 +435,11 @@ class Engine:
             assert fin[0] is u, 'deferred BatchNorm finalisation belongs to another unit'
             self._pending_fin = None
             bn = u.bn
+            if len(fin) > 4:      # SyncBN: statistics rows summed AND exchanged with the peers inside this launch
+                self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act_fin_xchg, raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean,
+                           bn.running_var, res, rres, rbnp, y, u.mask_bits, M, u.cout, mpg, 1 if relu else 0, fin[3], float(bn.eps), float(bn.momentum),
+                           *fin[4].tail_args(), self.next_xseq(), self.stream(dev))
+                return y
             self.timed('bn_act', (0.0, nbytes), dev, self.lib.bn_act_fin_mask, raw, fin[1], fin[2], bn.weight.data, bn.bias.data, u.bnp, u.sums, bn.running_mean, bn.running_var,
                                 res, rres, rbnp, y, u.mask_bits, M, u.cout, mpg, 1 if relu else 0, fin[3], float(bn.eps), float(bn.momentum),
                                 self.stream(dev))
@@ -457,6 +484,14 @@ class Engine:
         want_gm = want_gm and not (bits and MASK_ADD and C % 64 == 0)      # (the mask-gated add reads whole 64-channel mask words)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
         abytes = 2.0 * M * C * (3 + want_gm) + mask_bytes      # g, raw in; dx out; activation (or its bit mask) in; masked gradient out
+        if FIN_FUSE and FIN_XCHG and self.collectives_on and nblk // G <= FIN_MAX_ROWS and G * 2 * min(C, 64) <= 256 and C <= 4096:
+            x = self.p2p_exchange(dev)
+            if x is not None and x.fits(u.bsums):
+                # SyncBN, few statistics rows: the apply pass sums them in its prologue, exchanges the sums with the peers there and
+                # writes bsums (over the ranks), dgamma, dbeta (local)
+                self.timed('bn_bwd_apply', (0.0, abytes), dev, lib.bn_bwd_apply_fin_xchg, g, ymask, raw, u.bnp, partial, nblk // G, u.bsums, u.bn.weight.grad, u.bn.bias.grad,
+                           dx, gm, M, C, mpg, float(mpg * self.world), rl, *x.tail_args(), self.next_xseq(), s)
+                return dx, gm
         if FIN_FUSE and not self.collectives_on and nblk // G <= FIN_MAX_ROWS:
             # few statistics rows: the apply pass sums them in its prologue (and writes bsums, dgamma, dbeta)
             self.timed('bn_bwd_apply', (0.0, abytes), dev, lib.bn_bwd_apply_fin, g, ymask, raw, u.bnp, partial, nblk // G, u.bsums, u.bn.weight.grad, u.bn.bias.grad, dx, gm, M, C,

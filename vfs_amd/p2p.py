@@ -62,7 +62,7 @@ class P2PExchange:
             self.close()            # the window and whatever was mapped so far
             raise
         self.peers = torch.tensor(ptrs, dtype=torch.int64, device=dev)
-        self.state = torch.zeros(4, dtype=torch.int64, device=dev)      # {exchange counter, error flag, ticket of the fused reductions, -}
+        self.state = torch.zeros(4 + 64, dtype=torch.int64, device=dev)      # {exchange counter, error flag, workgroup ticket, -, slab_ready[64] of the folded exchanges (vfs_p2p.h)}
 
     def allreduce(self, lib, t, stream):
         """in place: t <- sum over ranks (rank order; bit-identical everywhere).  `lib` = the engine's current library object,

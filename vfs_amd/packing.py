@@ -157,6 +157,12 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=256, halo_geom=None):
     target_blocks = int(os.environ.get('VFS_WGRAD_TBG', target_blocks))
     nkb = (Ktot + 127) // 128
     ncb = Cout // (128 if Cout % 128 == 0 else 64)
+    # round 6 A/B knobs: a target of their own for the layers with few tiles (large maps: the operands dwarf the partials, more
+    # workgroups per CU hide the load latency) and for the layers with many tiles (small maps: the partials rival the operands)
+    if nkb * ncb <= 4 and 'VFS_WGRAD_TBG_SMALL' in os.environ:
+        target_blocks = int(os.environ['VFS_WGRAD_TBG_SMALL'])
+    if nkb * ncb >= 16 and 'VFS_WGRAD_TBG_DEEP' in os.environ:
+        target_blocks = int(os.environ['VFS_WGRAD_TBG_DEEP'])
     # every split writes (and wgrad_reduce re-reads) a full Cout x Ktot fp32 partial: aim for ~2-4
     # workgroups per CU, at least 8 pixel steps (512 pixels) per split, and <= 48 MB of partials
     max_split = max(1, M // 512)

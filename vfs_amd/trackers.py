@@ -455,6 +455,7 @@ class SimSiamBaseTracker(BaseTracker):
         self.backbone.attach(eng)
         self.img_head.attach(eng)
         self._ensure_arena()
+        eng.p2p_chain_start(dev)
         eng.pack_weights()
         B, V, _, T, H, W = imgs.shape
         Nv = B * T
@@ -486,24 +487,34 @@ class SimSiamBaseTracker(BaseTracker):
         dev = p.device
         s = eng.stream(dev)
         dp = eng.buf('img_head.dp', p.shape, BF16, dev)
+        eng.p2p_chain_start(dev)
         gl = gl.contiguous().float()
         eng.lib.cosine_loss_bwd(p[:Nv], z[:Nv], p[Nv:], z[Nv:], gl, dp[:Nv], dp[Nv:], Nv, p.shape[1], c['T'],
                                 c['K'], c['neg'], c['weight'], s)
         # split-K partials of the weight gradients are reduced by one table-driven launch per stage (data parallel: the
         # stage's gradients must be final before their all-reduce) or one for the whole step (single process)
         eng.defer_wgrad = os.environ.get('VFS_WGRAD_BATCH', '0') == '1'
+        # Data parallel: the gradients of a stage are all-reduced as soon as they are final.  Round 6: the buckets are issued FROM THE
+        # SIDE STREAM (the stream the weight gradients run on) - rounds 2-5 joined the side stream into the main chain at every stage
+        # boundary, so the dgrad chain waited five times per step for the weight-gradient stream it is supposed to run ahead of.
+        ddp_side = os.environ.get('VFS_DDP_SIDE', '1') == '1'
+
+        def reduce_now(rng):
+            if not eng.collectives_on:
+                return
+            eng.flush_wgrad(dev)
+            if ddp_side and dev.type == 'cuda' and os.environ.get('VFS_SIDE_STREAM', '1') == '1':
+                with eng.on_side_stream(dev):
+                    self._allreduce_range(rng)
+            else:
+                eng.wgrad_join(dev)
+                self._allreduce_range(rng)
         try:
             gfeat = self.img_head.backward_nhwc(eng, c['hctx'], dp)
-            if eng.collectives_on:
-                eng.flush_wgrad(dev)
-                eng.wgrad_join(dev)
-            self._allreduce_range(self._head_range())
+            reduce_now(self._head_range())
 
             def stage_done(module):      # gradients of `module` are final: reduce them while earlier stages run
-                if eng.collectives_on:
-                    eng.flush_wgrad(dev)
-                    eng.wgrad_join(dev)
-                    self._allreduce_range(self._param_range(module))
+                reduce_now(self._param_range(module))
             self.backbone.backward_nhwc(eng, c['bctx'], {c['last']: gfeat}, on_stage_done=stage_done)
             eng.flush_wgrad(dev)
         finally:
@@ -547,6 +558,7 @@ class SimSiamBaseTracker(BaseTracker):
             return
         lo, hi = rng
         g = self._flat['grads']
+        cur = torch.cuda.current_stream(g.device) if g.device.type == 'cuda' else None      # the stream the buckets are ordered behind
         world = dist.get_world_size()
         step = max(1, self.grad_bucket_bytes // 4)
         bf16 = os.environ.get('VFS_GRAD_BF16', '0') == '1'      # opt-in: bf16 buckets halve the xGMI traffic (the reference reduces fp32)
@@ -557,17 +569,22 @@ class SimSiamBaseTracker(BaseTracker):
             chunk = g[a:b]
             if bf16:
                 eng.lib.f32_to_bf16(chunk, stage[a:b], b - a, 1.0 / world, eng.stream(chunk.device))
-                eng.record(self._issue_allreduce, stage[a:b], dist.ReduceOp.SUM)
+                eng.record(self._issue_allreduce, stage[a:b], dist.ReduceOp.SUM, cur)
                 self._bf16_pending.append((a, b))
                 continue
             if chunk.device.type == 'cuda':
                 eng.lib.scale(chunk, b - a, 1.0 / world, eng.stream(chunk.device))
             else:
                 eng.record(chunk.mul_, 1.0 / world)
-            eng.record(self._issue_allreduce, chunk, dist.ReduceOp.SUM)
+            eng.record(self._issue_allreduce, chunk, dist.ReduceOp.SUM, cur)
 
-    def _issue_allreduce(self, chunk, op):
-        w = dist.all_reduce(chunk, op=op, async_op=True)
+    def _issue_allreduce(self, chunk, op, stream=None):
+        """asynchronous all-reduce behind `stream` (a recorded chain replays this call outside the stream context it was issued in)"""
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                w = dist.all_reduce(chunk, op=op, async_op=True)
+        else:
+            w = dist.all_reduce(chunk, op=op, async_op=True)
         if w is not None:
             self._works.append(w)
 
