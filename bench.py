@@ -675,7 +675,7 @@ def main():
         res['roofline']['kernel_time_over_step'] = sum(v[1] for v in agg.values()) / dt_prof      # > 1: the two streams overlap
         # the same families on the schedule that was TIMED (tape replay, two streams): the committed rocprofv3 --stats summary of
         # this command, when the round has one; `live_over_rocprof` = this run's eager event time / that summary's kernel time
-        rp = rocprof_families(f'bench_{args.model}')
+        rp = rocprof_families(f'bench_{args.model}' + ('' if args.size == 256 else f'_{args.size}'))
         if rp is not None:
             for f, v in rp['families'].items():
                 if f in agg:

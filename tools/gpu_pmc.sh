@@ -1,13 +1,16 @@
 #!/bin/bash
 # HBM traffic of the bench kernels from the L2 memory-side counters (separate passes per guide)
-# usage: tools/gpu_pmc.sh <r18|r50> [davis]   (davis: the fp32 DAVIS workload instead of the train step -> gpurun_out/pmc_davis_<model>.json)
-MODEL=${1:-r18}; WORK=${2:-train}
+# usage: tools/gpu_pmc.sh <r18|r50> [davis|train] [size]   (davis: the fp32 DAVIS workload instead of the train step -> gpurun_out/pmc_davis_<model>.json;
+#        size 512: BASELINE configs[4] -> gpurun_out/pmc_<model>_512.json)
+# Round 6: the train step is profiled on its DEFAULT schedule (command-tape replay, weight gradients on the side stream) - rounds 1-5 forced
+# VFS_GRAPHS=0 VFS_SIDE_STREAM=0.  (rocprofv3 serialises the dispatches while it collects counters, so the bytes per kernel do not depend on it.)
+MODEL=${1:-r18}; WORK=${2:-train}; SIZE=${3:-256}
 if [ "$WORK" = davis ]; then BARGS="--workload davis --precision fp32 --steps 49 --warmup 0 --no-cpu-baseline --no-roofline"; OUT=davis_$MODEL
-else BARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-davis"; OUT=$MODEL; fi
+else BARGS="--steps 3 --warmup 1 --size $SIZE --no-cpu-baseline --no-roofline --no-davis"; OUT=$MODEL; [ "$SIZE" != 256 ] && OUT=${MODEL}_$SIZE; fi
 mkdir -p gpurun_out && cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && VFS_GRAPHS=0 VFS_SIDE_STREAM=0 timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL $BARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o $MODEL -- python $GRAFT_REPO_ROOT/bench.py --model $MODEL $BARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
   echo "$C exit $?"
 done
 cd $GRAFT_REPO_ROOT
