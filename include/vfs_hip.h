@@ -179,6 +179,21 @@ int vfs_bn_bwd_apply_fin(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x
 /* the same result as vfs_bn_stats_finalize, computed from the stored bf16 output raw [G*rows_per_group][C] instead of the conv
  * kernels' 128-pixel statistics rows: for SMALL groups that are not multiples of 128 rows (the head's BN1d layers,
  * sim_siam_head.py:78-111, 32 rows per view on the ResNet-50 config), so that ONE conv launch covers all groups */
+/* Round 6 - nn.Linear + BatchNorm1d (training statistics) + [ReLU] of the SimSiam head in ONE launch (sim_siam_head.py:78-111: the
+ * projector / predictor units Linear -> BN -> ReLU on M = G * mpg <= 64 rows, G <= 4 views, mpg % 8 == 0, K % 128 == 0, C % 16 == 0):
+ * raw = x wf^T + bias (bf16, kept for the backward), statistics of the stored values per view, act = [relu](raw * scale + shift),
+ * bnp / sums / running statistics as vfs_bn_stats_raw_finalize writes them - the same bits as vfs_conv_fwd +
+ * vfs_bn_stats_raw_finalize + vfs_bn_act, two dependent launches less per unit.  Single-GPU path (SyncBN keeps the exchange). */
+int vfs_linear_bn_act(const vfs_bf16* x, const vfs_bf16* wf, const float* bias, const float* gamma, const float* beta,
+                      vfs_bf16* raw, vfs_bf16* act, float* bnp, double* sums, float* running_mean, float* running_var, int M,
+                      int K, int C, int mpg, int relu, double count, float eps, float momentum, vfs_stream_t stream);
+/* Round 6 - vfs_bn_bwd_reduce + vfs_bn_bwd_apply_fin in ONE launch for groups with a single statistics row (mpg | 512, or mpg < 16:
+ * the BatchNorm1d layers of the SimSiam head, sim_siam_head.py:78-111, and tiny maps): the apply pass computes the row {sum g*mask,
+ * sum g*mask*xhat} from (g, x, mask) in its prologue in vfs_bn_bwd_reduce's summation order - the same bits - and writes sums,
+ * dgamma, dbeta, dx (gm) as vfs_bn_bwd_apply_fin does.  torch autograd of batch_norm (+ relu) on a [M][C] tensor. */
+int vfs_bn_bwd_apply_raw(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, double* sums, float* dgamma,
+                         float* dbeta, vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg, double count, int relu,
+                         vfs_stream_t stream);
 int vfs_bn_stats_raw_finalize(const vfs_bf16* raw, double* sums, const float* gamma, const float* beta, float* bnp,
                               float* running_mean, float* running_var, int G, int rows_per_group, int C, double count,
                               float eps, float momentum, vfs_stream_t stream);

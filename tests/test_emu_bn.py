@@ -576,3 +576,87 @@ def test_ticketed_reduction_under_memory_pressure(gpu_backend):
     assert torch.allclose(first, want, rtol=1e-12, atol=1e-9)
     bad = [i for i, o in enumerate(outs) if not torch.equal(o.cpu(), first)]
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize('G,mpg,K,C,relu', [(2, 32, 2048, 64, 1), (2, 32, 512, 2048, 0), (2, 16, 256, 128, 1), (1, 40, 128, 32, 1), (4, 8, 128, 16, 0)])
+def test_linear_bn_act_one_launch_equals_three(backend, G, mpg, K, C, relu):
+    """round 6: vfs_linear_bn_act (nn.Linear + BatchNorm1d + ReLU of the SimSiam head in one launch, sim_siam_head.py:78-111) against the
+    three launches it replaces - vfs_conv_fwd (skinny GEMM), vfs_bn_stats_raw_finalize, vfs_bn_act: raw, act, bnp, sums and the
+    running statistics bit for bit (same GEMM order, statistics of the stored values in the same summation order)"""
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(G * 1000 + mpg * 10 + C)
+    M = G * mpg
+    x = rb(torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = rb(torch.randn(C, K, generator=g) * (1.0 / K) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(C, generator=g) * 0.1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+
+    def three():
+        raw = torch.empty(M, C, dtype=torch.bfloat16)
+        lib.conv_fwd(x.view(M, 1, 1, K), w.view(C, 1, 1, K), raw.view(M, 1, 1, C), bias, None, M, 1, 1, K, 1, 1, C, 1, 1, 1, 0, None)
+        sums, bnp = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(G, 4, C)
+        rm, rv = torch.full((C,), 0.25), torch.full((C,), 1.5)
+        lib.bn_stats_raw_finalize(raw, sums, gamma, beta, bnp, rm, rv, G, mpg, C, float(mpg), 1e-5, 0.1, None)
+        act = torch.empty(M, C, dtype=torch.bfloat16)
+        lib.bn_act(raw, bnp, None, None, None, act, M, C, mpg, relu, None)
+        return raw, act, bnp, sums, rm, rv
+
+    def one():
+        raw, act = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+        sums, bnp = torch.zeros(G, 2, C, dtype=torch.float64), torch.zeros(G, 4, C)
+        rm, rv = torch.full((C,), 0.25), torch.full((C,), 1.5)
+        lib.linear_bn_act(x, w, bias, gamma, beta, raw, act, bnp, sums, rm, rv, M, K, C, mpg, relu, float(mpg), 1e-5, 0.1, None)
+        return raw, act, bnp, sums, rm, rv
+    a, b = three(), one()
+    names = ('raw', 'act', 'bnp', 'sums', 'running_mean', 'running_var')
+    for n, ta, tb in zip(names, a, b):
+        if ta.dtype == torch.bfloat16:
+            assert torch.equal(ta.view(torch.int16), tb.view(torch.int16)), n
+        else:
+            assert torch.equal(ta, tb), n
+    ref = torch.nn.functional.linear(x.float(), w.float(), bias)
+    assert relerr(b[0].float(), ref) < 6e-3
+    with pytest.raises(Exception):
+        lib.linear_bn_act(x, w, bias, gamma, beta, b[0], b[1], b[2], b[3], None, None, M, K, C, mpg + 1, relu, float(mpg), 1e-5, 0.1, None)
+
+
+@pytest.mark.parametrize('G,mpg,C,rl', [(2, 32, 2048, 1), (2, 32, 512, 0), (1, 64, 64, 1), (2, 24, 32, 1), (3, 8, 128, 2), (2, 256, 64, 1)])
+def test_bn_bwd_apply_raw_one_launch_equals_two(backend, G, mpg, C, rl):
+    """round 6: vfs_bn_bwd_apply_raw (groups with ONE statistics row: the SimSiam head's BatchNorm1d layers) against vfs_bn_bwd_reduce +
+    vfs_bn_bwd_apply_fin on the same operands - sums, dgamma, dbeta, dx, gm bit for bit (relu modes: none, recomputed from x, bit mask)"""
+    import math
+    lib = backend.hostlib
+    g = torch.Generator().manual_seed(G * 100 + mpg + C)
+    M = G * mpg
+    x = rb(torch.randn(M, C, generator=g) * 1.3 + 0.2).to(torch.bfloat16)
+    gy = rb(torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    bnp = torch.stack([torch.rand(G, C, generator=g) + 0.5, torch.randn(G, C, generator=g) * 0.4, torch.randn(G, C, generator=g) * 0.2,
+                       torch.rand(G, C, generator=g) + 0.7], 1).contiguous()
+    ym = None
+    if rl == 2:
+        from tests.emu_util import pack_relu_mask
+        ym = pack_relu_mask(torch.randn(M, C, generator=g))
+    ppb = math.gcd(mpg, 512)
+    if ppb < 16:
+        ppb = mpg
+    assert M // ppb == G
+
+    def run(one):
+        bs = torch.zeros(G, 2, C, dtype=torch.float64)
+        dg, db = torch.full((C,), 0.5), torch.full((C,), -0.25)
+        dx, gm = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+        if one:
+            lib.bn_bwd_apply_raw(gy, ym, x, bnp, bs, dg, db, dx, gm, M, C, mpg, float(mpg), rl, None)
+        else:
+            part = torch.zeros(G, 2, C)
+            lib.bn_bwd_reduce(gy, ym, x, bnp, part, M, C, mpg, ppb, rl, None)
+            lib.bn_bwd_apply_fin(gy, ym, x, bnp, part, 1, bs, dg, db, dx, gm, M, C, mpg, float(mpg), rl, None)
+        return bs, dg, db, dx, gm
+    a, b = run(False), run(True)
+    for n, ta, tb in zip(('sums', 'dgamma', 'dbeta', 'dx', 'gm'), a, b):
+        if ta.dtype == torch.bfloat16:
+            assert torch.equal(ta.view(torch.int16), tb.view(torch.int16)), n
+        else:
+            assert torch.equal(ta, tb), n
+    with pytest.raises(Exception):      # three rows per group: not this entry point's shape
+        lib.bn_bwd_apply_raw(gy[:96], None, x[:96], bnp, a[0], a[1], a[2], a[3][:96], None, 96, C, 48, 48.0, 0, None)

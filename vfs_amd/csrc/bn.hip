@@ -71,12 +71,7 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const TIN* __restri
 // window exchange writes into its sums (vfs_p2p.h) - must not reach the running statistics: they outlive the step (checkpoints).
 // (written with explicit fmaf: the compiler contracted `a * b + c * d` differently in different kernels - the fused and the
 // two-launch finalisation must produce the same bits, tests/test_emu_bn.py::test_bn_chunked_single_launch_reduction)
-__device__ __forceinline__ void bn_running_update(float& rm, float& rv, float momentum, double mean, double unbiased) {
-  if (mean != mean || unbiased != unbiased) return;
-  const float keep = 1.f - momentum;
-  rm = __builtin_fmaf(momentum, (float)mean, keep * rm);
-  rv = __builtin_fmaf(momentum, (float)unbiased, keep * rv);
-}
+// (bn_running_update: vfs_ops.h - shared with the fused Linear + BatchNorm1d launch of csrc/conv_pw.hip)
 
 // sums[G][2][C] (sum x, sum x^2; already all-reduced across ranks for SyncBN) + count ->
 // bnp, and the running statistics updated group after group (each group is one BN call of the
@@ -686,16 +681,16 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(PoolBwdArgs a) {
 }
 
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
-  // workgroup = ppb pixels x one slab of <= 64 channels (blockIdx.y): wide layers (C up to 2048 with
-  // few pixels) still fill the chip, and every lane keeps 8-12 independent 16-byte loads in flight
-  __shared__ float red[256][17];
+// One statistics row of the BatchNorm backward: S1 = sum g*mask, S2 = sum g*mask*xhat over the ppb pixels from m0 on, for the <= 64
+// channels of slab blockIdx.y; every thread of the workgroup calls it; the row lands in red and thread (ec, ei) of the
+// first cv * 16 returns ITS element (channel ec * 8 + (ei & 7), statistic ei >> 3) - summed over the row threads in fixed order.
+// Shared by bn_bwd_reduce_kernel (the row goes to HBM) and bn_bwd_apply_kernel<true, true> (round 6: the row never leaves the launch).
+__device__ __forceinline__ float bn_bwd_row(const BnBwdArgs& a, long long m0, int ppb, float (*red)[17], int e) {
   const int cslab = a.C < 64 ? a.C : 64;
   const int cv = cslab >> 3;        // chunk-threads per pixel (<= 8)
   const int rows = 256 / cv;        // pixels processed per step
   const int t = threadIdx.x;
   const int ct = t % cv, rt = t / cv;
-  const long long m0 = (long long)blockIdx.x * a.ppb;
   const int gi = (int)(m0 / a.mpg);
   const int c = blockIdx.y * cslab + ct * 8;
   const bool bits = a.relu == VFS_MASK_BITS;
@@ -708,7 +703,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 2 * a.C + c, mean);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + 3 * a.C + c, inv);
     // four pixel rows per trip: 8-12 independent 16-byte loads in flight per lane
-    for (int r = rt; r < a.ppb; r += 4 * rows) {
+    for (int r = rt; r < ppb; r += 4 * rows) {
       u32x4 gv[4], xv[4];
       unsigned ym[4];
       long long moff[4];
@@ -716,7 +711,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long m = m0 + r + u * rows;
-        ok[u] = (r + u * rows < a.ppb) && (m < a.M);
+        ok[u] = (r + u * rows < ppb) && (m < a.M);
         const size_t o = (size_t)(ok[u] ? m : m0) * a.C + c;
         gv[u] = ld16(a.g + o);
         xv[u] = ld16(a.x + o);
@@ -758,10 +753,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   for (int i = 0; i < 8; ++i) { red[t][i] = s1[i]; red[t][8 + i] = s2[i]; }
   __syncthreads();
   // thread (ct, i16) sums over the row-threads in fixed order
-  for (int e = t; e < cv * 16; e += 256) {
+  float s = 0.f;
+  if (e < cv * 16) {
     const int ec = e / 16, ei = e % 16;
-    float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[r * cv + ec][ei];
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+  // workgroup = ppb pixels x one slab of <= 64 channels (blockIdx.y): wide layers (C up to 2048 with
+  // few pixels) still fill the chip, and every lane keeps 8-12 independent 16-byte loads in flight
+  __shared__ float red[256][17];
+  const int cslab = a.C < 64 ? a.C : 64, cv = cslab >> 3;
+  const int e = threadIdx.x;        // cv * 16 <= 128 result elements: one per thread
+  const float s = bn_bwd_row(a, (long long)blockIdx.x * a.ppb, a.ppb, red, e);
+  if (e < cv * 16) {
+    const int ec = e / 16, ei = e % 16;
     const int ch = blockIdx.y * cslab + ec * 8 + (ei & 7);
     a.partial[(size_t)blockIdx.x * 2 * a.C + (ei >> 3) * a.C + ch] = s;
   }
@@ -769,7 +777,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 
 // pass 2: dx = scale * (gm - S1/count - xhat * S2/count) = A*gm + B*x + D with per-channel
 // A = scale, B = -scale*invstd*m2, D = scale*(mean*invstd*m2 - m1) held in registers
-template <bool FIN>
+// RAW (round 6, with FIN): a group has ONE statistics row (mpg | 512 or mpg < 16: the SimSiam head's BatchNorm1d layers, tiny maps) -
+// the prologue computes it from (g, x, mask) itself, in bn_bwd_reduce_kernel's order (bn_bwd_row: the same bits), so that the
+// reduction launch in front of the apply pass disappears.
+template <bool FIN, bool RAW = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f, int ppb) {
   const SlabGeom s = slab_geom(a.M, a.C, a.mpg, ppb, FIN ? 0 : a.wide);
   double s1d[8], s2d[8];
@@ -793,7 +804,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, BnFin f,
       }
     } else {
       for (int g = lead ? 0 : s.gi; g < (lead ? f.G : s.gi + 1); ++g) {
-        slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+        if constexpr (RAW) {
+          __shared__ float rawred[256][17];
+          __syncthreads();               // previous users of sums_s / rawred are done
+          const float v = bn_bwd_row(a, (long long)g * a.mpg, a.mpg, rawred, t);
+          if (t < (cslab >> 3) * 16) sums_s[(t % 16) >> 3][(t / 16) * 8 + (t & 7)] = (double)v;      // the one row of the group, as the rows path would read it back
+          __syncthreads();
+        } else {
+          slab_rows_reduce(f, g, a.C, cslab, red, sums_s);
+        }
         if (t < cslab) {
           if (g == s.gi) { mine[0][t] = sums_s[0][t]; mine[1][t] = sums_s[1][t]; }
           if (lead) {
@@ -1157,6 +1176,16 @@ int vfs_bn_bwd_apply_launch(const BnBwdArgs& a, hipStream_t s) {
   const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb, aw.wide);
   hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, aw, BnFin{}, ppb);
   return vfs_check_launch("bn_bwd_apply");
+}
+// the apply pass that computes its single statistics row per group itself (bn_bwd_apply_kernel<true, true>)
+int vfs_bn_bwd_apply_raw_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s) {
+  if (!slab_ok(a.C)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_raw: C must be 8*2^k below 64, a multiple of 64 above");
+  if (a.M <= 0 || a.mpg <= 0 || a.M % a.mpg || a.mpg > 512 || f.G != (int)(a.M / a.mpg) || !f.sums || !f.dgamma || !f.dbeta || f.x.peers)
+    return vfs_set_error(VFS_ERR_ARG, "bn_bwd_apply_raw: groups of at most 512 rows that tile M, sums / dgamma / dbeta given, no exchange");
+  int ppb;
+  const dim3 grid = slab_grid(a.M, a.C, a.mpg, &ppb);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, s, a, f, ppb);
+  return vfs_check_launch("bn_bwd_apply_raw");
 }
 int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s) {
   if (fin_xchg_check(f, a.C, "bn_bwd_apply_fin_xchg: statistics rows, G*2*min(C,64) <= 256, C <= 4096, G*2*C <= 8192, world <= 8, state set")) return VFS_ERR_ARG;

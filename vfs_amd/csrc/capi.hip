@@ -319,6 +319,17 @@ int vfs_bn_stats_raw_finalize(const vfs_bf16* raw, double* sums, const float* ga
   return vfs_bn_stats_raw_launch(raw, sums, G, rows_per_group, C, gamma, beta, bnp, running_mean, running_var, count, eps, momentum,
                                  S(stream));
 }
+int vfs_linear_bn_act(const vfs_bf16* x, const vfs_bf16* wf, const float* bias, const float* gamma, const float* beta, vfs_bf16* raw,
+                      vfs_bf16* act, float* bnp, double* sums, float* running_mean, float* running_var, int M, int K, int C, int mpg,
+                      int relu, double count, float eps, float momentum, vfs_stream_t stream) {
+  if (!x || !wf || !gamma || !beta || !raw || !act || !bnp || !sums) return vfs_set_error(VFS_ERR_ARG, "linear_bn_act: null buffer");
+  if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "linear_bn_act: M % mpg");
+  LinBnArgs a;
+  a.x = x; a.w = wf; a.bias = bias; a.gamma = gamma; a.beta = beta; a.raw = raw; a.act = act; a.bnp = bnp; a.sums = sums;
+  a.rm = running_mean; a.rv = running_var; a.M = M; a.K = K; a.C = C; a.G = M / mpg; a.mpg = mpg; a.relu = relu; a.count = count;
+  a.eps = eps; a.momentum = momentum;
+  return vfs_linear_bn_act_launch(a, S(stream));
+}
 int vfs_bn_bwd_sums_paramgrad(const float* partial, double* sums, double* scratch, float* dgamma, float* dbeta, int G, int bpg,
                               int C, vfs_stream_t stream) {
   return vfs_bn_reduce_fused_launch(1, partial, sums, scratch, G, bpg, C, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.f, 0.f,
@@ -439,6 +450,21 @@ int vfs_bn_bwd_apply_fin(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x
   BnFin f;
   f.partial = partial; f.bpg = bpg; f.G = (int)(M / mpg); f.sums = sums; f.dgamma = dgamma; f.dbeta = dbeta;
   return vfs_bn_bwd_apply_fin_launch(a, f, S(stream));
+}
+int vfs_bn_bwd_apply_raw(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x, const float* bnp, double* sums, float* dgamma,
+                         float* dbeta, vfs_bf16* dx, vfs_bf16* gm, long long M, int C, int mpg, double count, int relu,
+                         vfs_stream_t stream) {
+  if (mpg <= 0 || M % mpg) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_raw: M % mpg");
+  int gcd = mpg, r = 512;      // ONE statistics row per group: the shapes the two-launch form serves with ppb == mpg (gcd(mpg, 512) == mpg or < 16)
+  while (r) { const int q = gcd % r; gcd = r; r = q; }
+  if (mpg > 512 || !(gcd == mpg || gcd < 16)) return vfs_set_error(VFS_ERR_SHAPE, "bn_bwd_apply_raw: one statistics row per group (mpg <= 512 and gcd(mpg, 512) == mpg or < 16)");
+  const int ppb = mpg;
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.y = y; a.x = x; a.bnp = bnp; a.dx = dx; a.gm = gm; a.M = M; a.C = C; a.mpg = mpg; a.ppb = ppb; a.count = count; a.relu = relu;
+  BnFin f;
+  f.partial = nullptr; f.bpg = 1; f.G = (int)(M / mpg); f.sums = sums; f.dgamma = dgamma; f.dbeta = dbeta;
+  return vfs_bn_bwd_apply_raw_launch(a, f, S(stream));
 }
 int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const uint8_t* idx, const vfs_bf16* x, const vfs_bf16* xpool,
                                 const float* bnp, float* partial, int N, int H, int W, int C, int Hp, int Wp, int npg, int ppb,

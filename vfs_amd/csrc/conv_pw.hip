@@ -19,6 +19,7 @@
 // Every wave of the workgroup executes the SAME number of s_barrier: one per K-step (B: stage landed / previous stage free), one
 // after a tile's last K-step (T: the last stage is free) and the epilogue's own (the loaders mirror them).
 #include "vfs_igemm_epi.h"
+#include "vfs_ops.h"
 
 int vfs_option_igemm_pw = 0;          // 0: off (default: measured slower than the one-tile kernels, MEASUREMENTS.md round 5); 1: where the plan below says so; 2: every eligible 1x1
 int vfs_option_igemm_pw_min_tiles = 192;   // fewer 128-pixel tiles than this leave CUs idle: the split-channel kernels take over
@@ -240,6 +241,132 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(ConvArgs a) {
       st8(a.out + (size_t)m * C + c, pk);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: nn.Linear + BatchNorm1d (training statistics) + ReLU of the SimSiam head in ONE launch (sim_siam_head.py:78-111: the
+// projector's Linear -> BN -> ReLU units and the predictor's first one) for the single-GPU step.  The head works on M = G x mpg <= 64
+// rows (two views of 32 videos on the ResNet-50 config): conv_skinny + bn_stats_raw + bn_act were three dependent launches of 4-6 us
+// each for a few KB.  A workgroup owns 16 output channels x ALL rows, so the batch statistics of its channels are local to it: the
+// GEMM as in conv_skinny_kernel (four waves = four K quarters, fragments straight from global memory, four 16-row tiles per wave),
+// then the statistics over the STORED (bf16) values in bn_stats_raw_kernel's summation order (eight row lanes in double, added in
+// lane order - the same bits), scale / shift, running statistics group after group, and y = relu(q * scale + shift) exactly as
+// bn_act_kernel computes it.  Outputs: raw (the backward needs it), act, bnp, sums, running statistics.
+#define LINBN_MAXG 4
+__global__ __launch_bounds__(256) void linear_bn_act_kernel(LinBnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sAcc[4][4][64][4];
+  __shared__ float sRaw[64][16];
+  __shared__ double sh[8][2][16];
+  __shared__ float sCoef[LINBN_MAXG][2][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int M = a.M, K = a.K, C = a.C;
+  const int c0 = blockIdx.x * 16;
+  const int kq = K >> 2;                                  // K % 128 == 0: whole 32-deep steps per wave
+  const bf16_t* wrow = a.w + (size_t)(c0 + lr) * K + wave * kq + lq * 8;
+  const bf16_t* xr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = a.x + (size_t)min(16 * i + lr, M - 1) * K + wave * kq + lq * 8;      // rows past M: clamped, never stored
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int steps = kq >> 5;
+#pragma unroll 2
+  for (int s = 0; s < steps; ++s) {
+    const bf16x8 af = *reinterpret_cast<const bf16x8*>(wrow + s * 32);
+    bf16x8 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(xr[i] + s * 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[i], acc[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&sAcc[wave][i][lane][0]) = acc[i];
+  __syncthreads();
+  // wave w finishes row tile w: lane = (channel quad lq, row lr); the K quarters add up in wave order (as conv_skinny_kernel)
+  const int m = 16 * wave + lr, cq = lq * 4;
+  {
+    f32x4 v = *reinterpret_cast<const f32x4*>(&sAcc[0][wave][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&sAcc[w][wave][lane][0]);
+    if (m < M) {
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += a.bias[c0 + cq + r];
+      }
+      u32x2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      st8(a.raw + (size_t)m * C + c0 + cq, pk);
+      sRaw[m][cq] = bflo(pk.x); sRaw[m][cq + 1] = bfhi(pk.x); sRaw[m][cq + 2] = bflo(pk.y); sRaw[m][cq + 3] = bfhi(pk.y);
+    }
+  }
+  __syncthreads();
+  // statistics of the stored values, group after group (bn_stats_raw_kernel: eight row lanes, double, lane order)
+  const int cl = t & 15, sl = (t >> 4) & 7;
+  const bool stat_thread = t < 128;
+  const int c = c0 + cl;
+  float rm = 0.f, rv = 0.f;
+  if (stat_thread && sl == 0) { rm = a.rm ? a.rm[c] : 0.f; rv = a.rv ? a.rv[c] : 0.f; }
+  for (int gi = 0; gi < a.G; ++gi) {
+    double a0 = 0.0, a1 = 0.0;
+    if (stat_thread) {
+      for (int b = sl; b < a.mpg; b += 8) {
+        const double v = (double)sRaw[gi * a.mpg + b][cl];
+        a0 += v;
+        a1 += v * v;
+      }
+    }
+    __syncthreads();
+    if (stat_thread) { sh[sl][0][cl] = a0; sh[sl][1][cl] = a1; }
+    __syncthreads();
+    if (stat_thread && sl == 0) {
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0 += sh[k][0][cl]; r1 += sh[k][1][cl]; }
+      a.sums[((size_t)gi * 2 + 0) * C + c] = r0;
+      a.sums[((size_t)gi * 2 + 1) * C + c] = r1;
+      const double mean = r0 / a.count;
+      double var = r1 / a.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float scale = a.gamma[c] * invstd;
+      const float shift = a.beta[c] - (float)mean * scale;
+      float* o = a.bnp + (size_t)gi * 4 * C;
+      o[c] = scale;
+      o[C + c] = shift;
+      o[2 * C + c] = (float)mean;
+      o[3 * C + c] = invstd;
+      sCoef[gi][0][cl] = scale;
+      sCoef[gi][1][cl] = shift;
+      const double unbiased = a.count > 1.0 ? var * (a.count / (a.count - 1.0)) : var;
+      bn_running_update(rm, rv, a.momentum, mean, unbiased);
+    }
+  }
+  if (stat_thread && sl == 0) {
+    if (a.rm) a.rm[c] = rm;
+    if (a.rv) a.rv[c] = rv;
+  }
+  __syncthreads();
+  if (m < M) {      // y = [relu](q * scale + shift) on the stored values, as bn_act_kernel
+    const int gi = m / a.mpg;
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      y[r] = sRaw[m][cq + r] * sCoef[gi][0][cq + r] + sCoef[gi][1][cq + r];
+      if (a.relu) y[r] = fmaxf(y[r], 0.f);
+    }
+    u32x2 pk;
+    pk.x = pack2bf(y[0], y[1]);
+    pk.y = pack2bf(y[2], y[3]);
+    st8(a.act + (size_t)m * C + c0 + cq, pk);
+  }
+}
+int vfs_linear_bn_act_launch(const LinBnArgs& a, hipStream_t stream) {
+  if (a.M < 1 || a.M > 64 || a.G < 1 || a.G > LINBN_MAXG || a.mpg * a.G != a.M || a.K % 128 || a.C % 16)
+    return vfs_set_error(VFS_ERR_SHAPE, "linear_bn_act: M = G * mpg <= 64 rows, G <= 4, K % 128 == 0, C % 16 == 0");
+  hipLaunchKernelGGL(linear_bn_act_kernel, dim3(a.C / 16), dim3(256), 0, stream, a);
+  return vfs_check_launch("linear_bn_act");
 }
 
 bool vfs_conv_skinny_eligible(const ConvArgs& a, int mode) {

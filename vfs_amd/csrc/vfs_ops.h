@@ -17,6 +17,15 @@ struct BnActArgs {
   int wide = 0;         // plain (non-FIN) launch: whole pixel rows per workgroup (set by the launcher, bn.hip slab_geom)
 };
 
+// running = (1 - momentum) * running + momentum * statistic; a NaN statistic (the poison of a failed SyncBN exchange) is kept out
+__device__ __forceinline__ void bn_running_update(float& rm, float& rv, float momentum, double mean, double unbiased) {
+  if (mean != mean || unbiased != unbiased) return;
+  const float keep = 1.f - momentum;
+  rm = __builtin_fmaf(momentum, (float)mean, keep * rm);
+  rv = __builtin_fmaf(momentum, (float)unbiased, keep * rv);
+}
+
+
 // Optional in-kernel statistics finalisation for the apply passes (bn_act / bn_bwd_apply, SMALL row counts): the
 // workgroup reduces the partial rows of its own (group, channel slab) in its prologue - every workgroup gets the same
 // coefficients, in the same summation order - instead of waiting for a separate 6-us launch between the conv and the
@@ -182,6 +191,24 @@ int vfs_p2p_free_host(void* ptr);
 int vfs_p2p_export_host(void* ptr, void* handle64);
 int vfs_p2p_import_host(const void* handle64, void** ptr);
 int vfs_p2p_unimport_host(void* ptr);
+// nn.Linear + BatchNorm1d + ReLU in one launch (conv_pw.hip: linear_bn_act_kernel)
+struct LinBnArgs {
+  const bf16_t* x;      // [M][K]
+  const bf16_t* w;      // [C][K]
+  const float* bias;    // [C] or null
+  const float* gamma;
+  const float* beta;
+  bf16_t* raw;          // [M][C]
+  bf16_t* act;          // [M][C]
+  float* bnp;           // [G][4][C]
+  double* sums;         // [G][2][C]
+  float* rm;
+  float* rv;
+  int M, K, C, G, mpg, relu;
+  double count;
+  float eps, momentum;
+};
+int vfs_linear_bn_act_launch(const LinBnArgs& a, hipStream_t stream);      // conv_pw.hip
 int vfs_p2p_chain_start_launch(unsigned long long* state, hipStream_t s);
 int vfs_p2p_allreduce_f64_launch(double* buf, int n, void* const* peers, int rank, int world, unsigned long long* state, int phase,
                                  unsigned long long spin_limit, hipStream_t s);
@@ -209,6 +236,7 @@ int vfs_adam_launch(float* p, const float* g, float* m, float* v, long long n, f
                     hipStream_t s);
 int vfs_cosine_loss_fwd_launch(const LossArgs& a, hipStream_t s);
 int vfs_bn_act_fin_launch(const BnActArgs& a, const BnFin& f, hipStream_t s);
+int vfs_bn_bwd_apply_raw_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s);
 int vfs_bn_bwd_apply_fin_launch(const BnBwdArgs& a, const BnFin& f, hipStream_t s);
 int vfs_loss_means_launch(const float* loss, float* means, int K, int N, hipStream_t s);
 int vfs_cosine_loss_bwd_launch(const LossArgs& a, hipStream_t s);

@@ -290,6 +290,10 @@ class Engine:
         # config: 32 rows per view): ONE launch without statistics rows, the sums come from the stored output
         raw_stats = (want_stats and not fused and not self.collectives_on and mpg <= 2048
                      and os.environ.get('VFS_RAW_STATS', '1') == '1')
+        # round 6: Linear + BatchNorm1d + ReLU of the head in ONE launch (vfs_linear_bn_act: the workgroup that owns 16 output channels
+        # owns all <= 64 rows, so the batch statistics are local to it) instead of conv + statistics + apply
+        lin_fused = (raw_stats and u.kind == 'linear' and defer_fin and M <= 64 and G <= 4 and u.cin % 128 == 0 and u.cout % 16 == 0
+                     and os.environ.get('VFS_HEAD_FUSE', '1') == '1')
         if raw_stats:
             fused, want_rows = True, False
         else:
@@ -309,6 +313,17 @@ class Engine:
         bias = u.bias.data if u.bias is not None else None
         groups = [(0, N, partial)] if fused else [
             (g * Ng, Ng, partial[g * nblk_g * 2 * u.cout:] if want_rows else None) for g in range(G)]
+        if lin_fused:
+            bn = u.bn
+            u.sums = self.buf(f'{u.name}.sums', (G, 2, u.cout), torch.float64, dev)
+            u.bnp = self.buf(f'{u.name}.bnp', (G, 4, u.cout), torch.float32, dev)
+            act = self.buf(f'{u.name}{tag}.act', (N, u.cout), BF16, dev)      # (the shape bn_act gives the head: raw.view(N, cout))
+            self.timed('conv_igemm', (2.0 * M * u.cout * u.cin, 2.0 * (M * u.cin + 2 * M * u.cout + u.cout * u.cin)), dev, lib.linear_bn_act,
+                       x, u.wf, bias, bn.weight.data, bn.bias.data, y, act, u.bnp, u.sums, bn.running_mean, bn.running_var, M, u.cin, u.cout, mpg,
+                       1 if getattr(u, 'relu', False) else 0, float(mpg), float(bn.eps), float(bn.momentum), s)
+            u.nbt_pending = getattr(u, 'nbt_pending', 0) + G
+            self._fused_act = (u, act)      # the bn_act call that follows hands this tensor out
+            return y, Ho, Wo
         for n0, nn_, part in groups:
             if u.kind == 'stem':
                 self.timed('stem_fwd', (2.0 * nn_ * Ho * Wo * 64 * 147, 2.0 * nn_ * (H * W * 4 + Ho * Wo * 64)), dev, lib.stem_fwd,
@@ -426,6 +441,12 @@ class Engine:
         """y = [relu](bn(raw) [+ res] [+ bn(rres)]).  want_mask (the join of a residual block, training): also write the
         bit-packed mask y > 0 (uint8 [M][C/8], left in u.mask_bits) - the unit's BatchNorm backward reads it instead of y"""
         dev = raw.device
+        fa = getattr(self, '_fused_act', None)
+        if fa is not None:      # Linear + BatchNorm1d + ReLU ran as one launch (conv_fwd, lin_fused)
+            self._fused_act = None
+            assert fa[0] is u and res is None and rres is None and not want_mask and bool(relu) == bool(getattr(u, 'relu', False))
+            u.mask_bits = None
+            return fa[1]
         y = self.buf(f'{u.name}{tag}.act', raw.shape, BF16, dev)
         u.mask_bits = self.buf(f'{u.name}{tag}.mbits', (M * u.cout // 8,), torch.uint8, dev) if (want_mask and MASK_BITS and u.cout % 8 == 0 and (u.cout < 64 or u.cout % 64 == 0)) else None      # slab-major layout (mask8_index): whole 64-channel slabs
         mpg = M // G if train else M
@@ -473,8 +494,11 @@ class Engine:
         mask_bytes = 0.0 if ymask is None else (M * C / 8.0 if bits else 2.0 * M * C)
         fused = getattr(self, '_fused_bn', None)
         self._fused_bn = None
+        raw_row = False
         if fused is not None and fused[0] is u:     # the producing dgrad already emitted the statistics rows
             partial, nblk = fused[1], fused[2]
+        elif (FIN_FUSE and not self.collectives_on and nblk == G and mpg <= 512 and os.environ.get('VFS_HEAD_FUSE', '1') == '1'):
+            raw_row = True      # round 6: one statistics row per group (the head's BatchNorm1d layers): the apply pass computes it itself
         else:
             self.timed('bn_bwd_reduce', (0.0, 2.0 * M * C * 2 + mask_bytes), dev, lib.bn_bwd_reduce, g, ymask, raw, u.bnp,
                        partial, M, C, mpg, ppb, rl, s)
@@ -484,6 +508,10 @@ class Engine:
         want_gm = want_gm and not (bits and MASK_ADD and C % 64 == 0)      # (the mask-gated add reads whole 64-channel mask words)
         gm = self.buf(f'{u.name}.gm', raw.shape, BF16, dev) if want_gm else None
         abytes = 2.0 * M * C * (3 + want_gm) + mask_bytes      # g, raw in; dx out; activation (or its bit mask) in; masked gradient out
+        if raw_row:
+            self.timed('bn_bwd_apply', (0.0, abytes + 2.0 * M * C * 2 + mask_bytes), dev, lib.bn_bwd_apply_raw, g, ymask, raw, u.bnp, u.bsums, u.bn.weight.grad, u.bn.bias.grad,
+                       dx, gm, M, C, mpg, float(mpg), rl, s)
+            return dx, gm
         if FIN_FUSE and FIN_XCHG and self.collectives_on and nblk // G <= FIN_MAX_ROWS and G * 2 * min(C, 64) <= 256 and C <= 4096:
             x = self.p2p_exchange(dev)
             if x is not None and x.fits(u.bsums):
