@@ -32,7 +32,6 @@ int vfs_option_stem_blocks = 0;
 extern int vfs_option_bn_ticket, vfs_option_bn_chunk_rows, vfs_option_bn_wide, vfs_option_bn_wide_min_mb;
 int vfs_option_stem_direct = 1;
 extern int vfs_option_igemm_xcd, vfs_option_igemm_narrow_below;
-int vfs_option_wgrad_inl_same_xcd = 0;      // EXPERIMENT (vfs_conv.h WgradArgs::inl_same_xcd)
 extern int vfs_option_igemm_ring_mfma32, vfs_option_igemm_ring_gather, vfs_option_igemm_bc, vfs_option_igemm_onek, vfs_option_igemm_ring_tiles, vfs_option_igemm_ring_upfront, vfs_option_igemm_ring_fbn, vfs_option_wgrad_lin, vfs_option_wgrad_lin2, vfs_option_wgrad_ring, vfs_option_wgrad_xcd, vfs_option_halo_xcd, vfs_option_igemm_mfma_stats, vfs_option_lpx_target, vfs_option_lpx_wgs, vfs_option_lpx_minb, vfs_option_lp2, vfs_option_lp2_fpb, vfs_option_lp2_cap, vfs_option_lp2_xcd, vfs_option_lp2_trim, vfs_option_lp2_dbg, vfs_option_conv_f32_variant, vfs_option_conv_f32_dbg;
 
 static ConvGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad, int Ktot) {
@@ -75,7 +74,6 @@ int vfs_set_option(const char* name, int value) {
   if (!strcmp(name, "igemm_mfma_stats")) { vfs_option_igemm_mfma_stats = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin2")) { vfs_option_wgrad_lin2 = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_ring")) { vfs_option_wgrad_ring = value; return VFS_OK; }
-  if (!strcmp(name, "wgrad_inl_same_xcd")) { vfs_option_wgrad_inl_same_xcd = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_lin")) { vfs_option_wgrad_lin = value; return VFS_OK; }
   if (!strcmp(name, "wgrad_xcd")) { vfs_option_wgrad_xcd = value; return VFS_OK; }
   if (!strcmp(name, "halo_deep_max")) { vfs_option_halo_deep_max = value; return VFS_OK; }
@@ -276,7 +274,6 @@ int vfs_conv_wgrad_inl(const vfs_bf16* dy, const vfs_bf16* x, const float* in_bn
   a.dy = dy; a.x = x; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
   a.in_bnp = in_bnp; a.in_npg = in_bnp ? in_npg : 0;
   a.grad = grad; a.tickets = tickets;
-  a.inl_same_xcd = vfs_option_wgrad_inl_same_xcd;
   if (vfs_option_halo && vfs_wgrad_halo_eligible(a, GATHER_FWD) && !(in_bnp && vfs_small_map(H, W) && in_npg % 2))
     return vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);
   if (in_bnp) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_inl: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");

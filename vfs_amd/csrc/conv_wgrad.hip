@@ -311,20 +311,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ring_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int nkb = g.Ktot >> 7, ncb = a.Cout >> 7;
   int b = blockIdx.x;
-  int kb, cb, split;
-  if (a.inl_same_xcd) {      // experiment: every split of a tile on the XCD that owns the tile
-    int tile;
-    wgt_same_xcd_map(b, a.nsplit, tile, split);
-    kb = tile % nkb; cb = tile / nkb;
-  } else {
-    if (a.xcd_swizzle) {
-      const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7;
-      b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
-    kb = b % nkb; b /= nkb;
-    cb = b % ncb; b /= ncb;
-    split = b;
+  if (a.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  const int kb = b % nkb; b /= nkb;
+  const int cb = b % ncb; b /= ncb;
+  const int split = b;
   const int pix_begin = split * a.pix_per_split;
   const int iters = a.pix_per_split >> 6;
 
@@ -418,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ring_kernel(WgradArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         wgt_store_piece(prs, wgt_piece_off(split, tile, ntiles, 16, (tn * 2 + tm) * 4 + q),
-                        (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]}, a.inl_same_xcd);
+                        (f32x4){acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]});
   if (!wgt_last_arriver(a, tile)) return;
   const unsigned sstride = (unsigned)((size_t)ntiles * 16 * 4096);
 #pragma unroll 1
@@ -443,7 +436,6 @@ int vfs_option_wgrad_lin = 1;   // the linear-address path for 1x1 / stride-1 pr
 template <int BCW, int MODE, int LIN = 0>
 static int launch_wgrad(const WgradArgs& a0, hipStream_t stream) {
   WgradArgs a = a0;
-  a.inl_same_xcd = 0;      // (the experiment covers the ring and the 3x3 halo kernel only)
   int nkb = (a.g.Ktot + 127) / 128;
   int ncb = a.Cout / BCW;
   a.xcd_swizzle = vfs_option_wgrad_xcd && nkb * ncb > 1 && nkb * ncb * a.nsplit >= 16;
@@ -467,7 +459,6 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
     WgradArgs b = a;
     const int tiles = (a.g.Ktot >> 7) * (a.Cout >> 7);
     b.xcd_swizzle = vfs_option_wgrad_xcd && tiles > 1 && tiles * a.nsplit >= 16;
-    if (b.inl_same_xcd && (!b.tickets || tiles % 8)) b.inl_same_xcd = 0;
     hipLaunchKernelGGL(conv_wgrad_ring_kernel, dim3(tiles * a.nsplit), dim3(256), 0, stream, b);
     return vfs_check_launch("conv_wgrad_ring");
   }

@@ -60,16 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7;
     b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  int cc, cb, split;
-  if (a.inl_same_xcd) {      // experiment (vfs_conv.h): every split of a tile on the XCD that owns the tile
-    int tile;
-    wgt_same_xcd_map(blockIdx.x, a.nsplit, tile, split);
-    cc = tile % nchunk; cb = tile / nchunk;
-  } else {
-    cc = b % nchunk; b /= nchunk;
-    cb = b % ncb; b /= ncb;
-    split = b;
-  }
+  const int cc = b % nchunk; b /= nchunk;
+  const int cb = b % ncb; b /= ncb;
+  const int split = b;
   const int j = t & 7, row0 = t >> 3;
   const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;   // ragged edge tiles: their dY rows load as zero
 
@@ -228,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(WgradArgs a,
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) wgt_store_piece(prs, wgt_piece_off(split, tile, nwt, 36, tp * 4 + tn * 2 + tm), acc[tp][tm][tn], a.inl_same_xcd);
+      for (int tm = 0; tm < 2; ++tm) wgt_store_piece(prs, wgt_piece_off(split, tile, nwt, 36, tp * 4 + tn * 2 + tm), acc[tp][tm][tn]);
   if (!wgt_last_arriver(a, tile)) return;
   const unsigned sstride = (unsigned)((size_t)nwt * 36 * 4096);
 #pragma unroll 1
@@ -271,7 +264,6 @@ int vfs_wgrad_halo_dispatch(const WgradArgs& a, hipStream_t stream, int* eff_nsp
   const int blocks = (a.g.C >> 6) * (a.Cout >> 6) * b.nsplit;
   b.xcd_swizzle = vfs_option_wgrad_xcd && (a.g.C >> 6) * (a.Cout >> 6) > 1 && blocks >= 16;
   if (a.in_bnp && (a.g.N + a.in_npg - 1) / a.in_npg > 8) return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: more than 8 BatchNorm groups");
-  if (b.inl_same_xcd && (!b.tickets || ((a.g.C >> 6) * (a.Cout >> 6)) % 8)) b.inl_same_xcd = 0;
   if (b.tickets && (!b.grad || (a.g.C >> 6) * (a.Cout >> 6) > VFS_WGRAD_TICKETS || (size_t)b.nsplit * a.Cout * a.g.Ktot * 4 >= 0xFFFFFFF0ull))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: the in-launch reduction takes a gradient, at most 4096 tiles and < 4 GiB of partials");
   if (smallw) {

@@ -95,10 +95,6 @@ struct WgradArgs {
   // the first launch, left at zero.  tickets == nullptr: partials only (the caller launches wgrad_reduce).
   float* grad = nullptr;
   unsigned* tickets = nullptr;
-  // EXPERIMENT (round 6, VFS_WGRAD_INL=2): all splits of a tile run on ONE XCD (hardware workgroup b -> XCD b % 8) and hand their
-  // partials over through that XCD's L2 with plain stores and sc0 loads instead of device-scope accesses.  Correct only while the
-  // dispatcher places workgroup b on XCD b % 8 - a measurement of what a same-XCD reduction could buy, not a product path.
-  int inl_same_xcd = 0;
 };
 
 // relu(x*scale + shift) on one 16-byte vector (8 channels), rounded to bf16 exactly as bn_act_kernel does

@@ -31,19 +31,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wgt_partial_rsrc(const WgradAr
 __device__ __forceinline__ unsigned wgt_piece_off(int split, int tile, int ntiles, int NI, int i) {
   return (unsigned)(((((size_t)split * ntiles + tile) * NI + i) * 256 + threadIdx.x) * 16);
 }
-__device__ __forceinline__ void wgt_store_piece(const __amdgpu_buffer_rsrc_t& prs, unsigned off, f32x4 v, int same_xcd = 0) {
-  if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, off, 0, 0);      // (experiment: the XCD's own L2)
-  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, off, 0, VFS_SC1);
-}
-__device__ __forceinline__ u32x4 wgt_load_piece(const __amdgpu_buffer_rsrc_t& prs, unsigned off, int same_xcd) {
-  if (same_xcd) return __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, 1);      // sc0: past this CU's L1, from the XCD's L2
-  return __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, VFS_SC1);
-}
-// same-XCD experiment: hardware workgroup b (XCD b % 8) -> (tile, split) with ALL splits of a tile on one XCD; ntiles % 8 == 0
-__device__ __forceinline__ void wgt_same_xcd_map(int b, int nsplit, int& tile, int& split) {
-  const int xcd = b & 7, j = b >> 3;
-  tile = (j / nsplit) * 8 + xcd;
-  split = j - (j / nsplit) * nsplit;
+__device__ __forceinline__ void wgt_store_piece(const __amdgpu_buffer_rsrc_t& prs, unsigned off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, off, 0, VFS_SC1);
 }
 // all threads of the workgroup, after their wgt_store calls: true in the workgroup that completes tile `tile`
 __device__ __forceinline__ bool wgt_last_arriver(const WgradArgs& a, int tile) {
@@ -75,7 +64,7 @@ __device__ __forceinline__ void wgt_sum_splits(const WgradArgs& a, const __amdgp
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int i = 0; i < NP; ++i)
-        v[q][i] = wgt_load_piece(prs, off[i] == WGT_SKIP ? WGT_SKIP : off[i] + (unsigned)(s + q) * sstride, a.inl_same_xcd);
+        v[q][i] = __builtin_amdgcn_raw_buffer_load_b128(prs, off[i] == WGT_SKIP ? WGT_SKIP : off[i] + (unsigned)(s + q) * sstride, 0, VFS_SC1);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -84,7 +73,7 @@ __device__ __forceinline__ void wgt_sum_splits(const WgradArgs& a, const __amdgp
   for (; s < a.nsplit; ++s) {
     u32x4 v[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) v[i] = wgt_load_piece(prs, off[i] == WGT_SKIP ? WGT_SKIP : off[i] + (unsigned)s * sstride, a.inl_same_xcd);
+    for (int i = 0; i < NP; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, off[i] == WGT_SKIP ? WGT_SKIP : off[i] + (unsigned)s * sstride, 0, VFS_SC1);
 #pragma unroll
     for (int i = 0; i < NP; ++i) sum[i] += __builtin_bit_cast(f32x4, v[i]);
   }

@@ -32,8 +32,7 @@ MASK_BITS = os.environ.get('VFS_MASK_BITS', '1') == '1'   # residual joins also 
 NOMASK = os.environ.get('VFS_DEBUG_NOMASK') == '1'     # what-if timing: BatchNorm backward without reading the activation as ReLU mask
 SKIP = frozenset(filter(None, os.environ.get('VFS_DEBUG_SKIP', '').split(',')))
 KSPLIT = os.environ.get('VFS_KSPLIT', '0') == '1'     # split-K for the head's Linear layers (slower as measured)
-WGRAD_INL_XCD = os.environ.get('VFS_WGRAD_INL', '0') == '2'      # EXPERIMENT: in-launch reduction through ONE XCD's L2 (ring / 3x3 halo launches with tiles % 8 == 0; relies on workgroup b -> XCD b % 8)
-WGRAD_INL = os.environ.get('VFS_WGRAD_INL', '0') in ('1', '2')      # round 6, opt-in: split-K reduction of the weight gradients inside the launch (vfs_conv_wgrad_inl) - measured SLOWER (R50 7.97 -> 10.8 ms: device-scope sc1 accesses move ~0.2 TB/s, MEASUREMENTS.md); default: kernel + wgrad_reduce
+WGRAD_INL = os.environ.get('VFS_WGRAD_INL', '0') == '1'      # round 6, opt-in: split-K reduction of the weight gradients inside the launch (vfs_conv_wgrad_inl) - measured SLOWER (R50 7.97 -> 10.8 ms: device-scope sc1 accesses move ~0.2 TB/s, MEASUREMENTS.md); default: kernel + wgrad_reduce
 
 
 class ConvUnit:
@@ -72,8 +71,6 @@ class Engine:
         self._wtables = {}
         self._p2p, self._p2p_tried = None, False      # SyncBN statistic exchange over xGMI (vfs_amd/p2p.py), set up lazily
         self.generation = 0  # bumped whenever a persistent buffer is (re)allocated: recorded launch chains hold raw pointers
-        if WGRAD_INL_XCD:
-            self.lib.set_option(b'wgrad_inl_same_xcd', 1)
         for kv in filter(None, os.environ.get('VFS_OPTS', '').split(',')):      # kernel A/B knobs: "name=value,..."
             name, value = kv.split('=')
             self.lib.set_option(name.strip().encode(), int(value))
@@ -736,10 +733,6 @@ class Engine:
         halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
         inl = (WGRAD_INL and not self.defer_wgrad and u.cin % 4 == 0 and ((ktot + 127) // 128) * (u.cout // 64) <= self.n_wgrad_tickets)
-        if inl and WGRAD_INL_XCD:      # only the launches the same-XCD experiment covers; the others keep kernel + wgrad_reduce
-            tiles = ((u.cin // 64) * (u.cout // 64) if halo is not None else
-                     ((ktot // 128) * (u.cout // 128) if (u.k == 1 and u.stride == 1 and u.pad == 0 and ktot % 128 == 0 and u.cout % 128 == 0) else 0))
-            inl = tiles > 0 and tiles % 8 == 0
         partial = ((self.ws('ws.wgrad', wgrad_inl_floats(nsplit, u.cout, ktot), torch.float32, dev) if inl else self.wgrad_partial(u, nsplit, u.cout, ktot, dev))
                    if u.weight.requires_grad else None)
         flops = 2.0 * M * u.cout * ktot
