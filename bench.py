@@ -101,7 +101,7 @@ def stage_cuda_collectives_through_host():
 
 
 # kernel name (prefix after "void ") -> bench.py's family label, for the committed rocprofv3 --stats CSV of the TIMED schedule
-KERNEL_FAMILY = (('conv_igemm_kernel', 'conv_igemm'), ('conv_skinny_kernel', 'conv_igemm'), ('conv_pw_kernel', 'conv_igemm'), ('conv3x3_halo_kernel', 'conv3x3_halo'), ('stem_fwd_direct_kernel', 'stem_fwd'),
+KERNEL_FAMILY = (('conv_igemm_kernel', 'conv_igemm'), ('conv_skinny_kernel', 'conv_igemm'), ('conv_pw_kernel', 'conv_igemm'), ('linear_bn_act_kernel', 'conv_igemm'), ('conv3x3_halo_kernel', 'conv3x3_halo'), ('stem_fwd_direct_kernel', 'stem_fwd'),
                  ('conv_wgrad_kernel', 'conv_wgrad'), ('conv_wgrad_ring_kernel', 'conv_wgrad'), ('conv3x3_wgrad_halo_kernel', 'conv3x3_wgrad_halo'), ('stem_wgrad_fused_kernel', 'stem_wgrad'),
                  ('wgrad_reduce_', 'wgrad_reduce'), ('bn_act_kernel', 'bn_act'), ('bn_bwd_apply_kernel', 'bn_bwd_apply'),
                  ('bn_bwd_reduce_kernel', 'bn_bwd_reduce'), ('stem_pool_bn_bwd_reduce', 'bn_bwd_reduce'), ('bn_reduce_', 'bn_stats'),

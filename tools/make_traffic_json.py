@@ -9,7 +9,7 @@ import os
 import sys
 
 CLASSES = {   # bench.py's Engine.timed() classes (= kernel families) -> kernels launched under them
-    'conv_igemm': ('conv_igemm_kernel', 'conv_skinny_kernel', 'conv_pw_kernel'),
+    'conv_igemm': ('conv_igemm_kernel', 'conv_skinny_kernel', 'conv_pw_kernel', 'linear_bn_act_kernel'),
     'conv3x3_halo': ('conv3x3_halo_kernel',),
     'stem_fwd': ('stem_fwd_direct_kernel',),
     'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_ring_kernel'),          # (the table-driven reduction of the partials is its own class)
