@@ -180,10 +180,11 @@ int vfs_bn_bwd_apply_fin(const vfs_bf16* g, const vfs_bf16* y, const vfs_bf16* x
  * kernels' 128-pixel statistics rows: for SMALL groups that are not multiples of 128 rows (the head's BN1d layers,
  * sim_siam_head.py:78-111, 32 rows per view on the ResNet-50 config), so that ONE conv launch covers all groups */
 /* Round 6 - nn.Linear + BatchNorm1d (training statistics) + [ReLU] of the SimSiam head in ONE launch (sim_siam_head.py:78-111: the
- * projector / predictor units Linear -> BN -> ReLU on M = G * mpg <= 64 rows, G <= 4 views, mpg % 8 == 0, K % 128 == 0, C % 16 == 0):
+ * projector / predictor units Linear -> BN -> ReLU on M = G * mpg <= 256 rows, G <= 4 views, K % 128 == 0, C % 16 == 0):
  * raw = x wf^T + bias (bf16, kept for the backward), statistics of the stored values per view, act = [relu](raw * scale + shift),
- * bnp / sums / running statistics as vfs_bn_stats_raw_finalize writes them - the same bits as vfs_conv_fwd +
- * vfs_bn_stats_raw_finalize + vfs_bn_act, two dependent launches less per unit.  Single-GPU path (SyncBN keeps the exchange). */
+ * bnp / sums / running statistics as vfs_bn_stats_raw_finalize writes them - for <= 128 rows (where vfs_conv_fwd runs the skinny GEMM)
+ * the same bits as vfs_conv_fwd + vfs_bn_stats_raw_finalize + vfs_bn_act, above that equal up to the K order of the GEMM; two
+ * dependent launches less per unit.  Single-GPU path (SyncBN keeps the exchange). */
 int vfs_linear_bn_act(const vfs_bf16* x, const vfs_bf16* wf, const float* bias, const float* gamma, const float* beta,
                       vfs_bf16* raw, vfs_bf16* act, float* bnp, double* sums, float* running_mean, float* running_var, int M,
                       int K, int C, int mpg, int relu, double count, float eps, float momentum, vfs_stream_t stream);

@@ -253,9 +253,11 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(ConvArgs a) {
 // lane order - the same bits), scale / shift, running statistics group after group, and y = relu(q * scale + shift) exactly as
 // bn_act_kernel computes it.  Outputs: raw (the backward needs it), act, bnp, sums, running statistics.
 #define LINBN_MAXG 4
+// NT = 16-row tiles per workgroup (4: <= 64 rows, the ResNet-50 config; 8 / 16: <= 128 / 256 rows, the ResNet-18 config's 2 x 128)
+template <int NT>
 __global__ __launch_bounds__(256) void linear_bn_act_kernel(LinBnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sAcc[4][4][64][4];
-  __shared__ float sRaw[64][16];
+  __shared__ __attribute__((aligned(16))) float sAcc[4][NT][64][4];
+  __shared__ float sRaw[NT * 16][16];
   __shared__ double sh[8][2][16];
   __shared__ float sCoef[LINBN_MAXG][2][16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -264,31 +266,33 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(LinBnArgs a) {
   const int c0 = blockIdx.x * 16;
   const int kq = K >> 2;                                  // K % 128 == 0: whole 32-deep steps per wave
   const bf16_t* wrow = a.w + (size_t)(c0 + lr) * K + wave * kq + lq * 8;
-  const bf16_t* xr[4];
+  const bf16_t* xr[NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xr[i] = a.x + (size_t)min(16 * i + lr, M - 1) * K + wave * kq + lq * 8;      // rows past M: clamped, never stored
-  f32x4 acc[4];
+  for (int i = 0; i < NT; ++i) xr[i] = a.x + (size_t)min(16 * i + lr, M - 1) * K + wave * kq + lq * 8;      // rows past M: clamped, never stored
+  f32x4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int steps = kq >> 5;
 #pragma unroll 2
   for (int s = 0; s < steps; ++s) {
     const bf16x8 af = *reinterpret_cast<const bf16x8*>(wrow + s * 32);
-    bf16x8 b[4];
+    bf16x8 b[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(xr[i] + s * 32);
+    for (int i = 0; i < NT; ++i) b[i] = *reinterpret_cast<const bf16x8*>(xr[i] + s * 32);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[i], acc[i], 0, 0, 0);
+    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[i], acc[i], 0, 0, 0);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&sAcc[wave][i][lane][0]) = acc[i];
+  for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(&sAcc[wave][i][lane][0]) = acc[i];
   __syncthreads();
-  // wave w finishes row tile w: lane = (channel quad lq, row lr); the K quarters add up in wave order (as conv_skinny_kernel)
-  const int m = 16 * wave + lr, cq = lq * 4;
-  {
-    f32x4 v = *reinterpret_cast<const f32x4*>(&sAcc[0][wave][lane][0]);
+  // wave w finishes row tiles w, w + 4, ...: lane = (channel quad lq, row lr); the K quarters add up in wave order (as conv_skinny_kernel)
+  const int cq = lq * 4;
 #pragma unroll
-    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&sAcc[w][wave][lane][0]);
+  for (int ti = 0; ti < NT / 4; ++ti) {
+    const int tile = wave + 4 * ti, m = 16 * tile + lr;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&sAcc[0][tile][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&sAcc[w][tile][lane][0]);
     if (m < M) {
       if (a.bias) {
 #pragma unroll
@@ -348,7 +352,10 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(LinBnArgs a) {
     if (a.rv) a.rv[c] = rv;
   }
   __syncthreads();
-  if (m < M) {      // y = [relu](q * scale + shift) on the stored values, as bn_act_kernel
+#pragma unroll
+  for (int ti = 0; ti < NT / 4; ++ti) {      // y = [relu](q * scale + shift) on the stored values, as bn_act_kernel
+    const int m = 16 * (wave + 4 * ti) + lr;
+    if (m >= M) continue;
     const int gi = m / a.mpg;
     float y[4];
 #pragma unroll
@@ -363,9 +370,11 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(LinBnArgs a) {
   }
 }
 int vfs_linear_bn_act_launch(const LinBnArgs& a, hipStream_t stream) {
-  if (a.M < 1 || a.M > 64 || a.G < 1 || a.G > LINBN_MAXG || a.mpg * a.G != a.M || a.K % 128 || a.C % 16)
-    return vfs_set_error(VFS_ERR_SHAPE, "linear_bn_act: M = G * mpg <= 64 rows, G <= 4, K % 128 == 0, C % 16 == 0");
-  hipLaunchKernelGGL(linear_bn_act_kernel, dim3(a.C / 16), dim3(256), 0, stream, a);
+  if (a.M < 1 || a.M > 256 || a.G < 1 || a.G > LINBN_MAXG || a.mpg * a.G != a.M || a.K % 128 || a.C % 16)
+    return vfs_set_error(VFS_ERR_SHAPE, "linear_bn_act: M = G * mpg <= 256 rows, G <= 4, K % 128 == 0, C % 16 == 0");
+  if (a.M <= 64) hipLaunchKernelGGL(linear_bn_act_kernel<4>, dim3(a.C / 16), dim3(256), 0, stream, a);
+  else if (a.M <= 128) hipLaunchKernelGGL(linear_bn_act_kernel<8>, dim3(a.C / 16), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(linear_bn_act_kernel<16>, dim3(a.C / 16), dim3(256), 0, stream, a);
   return vfs_check_launch("linear_bn_act");
 }
 

@@ -292,7 +292,7 @@ class Engine:
                      and os.environ.get('VFS_RAW_STATS', '1') == '1')
         # round 6: Linear + BatchNorm1d + ReLU of the head in ONE launch (vfs_linear_bn_act: the workgroup that owns 16 output channels
         # owns all <= 64 rows, so the batch statistics are local to it) instead of conv + statistics + apply
-        lin_fused = (raw_stats and u.kind == 'linear' and defer_fin and M <= 64 and G <= 4 and u.cin % 128 == 0 and u.cout % 16 == 0
+        lin_fused = (raw_stats and u.kind == 'linear' and defer_fin and M <= 256 and G <= 4 and u.cin % 128 == 0 and u.cout % 16 == 0
                      and os.environ.get('VFS_HEAD_FUSE', '1') == '1')
         if raw_stats:
             fused, want_rows = True, False
