@@ -32,7 +32,7 @@ def run(rank, world, out_path):
     torch.set_num_threads(2)
     eng = engine.Engine(lib=emu_lib())
     engine.set_shared_engine(eng)
-    model, imgs, cfg = build(8)
+    model, imgs, cfg = build(int(os.environ.get('VFS_TEST_BATCH', '8')))
     per = imgs.shape[0] // world
     local = imgs[rank * per:(rank + 1) * per]
     import vfs_amd

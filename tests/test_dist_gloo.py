@@ -9,6 +9,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(REPO, 'tests', 'dist_worker.py')
@@ -22,23 +23,33 @@ def _free_port():
     return p
 
 
-def test_two_ranks_equal_one_process(tmp_path):
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_equal_one_process(tmp_path, world):
+    """2 ranks (four videos each) and 4 ranks (four videos each) against the single process on the whole batch.
+    The forward pass is bit-identical in every partition (same statistics rows, fp64 sums).  In the backward pass the BatchNorm sums
+    of a rank are fp32 partial sums over ITS rows: they differ from the single process's in the last fp32 bit (1e-7), which flips a
+    bf16 rounding of one dx element in the head now and then - and each flip fans out through the 3x3 convolutions below it
+    (measured at 4 ranks: 1, 2, 5, 8, 32, 81, ... 19 009 differing elements layer by layer down to the stem).  With 2 ranks x 4
+    videos no flip happens on this input and the gradients agree to the fp32 summation order (2e-6); with 4 ranks they agree to
+    bf16 noise (2e-3 at the stem) - the bar there is 2e-2, and what the test pins is the plumbing: world = 4 bucket / SyncBN
+    arithmetic, replicas bit-identical to each other, loss equal to the single process's."""
     from tests.emu_util import emu_lib
     emu_lib()                                  # build once, before the ranks race for it
     single = str(tmp_path / 'single.npz')
-    env0 = dict(os.environ, WORLD_SIZE='1', RANK='0')
+    batch = str(4 * world)
+    env0 = dict(os.environ, WORLD_SIZE='1', RANK='0', VFS_TEST_BATCH=batch)
     subprocess.run([sys.executable, WORKER, single], check=True, env=env0, timeout=600)
     port = str(_free_port())
     procs, outs = [], []
-    for r in range(2):
+    for r in range(world):
         o = str(tmp_path / f'rank{r}.npz')
         outs.append(o)
-        env = dict(os.environ, WORLD_SIZE='2', RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port, VFS_TEST_BATCH=batch)
         procs.append(subprocess.Popen([sys.executable, WORKER, o], env=env))
     for p in procs:
         assert p.wait(timeout=900) == 0
     s = np.load(single)
-    r0, r1 = np.load(outs[0]), np.load(outs[1])
+    r0, r1 = np.load(outs[0]), np.load(outs[-1])
 
     def l2(a, b):
         return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
@@ -53,10 +64,10 @@ def test_two_ranks_equal_one_process(tmp_path):
             assert np.array_equal(r0[k], r1[k]), k             # both ranks hold the reduced gradient
             if np.linalg.norm(s[k]) > 1e-3:
                 worst.append((l2(r0[k], s[k]), k))
-                assert l2(r0[k], s[k]) < 1e-4, (k, l2(r0[k], s[k]))       # measured: <= 2e-6 (fp32 summation order of the split weight gradients)
+                assert l2(r0[k], s[k]) < (1e-4 if world == 2 else 2e-2), (k, l2(r0[k], s[k]))       # measured: <= 2e-6 / 5e-3
         elif k.startswith('param/'):
             assert np.array_equal(r0[k], r1[k]), k             # replicas stay in lock-step after SGD
-    print('largest relative L2 gradient differences 2 ranks vs 1 process:', sorted(worst, reverse=True)[:5])
+    print(f'largest relative L2 gradient differences {world} ranks vs 1 process:', sorted(worst, reverse=True)[:5])
 
 
 def _run_ranks(tmp_path, tag, extra_env):
