@@ -660,7 +660,8 @@ class Engine:
         """stem weight gradient; the BN-backward apply pass is folded into its operand load"""
         dev = raw.device
         ntiles = N * ((H + 7) // 8) * ((W + 15) // 16)
-        tpb = (ntiles + 1535) // 1536        # ~6 workgroups per CU: the operand gather is latency-bound
+        nb = int(os.environ.get('VFS_STEM_WGRAD_BLOCKS', '1536'))
+        tpb = (ntiles + nb - 1) // nb        # ~6 workgroups per CU: the operand gather is latency-bound
         nblocks = (ntiles + tpb - 1) // tpb
         partial = self.wgrad_partial(u, nblocks, 64, 224, dev)
         with self.on_side_stream(dev):      # ws.wgrad belongs to the side stream
