@@ -286,31 +286,33 @@ __device__ __forceinline__ float bilerp(const float* __restrict__ seg, int H, in
   return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
 }
 
+// grid (LP_POST_BLOCKS, CO): one class per workgroup (as seg_minmax_exact_kernel, csrc/exact_f32.hip)
 __global__ __launch_bounds__(256) void seg_minmax_kernel(const float* __restrict__ seg, float* __restrict__ partial, int H, int W,
                                                          int CO, int Ho, int Wo) {
   __shared__ float smn[256], smx[256];
   const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
-  const int total = Ho * Wo;
-  for (int c = 0; c < CO; ++c) {
-    float mn = INFINITY, mx = -INFINITY;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
-      const float v = bilerp(seg, H, W, CO, c, p / Wo, p % Wo, sy, sx);
-      mn = fminf(mn, v); mx = fmaxf(mx, v);
-    }
-    smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + s]);
-        smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + s]);
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      partial[((size_t)blockIdx.x * CO + c) * 2] = smn[0];
-      partial[((size_t)blockIdx.x * CO + c) * 2 + 1] = smx[0];
+  const int total = Ho * Wo, c = blockIdx.y;
+  const int stride = gridDim.x * 256, dy = stride / Wo, dx = stride - dy * Wo;
+  float mn = INFINITY, mx = -INFINITY;
+  int p = blockIdx.x * 256 + threadIdx.x, oy = p / Wo, ox = p - oy * Wo;
+  for (; p < total; p += stride) {
+    const float v = bilerp(seg, H, W, CO, c, oy, ox, sy, sx);
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+    oy += dy; ox += dx;
+    if (ox >= Wo) { ox -= Wo; ++oy; }
+  }
+  smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + s]);
+      smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + s]);
     }
     __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[((size_t)blockIdx.x * CO + c) * 2] = smn[0];
+    partial[((size_t)blockIdx.x * CO + c) * 2 + 1] = smx[0];
   }
 }
 
@@ -346,7 +348,7 @@ int vfs_seg_postprocess_launch(const float* seg, float* partial, uint8_t* label,
                                hipStream_t s) {
   if (CO < 1 || CO > LP_MAX_CLASSES) return vfs_set_error(VFS_ERR_SHAPE, "seg_postprocess: 1 <= classes <= 256");
   const int nblk = LP_POST_BLOCKS;
-  hipLaunchKernelGGL(seg_minmax_kernel, dim3(nblk), dim3(256), 0, s, seg, partial, H, W, CO, Ho, Wo);
+  hipLaunchKernelGGL(seg_minmax_kernel, dim3(nblk, CO), dim3(256), 0, s, seg, partial, H, W, CO, Ho, Wo);
   int rc = vfs_check_launch("seg_minmax");
   if (rc) return rc;
   int blocks = (Ho * Wo + 255) / 256;
