@@ -241,7 +241,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_fused_kernel(StemBwdArgs a, co
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int v = t + 256 * i, p = v >> 3, j = v & 7;
+      // a wave = 8 pixels x 8 channel vectors: the pixels of one row AND one column parity (columns 0, 2, .. 14 or 1, 3, .. 15),
+      // so that stem_dx_vec's "does this window exist" branches are uniform per wave
+      const int v = t + 256 * i, ps = v >> 3, j = v & 7;
+      const int q = ps & 15, p = (ps & ~15) | (q < 8 ? 2 * q : 2 * (q - 8) + 1);
       const int y = y0 + (p >> 4), x = x0 + (p & 15);
       float d[8];
       if (y < a.H && x < a.W) {

@@ -21,9 +21,23 @@ __device__ __forceinline__ void stem_fill_table(const StemBwdArgs& a, float* tab
   }
 }
 
+// d[8] = A*bf16(ga) + (B*x + D) for eight channels: ga as a materialising path would have stored it (bf16), then the BN backward
+// formula - two explicit fused multiply-adds, so that every kernel that rebuilds dY (gather: stem_dx_vec; scatter:
+// stem_wgrad_scatter_kernel, csrc/stem.hip) produces the same bits whatever the compiler would have contracted
+__device__ __forceinline__ void stem_dx_combine(const float* tb, const float* g, u32x4 xv, float* d) {
+  float x[8];
+  unpack8(xv, x);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = __builtin_fmaf(tb[i], round_bf(g[i]), __builtin_fmaf(tb[64 + i], x[i], tb[128 + i]));
+}
+
 // d[8] = A*bf16(ga) + B*x + D  (= scale * (ga - m1 - xhat*m2)) for pixel (n,h,w), channels c..c+7 (C = 64).
 // ga = sum over the <=4 pooling windows whose argmax is (h,w) of gp*(yp>0); all window loads are
 // issued up front (clamped addresses + predicates) so ~13 independent loads are in flight.
+// Round 6: a pixel in an EVEN row lies in ONE window row (h>>1 == (h+1)>>1), one in an even column in one window column - only
+// (odd, odd) pixels have four windows, the average is 2.25.  The windows that do not exist are skipped by branches (they used to be
+// loaded from clamped addresses and masked): callers that give a wave pixels of one row and one column parity (stem_wgrad_fused)
+// save the loads and the vector work of 44 % of the windows; the sums are the same (the skipped terms were never added).
 __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* tab, int n, int h, int w, int c, float* d) {
   const int gi = n / a.npg;
   const int hp[2] = {h >> 1, (h + 1) >> 1}, wp[2] = {w >> 1, (w + 1) >> 1};
@@ -35,12 +49,13 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
   for (int k = 0; k < 4; ++k) {
     const int hh = hp[k >> 1], ww = wp[k & 1];
     ok[k] = hh < a.Hp && ww < a.Wp && !((k >> 1) && hp[1] == hp[0]) && !((k & 1) && wp[1] == wp[0]);
-    const int hc = hh < a.Hp ? hh : a.Hp - 1, wc = ww < a.Wp ? ww : a.Wp - 1;
     code[k] = (unsigned)((h - (2 * hh - 1)) * 3 + (w - (2 * ww - 1)));
-    const size_t o = ((((size_t)n * a.Hp + hc) * a.Wp) + wc) * 64 + c;
-    id[k] = ld8(a.idx + o);
-    gv[k] = ld16(a.gp + o);
-    yv[k] = ld16(a.yp + o);
+    if (ok[k]) {      // (id / gv / yv of a window that does not exist stay unset: they are only read under the same predicate)
+      const size_t o = ((((size_t)n * a.Hp + hh) * a.Wp) + ww) * 64 + c;
+      id[k] = ld8(a.idx + o);
+      gv[k] = ld16(a.gp + o);
+      yv[k] = ld16(a.yp + o);
+    }
   }
   const u32x4 xv = ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * 64 + c);
   float g[8];
@@ -48,21 +63,16 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
   for (int i = 0; i < 8; ++i) g[i] = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float gp[8], yp[8];
-    unpack8(gv[k], gp);
-    unpack8(yv[k], yp);
+    if (ok[k]) {
+      float gp[8], yp[8];
+      unpack8(gv[k], gp);
+      unpack8(yv[k], yp);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const unsigned b = ((i < 4 ? id[k].x : id[k].y) >> (8 * (i & 3))) & 0xffu;
-      if (ok[k] && b == code[k] && yp[i] > 0.f) g[i] += gp[i];
+      for (int i = 0; i < 8; ++i) {
+        const unsigned b = ((i < 4 ? id[k].x : id[k].y) >> (8 * (i & 3))) & 0xffu;
+        if (b == code[k] && yp[i] > 0.f) g[i] += gp[i];
+      }
     }
   }
-  float x[8];
-  unpack8(xv, x);
-  const float* tb = tab + gi * STEM_TAB + c;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    // ga as a materialising path would have stored it (bf16), then the BN backward formula
-    d[i] = tb[i] * round_bf(g[i]) + (tb[64 + i] * x[i] + tb[128 + i]);
-  }
+  stem_dx_combine(tab + gi * STEM_TAB + c, g, xv, d);
 }
