@@ -633,6 +633,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
     st16(a.y + o, pack8(best));
     if (a.xpool) st16(a.xpool + o, pack8(xb));   // exact: x is bf16 already
     if (a.idx) {
+      // round 6: a pooled activation that is not positive (every tap of the window <= 0 after BatchNorm: no gradient flows) gets code
+      // 0xFF, which no position matches - the backward kernels that route the gradient by the code no longer read y for the ReLU mask
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bi[i] = best[i] > 0.f ? bi[i] : 0xFF;
       u32x2 pk;
       pk.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
       pk.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
@@ -666,13 +670,12 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(PoolBwdArgs a) {
         const unsigned code = (unsigned)(dy * 3 + dx);
         const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
         const u32x2 id = ld8(a.idx + o);
-        float gp[8], yp[8];
+        float gp[8];
         unpack8(ld16(a.gp + o), gp);
-        unpack8(ld16(a.yp + o), yp);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const unsigned b = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;
-          if (b == code && yp[i] > 0.f) g[i] += gp[i];
+          const unsigned b = ((i < 4 ? id.x : id.y) >> (8 * (i & 3))) & 0xffu;      // 0xFF: ReLU-dead pooled element (bn_relu_maxpool_kernel)
+          if (b == code) g[i] += gp[i];
         }
       }
     }

@@ -32,8 +32,8 @@ __device__ __forceinline__ void stem_dx_combine(const float* tb, const float* g,
 }
 
 // d[8] = A*bf16(ga) + B*x + D  (= scale * (ga - m1 - xhat*m2)) for pixel (n,h,w), channels c..c+7 (C = 64).
-// ga = sum over the <=4 pooling windows whose argmax is (h,w) of gp*(yp>0); all window loads are
-// issued up front (clamped addresses + predicates) so ~13 independent loads are in flight.
+// ga = sum over the <=4 pooling windows whose argmax is (h,w) of gp (windows whose pooled activation is not positive carry
+// code 0xFF and match nothing); the window loads are issued up front.
 // Round 6: a pixel in an EVEN row lies in ONE window row (h>>1 == (h+1)>>1), one in an even column in one window column - only
 // (odd, odd) pixels have four windows, the average is 2.25.  The windows that do not exist are skipped by branches (they used to be
 // loaded from clamped addresses and masked): callers that give a wave pixels of one row and one column parity (stem_wgrad_fused)
@@ -42,7 +42,7 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
   const int gi = n / a.npg;
   const int hp[2] = {h >> 1, (h + 1) >> 1}, wp[2] = {w >> 1, (w + 1) >> 1};
   u32x2 id[4];
-  u32x4 gv[4], yv[4];
+  u32x4 gv[4];
   unsigned code[4];
   bool ok[4];
 #pragma unroll
@@ -52,9 +52,8 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
     code[k] = (unsigned)((h - (2 * hh - 1)) * 3 + (w - (2 * ww - 1)));
     if (ok[k]) {      // (id / gv / yv of a window that does not exist stay unset: they are only read under the same predicate)
       const size_t o = ((((size_t)n * a.Hp + hh) * a.Wp) + ww) * 64 + c;
-      id[k] = ld8(a.idx + o);
-      gv[k] = ld16(a.gp + o);
-      yv[k] = ld16(a.yp + o);
+      id[k] = ld8(a.idx + o);      // argmax code, 0xFF where the pooled activation is not positive (bn_relu_maxpool_kernel): the
+      gv[k] = ld16(a.gp + o);      // ReLU mask travels in the code, yp is not read
     }
   }
   const u32x4 xv = ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * 64 + c);
@@ -64,13 +63,12 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (ok[k]) {
-      float gp[8], yp[8];
+      float gp[8];
       unpack8(gv[k], gp);
-      unpack8(yv[k], yp);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const unsigned b = ((i < 4 ? id[k].x : id[k].y) >> (8 * (i & 3))) & 0xffu;
-        if (b == code[k] && yp[i] > 0.f) g[i] += gp[i];
+        if (b == code[k]) g[i] += gp[i];
       }
     }
   }
