@@ -1039,6 +1039,7 @@ int vfs_stem_pool_bn_bwd_reduce_launch(const StemBwdArgs& a, int nblk, hipStream
 }
 int vfs_stem_pool_bn_bwd_apply_launch(const StemBwdArgs& a, hipStream_t s) {
   if (a.C != 64 || (a.N + a.npg - 1) / a.npg > STEM_MAX_GROUPS) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd_apply: C == 64, <= 8 groups");
+  if ((long long)a.N * a.H * a.W * 64 >= (1ll << 31)) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd_apply: 2^31 elements or more (32-bit offsets)");
   long long b = ((long long)a.N * a.H * a.W * (a.C >> 3) + 255) / 256;
   hipLaunchKernelGGL(stem_pool_bn_bwd_apply_kernel, dim3((int)(b > 8192 ? 8192 : b)), dim3(256), 0, s, a);
   return vfs_check_launch("stem_pool_bn_bwd_apply");

@@ -299,6 +299,7 @@ int vfs_stem_wgrad_fused_launch(const StemBwdArgs& a, const bf16_t* x4, int Hin,
                                 hipStream_t stream) {
   const int ntiles = vfs_stem_tiles(a.N, a.H, a.W);
   if ((a.N + a.npg - 1) / a.npg > 8) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: more than 8 BN groups");
+  if ((long long)a.N * a.H * a.W * 64 >= (1ll << 31)) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: 2^31 elements or more (32-bit offsets)");
   if (nblocks > ntiles) nblocks = ntiles;
   const int tpb = (ntiles + nblocks - 1) / nblocks;
   if ((ntiles + tpb - 1) / tpb != nblocks) return vfs_set_error(VFS_ERR_SHAPE, "stem_wgrad_fused: nblocks must equal ceil(ntiles / ceil(ntiles/nblocks))");

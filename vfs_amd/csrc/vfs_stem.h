@@ -45,18 +45,22 @@ __device__ __forceinline__ void stem_dx_vec(const StemBwdArgs& a, const float* t
   u32x4 gv[4];
   unsigned code[4];
   bool ok[4];
+  const unsigned prow = (unsigned)a.Wp * 64u;
+  const unsigned o00 = (((unsigned)n * (unsigned)a.Hp + (unsigned)hp[0]) * (unsigned)a.Wp + (unsigned)wp[0]) * 64u + (unsigned)c;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int hh = hp[k >> 1], ww = wp[k & 1];
     ok[k] = hh < a.Hp && ww < a.Wp && !((k >> 1) && hp[1] == hp[0]) && !((k & 1) && wp[1] == wp[0]);
     code[k] = (unsigned)((h - (2 * hh - 1)) * 3 + (w - (2 * ww - 1)));
-    if (ok[k]) {      // (id / gv / yv of a window that does not exist stay unset: they are only read under the same predicate)
-      const size_t o = ((((size_t)n * a.Hp + hh) * a.Wp) + ww) * 64 + c;
+    if (ok[k]) {      // (id / gv of a window that does not exist stay unset: they are only read under the same predicate)
+      // 32-bit element offsets (the launchers refuse tensors of 2^31 elements or more): the 64-bit index arithmetic of the first
+      // version was a third of the vector instructions that were left after the window skip
+      const unsigned o = o00 + ((k >> 1) ? prow : 0u) + ((k & 1) ? 64u : 0u);
       id[k] = ld8(a.idx + o);      // argmax code, 0xFF where the pooled activation is not positive (bn_relu_maxpool_kernel): the
       gv[k] = ld16(a.gp + o);      // ReLU mask travels in the code, yp is not read
     }
   }
-  const u32x4 xv = ld16(a.x + (((size_t)n * a.H + h) * a.W + w) * 64 + c);
+  const u32x4 xv = ld16(a.x + ((((unsigned)n * (unsigned)a.H + (unsigned)h) * (unsigned)a.W + (unsigned)w) * 64u + (unsigned)c));
   float g[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) g[i] = 0.f;
