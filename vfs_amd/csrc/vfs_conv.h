@@ -298,6 +298,10 @@ __device__ __forceinline__ unsigned bnfuse_load_mask(const BnBwdFuse& bn, long l
 }
 __device__ __forceinline__ void bnfuse_accum(BnFuseLane& L, const BnBwdFuse& bn, u32x4 gv, u32x4 xv, unsigned ymask) {
   // ymask: bit i <-> element i of the unit's activation is positive (residual units: bn.y given, as bits or as the tensor)
+#ifdef BNFUSE_WHATIF      // timing only (WRONG statistics): the epilogue without the per-element statistics work
+  L.s1[0] += __builtin_bit_cast(float, gv.x ^ xv.x ^ ymask);
+  return;
+#endif
   float g[8], x[8];
   unpack8(gv, g);
   unpack8(xv, x);
