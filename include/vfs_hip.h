@@ -226,8 +226,8 @@ int vfs_bn_act_fin_mask(const vfs_bf16* x, const float* partial, int bpg, const 
                         double count, float eps, float momentum, vfs_stream_t stream);
 /* stem: y = maxpool3x3/2/1(relu(bn(x)))  (resnet.py:435), idx = argmax code per element (tap 0..8 of the 3x3 window; 0xFF where
  * the pooled activation is not positive - no gradient flows there, and the kernels that route the gradient by the code
- * (vfs_maxpool_relu_bwd, vfs_stem_pool_bn_bwd_apply, vfs_stem_wgrad_fused) take the ReLU mask from it: their yp argument is kept
- * for the signature, they do not read it); xpool (optional) = the RAW x at each argmax: the BatchNorm backward of the stem then
+ * (vfs_maxpool_relu_bwd, vfs_stem_pool_bn_bwd_reduce with xpool, vfs_stem_pool_bn_bwd_apply, vfs_stem_wgrad_fused) take the ReLU mask
+ * from it: their yp argument is kept for the signature, they do not read it); xpool (optional) = the RAW x at each argmax: the BatchNorm backward of the stem then
  * never re-reads x */
 int vfs_bn_relu_maxpool(const vfs_bf16* x, const float* bnp, vfs_bf16* y, uint8_t* idx, vfs_bf16* xpool,
                         int N, int H, int W, int C, int Hp, int Wp, int npg, vfs_stream_t stream);

@@ -943,27 +943,27 @@ __global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(StemBwdArg
       // raw x at the argmax was saved by the forward pooling kernel: a pure stream over three pooled
       // tensors (pooled pixels are linear in memory), four rows in flight per lane
       for (int r = rt; r < a.ppb; r += 4 * rows) {
-        u32x4 gv[4], yv[4], xv[4];
-        bool ok[4];
+        u32x4 gv[4], xv[4];
+        u32x2 iv[4];      // the ReLU mask comes with the argmax codes (0xFF: pooled activation not positive - bn_relu_maxpool_kernel):
+        bool ok[4];       // 8 bytes per vector instead of the 16 of y
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const long long p = p0 + r + u * rows;
           ok[u] = (r + u * rows < a.ppb) && p < P;
           const size_t o = (size_t)(ok[u] ? p : p0) * a.C + c;
           gv[u] = ld16(a.gp + o);
-          yv[u] = ld16(a.yp + o);
+          iv[u] = ld8(a.idx + o);
           xv[u] = ld16(a.xp + o);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (!ok[u]) continue;
-          float g[8], yp[8], x[8];
+          float g[8], x[8];
           unpack8(gv[u], g);
-          unpack8(yv[u], yp);
           unpack8(xv[u], x);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            g[i] = yp[i] > 0.f ? g[i] : 0.f;
+            g[i] = (((i < 4 ? iv[u].x : iv[u].y) >> (8 * (i & 3))) & 0xffu) != 0xffu ? g[i] : 0.f;
             s1[i] += g[i];
             s2[i] += g[i] * ((x[i] - mean[i]) * inv[i]);
           }

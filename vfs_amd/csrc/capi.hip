@@ -471,6 +471,7 @@ int vfs_stem_pool_bn_bwd_reduce(const vfs_bf16* gp, const vfs_bf16* yp, const ui
                                 vfs_stream_t stream) {
   const long long mpg = (long long)npg * Hp * Wp;
   if (ppb <= 0 || mpg % ppb) return vfs_set_error(VFS_ERR_SHAPE, "stem_pool_bn_bwd_reduce: pooled pixels per group % ppb");
+  if (!gp || !idx || !bnp || !partial || (!x && !xpool) || (!xpool && !yp)) return vfs_set_error(VFS_ERR_ARG, "stem_pool_bn_bwd_reduce: null buffer");
   StemBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.gp = gp; a.yp = yp; a.idx = idx; a.x = x; a.xp = xpool; a.bnp = bnp; a.partial = partial;

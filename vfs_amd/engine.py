@@ -622,7 +622,7 @@ class Engine:
         nblk = (N * Hp * Wp) // ppb
         partial = self.ws('ws.bnbwd', nblk * 2 * C, torch.float32, dev)
         u.bsums = self.buf(f'{u.name}.bsums', (G, 2, C), torch.float64, dev)
-        self.timed('bn_bwd_reduce', (0.0, (2.0 * 3 + 1.0) * N * Hp * Wp * C), dev, lib.stem_pool_bn_bwd_reduce, gp, yp, idx, raw, xpool,
+        self.timed('bn_bwd_reduce', (0.0, (2.0 * 2 + 1.0) * N * Hp * Wp * C), dev, lib.stem_pool_bn_bwd_reduce, gp, yp, idx, raw, xpool,
                    u.bnp, partial, N, H, W, C, Hp, Wp, npg, ppb, s)
         if u.bn.training:
             self._bwd_sums(u, partial, G, nblk // G, C, dev)
