@@ -597,11 +597,11 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
     const int n = (int)(p / (unsigned)a.Hp);
     const int gi = n / a.npg;
     float sc[8], sh[8], best[8], xb[8];
-    int bi[8];
+    int bi[8], key[8];
     ld8f(a.bnp + (size_t)gi * 4 * a.C + c, sc);
     ld8f(a.bnp + (size_t)gi * 4 * a.C + a.C + c, sh);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; xb[i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { key[i] = (int)0x80000000u; xb[i] = 0.f; }
     // the nine window vectors are requested together (taps outside the map: clamped address, ignored below); with the loads
     // inside the bounds conditionals every tap was one dependent memory round trip
     u32x4 win[9];
@@ -618,16 +618,27 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnPoolArgs a) {
         win[dy * 3 + dx] = ld16(a.x + (((size_t)n * a.H + (hok ? h : 2 * hp)) * a.W + (ok ? w : 2 * wp)) * a.C + c);
       }
     }
+    // Round 6: value and tap travel in ONE integer key - the stored (bf16) activation in the upper half (non-negative floats order
+    // like integers; -0 sorts below +0), 8 - k below it: the larger key is the larger activation, among equals the EARLIER tap (the
+    // first maximum wins, as the scan `val > best` in ascending k did).  One compare + two selects per tap and element instead of
+    // a rounding sequence, a compare and three selects (the kernel is bound by this vector work: 9 taps x 8 channels per lane).
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {       // scan order of the taps as before: the first maximum wins
+    for (int k = 0; k < 9; ++k) {
       if (!((valid >> k) & 1u)) continue;
       float x[8];
       unpack8(win[k], x);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float val = round_bf(fmaxf(x[i] * sc[i] + sh[i], 0.f));  // pool the STORED (bf16) activation
-        if (val > best[i]) { best[i] = val; bi[i] = k; xb[i] = x[i]; }
+      for (int i = 0; i < 8; i += 2) {
+        const unsigned pv = pack2bf(fmaxf(x[i] * sc[i] + sh[i], 0.f), fmaxf(x[i + 1] * sc[i + 1] + sh[i + 1], 0.f));  // pool the STORED (bf16) activation
+        const int k0 = (int)((pv << 16) | (unsigned)(8 - k)), k1 = (int)((pv & 0xffff0000u) | (unsigned)(8 - k));
+        if (k0 > key[i]) { key[i] = k0; xb[i] = x[i]; }
+        if (k1 > key[i + 1]) { key[i + 1] = k1; xb[i + 1] = x[i + 1]; }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      best[i] = __builtin_bit_cast(float, (unsigned)key[i] & 0xffff0000u);
+      bi[i] = 8 - (key[i] & 0xf);
     }
     const size_t o = ((((size_t)n * a.Hp + hp) * a.Wp) + wp) * a.C + c;
     st16(a.y + o, pack8(best));
