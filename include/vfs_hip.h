@@ -114,9 +114,11 @@ int vfs_conv_fwd_dilated(const vfs_bf16* x, const vfs_bf16* wf, vfs_bf16* y, con
                          int dilation, vfs_stream_t stream);
 /* conv-BN-ReLU -> conv without materialising the activation: x_raw is the RAW output of the producer unit,
  * in_bnp its float[G][4][Cin] {scale, shift, mean, invstd}, in_npg images per group; relu(x*scale+shift)
- * (rounded to bf16 exactly as vfs_bn_act) is applied while the halo patch is staged, padding stays zero.
- * 3x3 / stride 1 / pad 1 on halo-tile-eligible shapes only (VFS_ERR_SHAPE otherwise); the matching weight
- * gradient reads the same raw tensor.  Replaces vfs_bn_act + vfs_conv_fwd / vfs_conv_wgrad. */
+ * (rounded to bf16 exactly as vfs_bn_act) is applied while the operand is staged, padding stays zero.
+ * 3x3 / stride 1 / pad 1 on halo-tile-eligible shapes, and (round 6: the conv2 -> conv3 edge of a bottleneck block,
+ * resnet.py:221-230) 1x1 / stride 1 / pad 0 with Cin % 64 == 0 and groups of whole 128-pixel tiles (in_npg*H*W % 128 == 0);
+ * VFS_ERR_SHAPE otherwise.  The matching weight gradient reads the same raw tensor.  Replaces vfs_bn_act + vfs_conv_fwd /
+ * vfs_conv_wgrad. */
 int vfs_conv_fwd_bnin(const vfs_bf16* x_raw, const float* in_bnp, int in_npg, const vfs_bf16* wf, vfs_bf16* y,
                       const float* bias, float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                       int KH, int KW, int stride, int pad, vfs_stream_t stream);

@@ -392,6 +392,44 @@ def test_conv_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):
         lib.conv_fwd_bnin(rawd, bnpd, npg, wf, y1, None, st1, N, H, W, Cin, H // 2, W // 2, Cout, 3, 3, 2, 1, None)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,G', [
+    (2, 8, 16, 64, 256, 2),       # one K-step (the single-buffer pipeline), 128-channel tiles, two groups
+    (4, 8, 8, 128, 512, 2),       # two K-steps, two groups of 128 pixels
+    (2, 16, 16, 256, 128, 1),     # four K-steps on the double-buffer pipeline
+    (2, 8, 8, 64, 64, 1),         # 64-channel tile
+])
+def test_conv1x1_with_folded_input_batchnorm(backend, N, H, W, Cin, Cout, G):
+    """round 6: vfs_conv_fwd_bnin / vfs_conv_wgrad_bnin for the 1x1 / stride-1 consumer (the conv2 -> conv3 edge of a bottleneck
+    block) against vfs_bn_act followed by vfs_conv_fwd / vfs_conv_wgrad on the same raw tensor: bit-identical."""
+    lib, d, dev = backend.lib, backend.d, backend.dev
+    g = torch.Generator().manual_seed(N + H + Cin + 1)
+    raw = rb(torch.randn(N, H, W, Cin, generator=g) * 1.3).to(torch.bfloat16)
+    w = rb(torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wf, _ = pack(backend, w)
+    npg = N // G
+    bnp = torch.stack([torch.rand(G, Cin, generator=g) + 0.5, torch.randn(G, Cin, generator=g) * 0.4,
+                       torch.zeros(G, Cin), torch.ones(G, Cin)], 1).contiguous()
+    M = N * H * W
+    rawd, bnpd = d(raw), d(bnp)
+    act = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+    lib.bn_act(rawd, bnpd, None, None, None, act, M, Cin, M // G, 1, None)
+    nblk = conv_stats_rows(N, 1, H, W, Cin, Cout, 1, 1, 0, H, W)
+    y0 = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+    y1 = torch.full_like(y0, float('nan'))
+    st0 = torch.full((nblk, 2, Cout), float('nan'), device=dev)
+    st1 = torch.full_like(st0, float('nan'))
+    lib.conv_fwd(act, wf, y0, None, st0, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, None)
+    lib.conv_fwd_bnin(rawd, bnpd, npg, wf, y1, None, st1, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, None)
+    assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(st1.cpu(), st0.cpu())
+    dy = d(rb(torch.randn(N, H, W, Cout, generator=g)).to(torch.bfloat16))
+    nsplit, pps = wgrad_splits(M, Cout, Cin, target_blocks=12)
+    partial = torch.zeros(nsplit, Cout, Cin, device=dev)
+    g0, g1 = torch.zeros(Cout, Cin, 1, 1, device=dev), torch.zeros(Cout, Cin, 1, 1, device=dev)
+    lib.conv_wgrad(dy, act, partial, g0, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, nsplit, pps, None)
+    lib.conv_wgrad_bnin(dy, rawd, bnpd, npg, partial, g1, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, nsplit, pps, None)
+    assert torch.equal(g1.cpu(), g0.cpu())
+
+
 BIG_CASES = [  # the layer shapes of the bench configs (per-GPU batch reduced), ragged M included
     (8, 64, 64, 64, 64, 3, 1, 1),      # R18 layer1 @256
     (8, 64, 64, 64, 128, 3, 2, 1),     # R18 layer2.0.conv1

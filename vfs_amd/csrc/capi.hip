@@ -161,9 +161,12 @@ int vfs_conv_fwd_bnin(const vfs_bf16* x_raw, const float* in_bnp, int in_npg, co
   a.src = x_raw; a.wgt = wf; a.out = y; a.add = nullptr; a.bias = bias; a.stats = stats; a.Cout = Cout; a.bn = BnBwdFuse{};
   a.in_bnp = in_bnp; a.in_npg = in_npg;
   const bool smallw = vfs_small_map(H, W);
+  // round 6: also the 1x1 / stride-1 forward of the implicit-GEMM kernel (the conv2 -> conv3 edge), groups of whole 128-pixel tiles
+  const bool pw = KH * KW == 1 && stride == 1 && pad == 0 && H == Ho && W == Wo && Cin % 64 == 0 && ((long long)in_npg * H * W) % 128 == 0;
+  if (pw) return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
   if (!vfs_option_halo || Cin % 64 || (size_t)N * H * W * Cin * 2 >= 0xFFFFFFF0ull || !vfs_conv_halo_eligible(a, GATHER_FWD) ||
       (smallw && in_npg % 2))
-    return vfs_set_error(VFS_ERR_SHAPE, "conv_fwd_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_fwd_bnin: the 3x3/stride-1 halo-tile kernel and the 1x1/stride-1 kernel fold the input BatchNorm");
   return vfs_conv_igemm_dispatch(a, GATHER_FWD, S(stream));
 }
 
@@ -252,8 +255,13 @@ int vfs_conv_wgrad_bnin(const vfs_bf16* dy, const vfs_bf16* x_raw, const float* 
   a.g = make_geom(N, H, W, Cin, Ho, Wo, KH, KW, stride, pad, KH * KW * Cin);
   a.dy = dy; a.x = x_raw; a.partial = partial; a.Cout = Cout; a.pix_per_split = pix_per_split; a.nsplit = nsplit;
   a.in_bnp = in_bnp; a.in_npg = in_npg;
+  if (KH * KW == 1 && stride == 1 && pad == 0 && H == Ho && W == Wo) {      // round 6: the 1x1 / stride-1 kernel (register-staged) folds it too
+    int rc1 = vfs_conv_wgrad_dispatch(a, GATHER_FWD, S(stream));
+    if (rc1 || !grad) return rc1;
+    return vfs_wgrad_reduce_launch(partial, grad, nsplit, Cout, a.g.Ktot, Cin, KH, KW, 0, S(stream));
+  }
   if (!vfs_option_halo || !vfs_wgrad_halo_eligible(a, GATHER_FWD) || (vfs_small_map(H, W) && in_npg % 2))
-    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_bnin: only the 3x3/stride-1 halo-tile kernel folds the input BatchNorm");
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad_bnin: the 3x3/stride-1 halo-tile kernel and the 1x1/stride-1 kernel fold the input BatchNorm");
   int rc = vfs_wgrad_halo_dispatch(a, S(stream), &nsplit);
   if (rc) return rc;
   if (!grad) {

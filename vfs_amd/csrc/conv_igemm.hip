@@ -175,6 +175,14 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
   const int kbeg = min(nk, kslice * kper), kend = min(nk, kbeg + kper);
 
   u32x4 xr[4], wr[WLD];
+  // Folded BatchNorm-apply + ReLU of the INPUT (ConvArgs::in_bnp; round 6: the conv2 -> conv3 edge of a bottleneck block): x is
+  // the RAW output of the producer unit, relu(x * scale + shift) is applied to this thread's 8 channels of every K-step between
+  // the load and the LDS store, rounded to bf16 as bn_act_kernel rounds it - the activation tensor is never written or read.
+  // Pure 1x1 forward on the register pipelines only (the dispatcher keeps such launches off the DMA rings); a 128-pixel tile
+  // lies in one statistics group (the engine folds only when the groups are multiples of 128 pixels).
+  const bool bn_in = MODE == GATHER_FWD && PIPE < 3 && a.in_bnp != nullptr;      // uniform
+  const float* bn_in_p = bn_in ? a.in_bnp + (size_t)((m0 / (g.H * g.W)) / a.in_npg) * 4 * g.C + j * 8 : nullptr;
+  f32x4 isc0 = {0.f, 0.f, 0.f, 0.f}, isc1 = isc0, ish0 = isc0, ish1 = isc0;
   int l_cc = 0, l_ri = 0, l_si = 0, l_ti = 0;   // K-step counters of the NEXT load (uniform, no divisions)
   if (MODE != GATHER_STEM && kbeg > 0) {
     l_ti = kbeg / cpt; l_cc = kbeg - l_ti * cpt;
@@ -208,6 +216,11 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
       const unsigned off = ((xmask[i] >> ti) & 1u) ? xbase[i] + (unsigned)delta : OOB_OFFSET;
       xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
     }
+    if (bn_in) {      // pure 1x1: K-step kt is channel block kt
+      const float* p = bn_in_p + kt * 64;
+      isc0 = *reinterpret_cast<const f32x4*>(p); isc1 = *reinterpret_cast<const f32x4*>(p + 4);
+      ish0 = *reinterpret_cast<const f32x4*>(p + g.C); ish1 = *reinterpret_cast<const f32x4*>(p + g.C + 4);
+    }
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
       const unsigned off = wok[i] ? wbase[i] + (unsigned)wcol : OOB_OFFSET;
@@ -215,6 +228,11 @@ __global__ __launch_bounds__(256, PIPE >= 3 ? (BC == 64 ? 2 : 1) : (PIPE == 1 ? 
     }
   };
   auto store_tiles = [&](int buf) {
+    if (bn_in) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (xmask[i] & 1u) xr[i] = bn_relu_vec(xr[i], isc0, isc1, ish0, ish1);      // rows past M stay zero
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) st16(&sX[buf][lds_off(row0 + 32 * i, j)], xr[i]);
 #pragma unroll
@@ -443,8 +461,11 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   if (a.g.dil != 1 && mode != GATHER_FWD) return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: dilation is forward-only");
   if (a.bn.partial && (mode != GATHER_DGRAD || a.g.stride != 1))
     return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: fused BatchNorm-backward statistics need a stride-1 dgrad");
-  if (vfs_conv_skinny_eligible(a, mode)) return vfs_conv_skinny_dispatch(a, stream);   // at most 128 rows (conv_pw.hip)
-  if (vfs_conv_pw_eligible(a, mode)) return vfs_conv_pw_dispatch(a, mode, stream);   // persistent kernel (conv_pw.hip)
+  if (a.in_bnp && !(mode == GATHER_FWD && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 && a.g.H == a.g.Ho && a.g.W == a.g.Wo &&
+                    a.in_npg > 0 && ((long long)a.in_npg * a.g.H * a.g.W) % 128 == 0 && a.ksplit <= 1))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_igemm: the input BatchNorm folds into the 1x1 / stride-1 forward only, groups of whole 128-pixel tiles");
+  if (!a.in_bnp && vfs_conv_skinny_eligible(a, mode)) return vfs_conv_skinny_dispatch(a, stream);   // at most 128 rows (conv_pw.hip)
+  if (!a.in_bnp && vfs_conv_pw_eligible(a, mode)) return vfs_conv_pw_dispatch(a, mode, stream);   // persistent kernel (conv_pw.hip)
   // 128-channel tiles, unless that leaves the chip under-filled (deep stages: 16x16 / 8x8 maps, the head): with fewer than
   // igemm_narrow_below tiles the 64-channel tile doubles the workgroups - two latency-bound K chains per CU instead of one
   const long long tiles128 = (long long)((a.g.M + 127) / 128) * ((a.Cout + 127) / 128);
@@ -456,7 +477,7 @@ int vfs_conv_igemm_dispatch(const ConvArgs& a_in, int mode, hipStream_t stream) 
   const long long tiles = (long long)((a.g.M + 127) / 128) * ((a.Cout + bc - 1) / bc);
   const bool ring = vfs_option_igemm_ring_tiles > 0 && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
                     a.g.Ktot >= 256 && tiles <= vfs_option_igemm_ring_tiles && (!a.bn.partial || vfs_option_igemm_ring_fbn) &&
-                    (mode == GATHER_FWD || mode == GATHER_DGRAD);
+                    (mode == GATHER_FWD || mode == GATHER_DGRAD) && !a.in_bnp;      // (the DMA ring cannot transform what it moves)
   if (ring && vfs_option_igemm_ring_upfront && !a.bn.partial) {
     if (mode == GATHER_FWD) return wide ? launch_igemm<128, GATHER_FWD, 4>(a, stream) : launch_igemm<64, GATHER_FWD, 4>(a, stream);
     return wide ? launch_igemm<128, GATHER_DGRAD, 4>(a, stream) : launch_igemm<64, GATHER_DGRAD, 4>(a, stream);

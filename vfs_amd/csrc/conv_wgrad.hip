@@ -178,7 +178,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   };
+  // Folded BatchNorm-apply + ReLU of the input (WgradArgs::in_bnp; round 6, LIN = 1: the conv3 of a bottleneck block reading the RAW
+  // output of conv2): relu(x * scale + shift) on the lane's 8 channels between the load and the LDS store, as bn_act_kernel rounds
+  // it.  A 64-pixel step lies in one statistics group (groups are multiples of 128 pixels, splits of 64): the coefficients are
+  // reloaded when the group changes.
+  const bool bn_in = LIN == 1 && a.in_bnp != nullptr && a_ok;
+  const int bn_mpg = bn_in ? a.in_npg * g.H * g.W : 1;
+  int bn_gi = -1, st_it = 0;
+  f32x4 isc0 = {0.f, 0.f, 0.f, 0.f}, isc1 = isc0, ish0 = isc0, ish1 = isc0;
   auto store_tiles = [&](int buf) {
+    if (LIN == 1 && bn_in) {
+      const int p0 = pix_begin + st_it * 64;
+      if (p0 < g.M) {
+        const int gi = p0 / bn_mpg;      // uniform
+        if (gi != bn_gi) {
+          const float* p = a.in_bnp + (size_t)gi * 4 * g.C + a_kt * 64 + a_j * 8;
+          isc0 = *reinterpret_cast<const f32x4*>(p); isc1 = *reinterpret_cast<const f32x4*>(p + 4);
+          ish0 = *reinterpret_cast<const f32x4*>(p + g.C); ish1 = *reinterpret_cast<const f32x4*>(p + g.C + 4);
+          bn_gi = gi;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (p0 + a_pg * 4 + i < g.M) av[i] = bn_relu_vec(av[i], isc0, isc1, ish0, ish1);      // rows past M stay zero
+      }
+    }
+    ++st_it;
 #pragma unroll
     for (int i = 0; i < 4; ++i) st16(&sA[buf][(a_cj >> 3) * TILE + (a_pg * 4 + i) * WG_RS + a_j * 8], av[i]);
     if (d_active) {
@@ -455,7 +479,9 @@ int vfs_conv_wgrad_dispatch(const WgradArgs& a, int mode, hipStream_t stream) {
   const size_t rows = (size_t)a.g.M + a.pix_per_split, widest = (size_t)(a.g.C > a.Cout ? a.g.C : a.Cout);
   const bool lin = vfs_option_wgrad_lin && mode == GATHER_FWD && a.g.KH * a.g.KW == 1 && a.g.stride == 1 && a.g.pad == 0 &&
                    a.g.H == a.g.Ho && a.g.W == a.g.Wo && rows * widest * 2 < 0xFFF00000ull;
-  if (lin && vfs_option_wgrad_ring && a.g.Ktot % 128 == 0 && a.Cout % 128 == 0) {
+  if (a.in_bnp && !(lin && a.in_npg > 0 && ((long long)a.in_npg * a.g.H * a.g.W) % 128 == 0))
+    return vfs_set_error(VFS_ERR_SHAPE, "conv_wgrad: the input BatchNorm folds into the 1x1 / stride-1 kernel only, groups of whole 128-pixel tiles");
+  if (lin && vfs_option_wgrad_ring && a.g.Ktot % 128 == 0 && a.Cout % 128 == 0 && !a.in_bnp) {      // (the DMA ring cannot transform what it moves)
     WgradArgs b = a;
     const int tiles = (a.g.Ktot >> 7) * (a.Cout >> 7);
     b.xcd_swizzle = vfs_option_wgrad_xcd && tiles > 1 && tiles * a.nsplit >= 16;

@@ -87,8 +87,8 @@ struct WgradArgs {
   int Cout;
   int pix_per_split;   // multiple of 64
   int nsplit;
-  const float* in_bnp; // optional: x is a RAW conv output, relu(x*scale+shift) is applied while staging (halo kernel)
-  int in_npg;
+  const float* in_bnp = nullptr;      // optional: x is a RAW conv output, relu(x*scale+shift) is applied while staging (halo kernel; 1x1 staged kernel)
+  int in_npg = 0;
   int xcd_swizzle = 0; // generic kernel: XCD-aware logical block order (set by the dispatcher)
   // optional in-launch split-K reduction (round 6, vfs_wgrad_tail.h): the last workgroup of a (k-column, cout) tile to arrive sums the
   // tile's partials in split order and adds them to grad (reference OIHW layout); tickets: unsigned[VFS_WGRAD_TICKETS], zero before

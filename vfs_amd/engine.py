@@ -330,7 +330,7 @@ class Engine:
                            x[n0:n0 + nn_], u.wf, y[n0:n0 + nn_], part, nn_, H, W, Ho, Wo, s)
             elif in_bn is not None:     # x is the producer's RAW output: BatchNorm + ReLU folded into the operand load
                 assert (n0, nn_) == (0, N), 'folded input BatchNorm needs the single-launch (fused statistics) path'
-                self.timed('conv3x3_halo', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
+                self.timed('conv3x3_halo' if u.k == 3 else 'conv_igemm', (2.0 * nn_ * Ho * Wo * u.cout * u.k * u.k * u.cin,
                                             2.0 * (nn_ * H * W * u.cin + nn_ * Ho * Wo * u.cout + u.cout * u.k * u.k * u.cin)), dev, lib.conv_fwd_bnin,
                            x, in_bn[0], in_bn[1], u.wf, y, bias, part, nn_, H, W, u.cin, Ho, Wo, u.cout,
                            u.k, u.k, u.stride, u.pad, s)
@@ -407,7 +407,8 @@ class Engine:
         # pays only where the saved activation pass is large: the fold costs VALU work in the staging of
         # the consumer's forward and weight-gradient kernels (round-2 whole-step A/B on MI355X, threshold 48 / 32 / 16 MB:
         # ResNet-50 9.36 / 9.30 / 9.24 ms, ResNet-18 unchanged - its folded tensors are all >= 48 MB)
-        if N * H * W * u.cin * 2 < float(os.environ.get('VFS_BNACT_FUSE_MB', '16')) * (1 << 20):
+        mb = os.environ.get('VFS_BNACT_FUSE_1X1_MB', '16') if u.k == 1 else os.environ.get('VFS_BNACT_FUSE_MB', '16')
+        if N * H * W * u.cin * 2 < float(mb) * (1 << 20):
             return False
         Ng = N // G
         mpg = Ng * H * W
@@ -733,7 +734,8 @@ class Engine:
         ktot = u.k * u.k * u.cin
         halo = (N, H, W, u.cin) if wgrad_halo_eligible(N, H, W, u.cin, u.cout, u.k, u.stride, u.pad) else None
         nsplit, pps = wgrad_splits(M, u.cout, ktot, halo_geom=halo)
-        inl = (WGRAD_INL and not self.defer_wgrad and u.cin % 4 == 0 and ((ktot + 127) // 128) * (u.cout // 64) <= self.n_wgrad_tickets)
+        inl = (WGRAD_INL and not self.defer_wgrad and u.cin % 4 == 0 and ((ktot + 127) // 128) * (u.cout // 64) <= self.n_wgrad_tickets
+               and not (x_in_bn is not None and halo is None))      # (the in-launch reduction folds the input BatchNorm in the halo kernel only)
         partial = ((self.ws('ws.wgrad', wgrad_inl_floats(nsplit, u.cout, ktot), torch.float32, dev) if inl else self.wgrad_partial(u, nsplit, u.cout, ktot, dev))
                    if u.weight.requires_grad else None)
         flops = 2.0 * M * u.cout * ktot
@@ -756,7 +758,7 @@ class Engine:
                     self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad_inl, dx, x_in, inb[0], inb[1],
                                partial, wtarget, self.wgrad_tickets(dev), N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
                 elif x_in_bn is not None:     # x_in is the producer's RAW output (see conv_fwd)
-                    self.timed('conv3x3_wgrad_halo', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
+                    self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad_bnin, dx, x_in, x_in_bn[0], x_in_bn[1], partial,
                                wtarget, N, H, W, u.cin, Ho, Wo, u.cout, u.k, u.k, u.stride, u.pad, nsplit, pps, ss)
                 else:
                     self.timed('conv3x3_wgrad_halo' if halo is not None else 'conv_wgrad', (flops, wbytes), dev, lib.conv_wgrad, dx, x_in, partial, wtarget, N, H, W, u.cin, Ho,

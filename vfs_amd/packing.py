@@ -109,6 +109,11 @@ def bn_fold_eligible(N, G, H, W, Cin, Cout, k, stride, pad):
     """can conv(k, stride, pad) read the RAW output of its producer unit and apply BatchNorm + ReLU while
     staging (vfs_conv_fwd_bnin / vfs_conv_wgrad_bnin)?  Both halo kernels must take the shape and a tile
     must not straddle two statistics groups (8x8 images are tiled in pairs)."""
+    if k == 1 and stride == 1 and pad == 0:
+        # round 6: the 1x1 / stride-1 consumer (conv2 -> conv3 of a bottleneck block) on the register-staged implicit-GEMM forward and
+        # weight-gradient kernels: groups of whole 128-pixel tiles
+        return (os.environ.get('VFS_BNACT_FUSE_1X1', '1') == '1' and Cin % 64 == 0 and Cout % 64 == 0 and N % G == 0 and G <= 8
+                and ((N // G) * H * W) % 128 == 0)
     if not (conv_halo_eligible(N, H, W, Cin, Cout, k, stride, pad) and wgrad_halo_eligible(N, H, W, Cin, Cout, k, stride, pad)):
         return False
     if small_map(H, W) and (N // G) % 2:
