@@ -135,7 +135,9 @@ def test_every_stage_matches_oracle_on_engine_inputs(backend, depth, shape, extr
     if backend.name == 'emu' and depth == 50:
         pytest.skip('ResNet-50 takes 40-80 s per case on the emulator; the GPU runs these cases (the emulator runs every Bottleneck kernel '
                     'shape in tests/test_emu_conv.py / test_emu_bn.py and the ResNet-18 cases here)')
-    monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 48 MB)
+    monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # fold the input BatchNorm wherever the shapes allow (not only >= 16 MB)
+    monkeypatch.setenv('VFS_BNACT_FUSE_1X1_MB', '0')
+    monkeypatch.setenv('VFS_BNACT_FUSE_SMALL', '1')     # ... whole-image tiles included
     _every_stage(backend, depth, shape, extra, TOY_BARS)
 
 
@@ -368,6 +370,8 @@ def test_graph_replay_equals_eager(gpu_backend, monkeypatch):
     batches = [O.fill_tensor(shape, seed=100 + i, scale=2.0).to(dev) for i in range(6)]
 
     monkeypatch.setenv('VFS_BNACT_FUSE_MB', '0')     # exercise the folded-input-BatchNorm kernels at this small size too
+    monkeypatch.setenv('VFS_BNACT_FUSE_1X1_MB', '0')
+    monkeypatch.setenv('VFS_BNACT_FUSE_SMALL', '1')
 
     def run(graphs):
         monkeypatch.setenv('VFS_GRAPHS', '1' if graphs else '0')

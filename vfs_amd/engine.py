@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from ._lib import Tape, TapeLib, get_lib
 from .packing import (igemm_ksplit, bn_fold_eligible, build_pack_table, build_reduce_table, conv_halo_eligible, conv_stats_rows, wgrad_halo_eligible,
-                      wgrad_inl_floats, wgrad_splits)
+                      wgrad_inl_floats, wgrad_splits, small_map)
 
 BF16 = torch.bfloat16
 
@@ -407,6 +407,10 @@ class Engine:
         # pays only where the saved activation pass is large: the fold costs VALU work in the staging of
         # the consumer's forward and weight-gradient kernels (round-2 whole-step A/B on MI355X, threshold 48 / 32 / 16 MB:
         # ResNet-50 9.36 / 9.30 / 9.24 ms, ResNet-18 unchanged - its folded tensors are all >= 48 MB)
+        # whole-image tiles (maps of at most 8x8): the fold is a loss (ResNet-18 layer4 at 256^2, 17 MB: step 6.90 with, 6.82 without -
+        # profiles/r06_fold3x3_threshold_step_ab.txt); VFS_BNACT_FUSE_SMALL=1 keeps it (tests exercise the kernels through the engine)
+        if u.k == 3 and small_map(H, W) and os.environ.get('VFS_BNACT_FUSE_SMALL', '0') != '1':
+            return False
         mb = os.environ.get('VFS_BNACT_FUSE_1X1_MB', '16') if u.k == 1 else os.environ.get('VFS_BNACT_FUSE_MB', '16')
         if N * H * W * u.cin * 2 < float(mb) * (1 << 20):
             return False
