@@ -15,7 +15,7 @@ extern "C" {
 
 /* tuning knobs for A/B measurements: "halo" (1 = 3x3/stride-1 convs use the halo-tile kernels),
  * "stem_direct", "stem_blocks" (grid cap of the direct stem kernel, 0 = default), "bn_ticket",
- * "igemm_onek" (single-buffer implicit-GEMM variant: 0 never, 1 one-K-step problems, 2 every 1x1 (default), 3 all),
+ * "igemm_onek" (single-buffer implicit-GEMM variant: 0 never, 1 one-K-step problems, 2 every 1x1, 3 all (default since round 6)),
  * "igemm_ring_tiles" (1x1 problems with at most this many tiles use the LDS-DMA ring, default 512, 0 = off),
  * "igemm_ring_upfront" (ring variant: all fragment reads of a K-step before its MFMAs; default 0: measured, no gain),
  * "igemm_ring_fbn" (the ring also for dgrads with fused BatchNorm-backward statistics, default 1),

@@ -425,7 +425,7 @@ int vfs_option_igemm_ring_fbn = 1;      // the DMA ring also for dgrads with fus
 int vfs_option_igemm_ring_tiles = 512;   // DMA-ring variant for 1x1 problems with at most this many tiles (0: off)
 int vfs_option_igemm_ring_gather = 0;      // DMA ring for GATHERED problems (3x3 / strided forward, stride-1 and stride-2 dgrad classes) with at most this many tiles (0: off)
 int vfs_option_igemm_ring_mfma32 = 1;   // the pure-GEMM DMA ring on 32x32x16 MFMAs with the lean DMA issue (PIPE 5; 0: PIPE 3, A/B knob)
-int vfs_option_igemm_onek = 2;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always
+int vfs_option_igemm_onek = 3;   // single-buffer variant: 0 never, 1 for one-K-step problems (Ktot == 64), 2 every 1x1, 3 always (round 6: default, was 2: the strided / 3x3 gathers too - R18 step 6.85 -> 6.80 ms, R50 7.96 -> 7.93)
 
 template <int BC, int MODE, int PIPE = 0, bool FBN = false>
 static int launch_igemm(const ConvArgs& a, hipStream_t stream) {
