@@ -206,15 +206,16 @@ def test_conv_fwd_dgrad_wgrad(backend, N, H, W, Cin, Cout, k, stride, pad):
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,pad', [(3, 7, 7, 128, 64, 1, 1, 0), (2, 9, 11, 64, 64, 3, 2, 1), (1, 12, 12, 256, 128, 1, 1, 0)])
-def test_conv_single_buffer_variant(backend, N, H, W, Cin, Cout, k, stride, pad):
-    """the single-buffer implicit-GEMM kernel on multi-K-step problems of every kind (option igemm_onek = 3),
-    without the DMA ring taking the 1x1 cases"""
-    backend.lib.set_option(b'igemm_onek', 3)
+@pytest.mark.parametrize('onek', [3, 0])
+def test_conv_single_buffer_variant(backend, N, H, W, Cin, Cout, k, stride, pad, onek):
+    """the single-buffer implicit-GEMM kernel on multi-K-step problems of every kind (option igemm_onek = 3, the default since
+    round 6) and the double-buffer pipeline it replaced (igemm_onek = 0), without the DMA ring taking the 1x1 cases"""
+    backend.lib.set_option(b'igemm_onek', onek)
     backend.lib.set_option(b'igemm_ring_tiles', 0)
     try:
         run_conv_case(backend, N, H, W, Cin, Cout, k, stride, pad)
     finally:
-        backend.lib.set_option(b'igemm_onek', 2)
+        backend.lib.set_option(b'igemm_onek', 3)
         backend.lib.set_option(b'igemm_ring_tiles', 512)
 
 
