@@ -144,7 +144,7 @@ def wgrad_inl_floats(nsplit, Cout, Ktot):
     return nsplit * Cout * ((Ktot + 127) // 128 * 128)
 
 
-def wgrad_splits(M, Cout, Ktot, target_blocks=256, halo_geom=None):
+def wgrad_splits(M, Cout, Ktot, target_blocks=192, halo_geom=None):
     """Split-K plan for the wgrad kernels: (nsplit, pix_per_split).  halo_geom = (N, H, W, Cin)
     selects the plan of the 3x3 halo kernel (workgroup = 64 cin x 64 cout x 9 taps, split over
     128-pixel spatial tiles)."""
@@ -154,12 +154,12 @@ def wgrad_splits(M, Cout, Ktot, target_blocks=256, halo_geom=None):
         colblocks = (Cin // 64) * (Cout // 64)
         # every workgroup writes a 9x64x64 fp32 partial (147 KB): keep ~2 workgroups per CU so
         # the split-K traffic (blocks x 147 KB, written then re-read) stays well below the MFMA time
-        tb = int(os.environ.get('VFS_WGRAD_TB', 256))   # whole-step A/B on MI355X (the kernels run beside the dgrad chain): 256 > 128 > 512 (R50 9.86 -> 9.51 ms with TBG 256)
+        tb = int(os.environ.get('VFS_WGRAD_TB', 192))   # whole-step A/B on MI355X (the kernels run beside the dgrad chain): round 2: 256 > 128 > 512; round 6 (leaner main chain): 192 > 256 > 384 (R18 6.84 -> 6.79 ms)
         nsplit = max(1, min(ntiles, (tb + colblocks - 1) // colblocks))
         tps = (ntiles + nsplit - 1) // nsplit
         nsplit = (ntiles + tps - 1) // tps
         return nsplit, tps * 128
-    target_blocks = int(os.environ.get('VFS_WGRAD_TBG', target_blocks))
+    target_blocks = int(os.environ.get('VFS_WGRAD_TBG', target_blocks))      # round 6 re-tune: 192 (R50 7.95 -> 7.88 ms; 160 level, 128 / 256 / 384 slower)
     nkb = (Ktot + 127) // 128
     ncb = Cout // (128 if Cout % 128 == 0 else 64)
     # round 6 A/B knobs: a target of their own for the layers with few tiles (large maps: the operands dwarf the partials, more
